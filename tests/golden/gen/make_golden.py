@@ -1,0 +1,345 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from
+/root/reference) on CPU fp32.  BUILD CONTAINER ONLY -- the reference does not
+exist on the GPU box; the committed .npz files are what travels.
+
+    python tests/golden/gen/make_golden.py
+
+Weights come from tests/golden/filler.py (closed form, keyed by state_dict
+name), inputs from filler.make_batch(seed,...) or seeded torch generators, so
+only seeds + outputs are stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, GOLD)
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+import filler  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def ref_args(**over):
+    sys.argv = ["2_train.py", "--input-types", "vslt_img_txt", "--model", "tri_mbt_vsltcls",
+                "--modality-inclusion", "train-missing_test-missing", "--lr-init", "1e-5",
+                "--output-type", "intubation", "--batch-size", "4", "--transformer-num-layers", "2",
+                "--vslt-type", "TIE", "--model-types", "detection", "--imgtxt-time", "1",
+                "--mbt-only-vslt", "1", "--multiimages", "0", "--img-pretrain", "No", "--dropout", "0.0"]
+    from control.config import args
+    args.device = torch.device("cpu")
+    for k, v in over.items():
+        setattr(args, k, v)
+    return args
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("wrote", name, {k: tuple(v.shape) for k, v in out.items()})
+
+
+def load_filled(module, prefix=""):
+    sd = module.state_dict()
+    module.load_state_dict({k: filler.fill_tensor(prefix + k, v) for k, v in sd.items()})
+
+
+ROWSTEP = 5   # goldens keep every 5th token row of large activations (inputs are re-made from seeds)
+
+
+def digest(t: torch.Tensor):
+    """L2 norm + 8 strided samples."""
+    f = t.detach().reshape(-1).double()
+    idx = torch.linspace(0, f.numel() - 1, 8).long()
+    return torch.cat([f.norm().view(1), f[idx]]).numpy()
+
+
+# ------------------------------------------------------------------ g1/g2/g3
+def gen_blocks():
+    from builder.models.src.transformer.attention import MultiHeadAttention
+    from builder.models.src.transformer.module import LayerNorm
+    from builder.models.src.transformer.encoder import TransformerEncoderLayer
+    from builder.models.src.transformer.utils import get_attn_pad_mask
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    mha = MultiHeadAttention(256, 4)
+    load_filled(mha, "g1.")
+    for N, lens in ((54, [54, 4, 30, 7]), (133, [133, 4, 5, 90]), (261, [261, 200, 4, 64])):
+        x = torch.randn(4, N, 256, generator=g, requires_grad=True)
+        mask = get_attn_pad_mask(x, torch.tensor(lens), N)
+        y, _ = mha(x, x, x, mask)
+        w = torch.randn(y.shape, generator=g)
+        (y * w).sum().backward()
+        out[f"mha{N}_len"], out[f"mha{N}_y"] = torch.tensor(lens), y[:, ::ROWSTEP]
+        out[f"mha{N}_dx"] = x.grad[:, ::ROWSTEP]
+        out[f"mha{N}_dWq"] = digest(mha.query_proj.linear.weight.grad)
+        out[f"mha{N}_dbv"] = mha.value_proj.linear.bias.grad.clone()
+        mha.zero_grad()
+    # fully masked rows (kv_len 0): uniform softmax over all N keys
+    x = torch.randn(2, 40, 256, generator=g)
+    mask = get_attn_pad_mask(x, torch.tensor([0, 17]), 40)
+    out["mha_full_y"] = mha(x, x, x, mask)[0][:, ::ROWSTEP]
+    # unmasked
+    out["mha_nomask_y"] = mha(x, x, x, None)[0][:, ::ROWSTEP]
+    ln = LayerNorm(256)
+    load_filled(ln, "g2.")
+    z = (torch.randn(3, 17, 256, generator=g) * 2 + 0.3).requires_grad_()
+    y = ln(z)
+    w = torch.randn(y.shape, generator=g)
+    (y * w).sum().backward()
+    out.update(ln_y=y, ln_dz=z.grad, ln_dgamma=ln.gamma.grad, ln_dbeta=ln.beta.grad)
+    lay = TransformerEncoderLayer(256, 4, 1024, 0.0)
+    load_filled(lay, "g3.")
+    x = torch.randn(3, 70, 256, generator=g, requires_grad=True)
+    lens = torch.tensor([70, 9, 33])
+    y, _ = lay(x.clone(), get_attn_pad_mask(x, lens, 70))
+    w = torch.randn(y.shape, generator=g)
+    (y * w).sum().backward()
+    out.update(lay_len=lens, lay_y=y[:, ::ROWSTEP], lay_dx=x.grad[:, ::ROWSTEP],
+               lay_dW1=digest(lay.feed_forward.w_1.weight.grad), lay_dgamma_attn=lay.attention_prenorm.gamma.grad,
+               lay_dWk=digest(lay.self_attention.key_proj.linear.weight.grad))
+    save("blocks", **out)
+
+
+# ------------------------------------------------------------------------ g4
+def gen_encoder():
+    from builder.models.src.transformer.mbt_encoder import TrimodalTransformerEncoder_MBT
+    out = {}
+    B, T, L = 4, 20, 3
+    case = 0
+    for vsltonly in (0, 1):
+        for resb in (False, True):
+            for fstart in (0, 1):
+                for multi in (0, 1):
+                    g = torch.Generator().manual_seed(100 + case)
+                    enc = TrimodalTransformerEncoder_MBT(batch_size=B, n_modality=3, bottlenecks_n=4,
+                                                         fusion_startidx=fstart, d_input=256, resbottle=resb,
+                                                         n_layers=L, n_head=4, d_model=256, d_ff=1024, dropout=0.0,
+                                                         vsltonly=vsltonly, pe_maxlen=2500,
+                                                         use_pe=[False, False, True], mask=[True, bool(multi), True])
+                    enc.eval()
+                    load_filled(enc, "g4.")
+                    n_img = 147 if multi else 49
+                    v = torch.randn(B, T, 256, generator=g)
+                    i = torch.randn(B, n_img, 256, generator=g)
+                    t = torch.randn(B, 30, 256, generator=g)
+                    in_len = torch.tensor([T, 3, 11, 7])
+                    txt_len = torch.tensor([20, 0, 5, 0])
+                    if multi:
+                        img_len = (torch.tensor([3, 1, 0, 2]) * 49).type(torch.IntTensor)
+                    else:
+                        img_len = n_img
+                    missing = torch.tensor([0, 1, 2, 3])
+                    with torch.no_grad():
+                        outs, _ = enc(enc_outputs=[v, i, t], fixed_lengths=[T, n_img, 30],
+                                      varying_lengths=[in_len.clone(), img_len if not multi else img_len.clone(),
+                                                       txt_len + 2],
+                                      fusion_idx=None, missing=missing)
+                    tag = f"c{case}"
+                    out[tag + "_cfg"] = np.array([vsltonly, int(resb), fstart, multi, B, T, L])
+                    for m, o in enumerate(outs):
+                        out[f"{tag}_out{m}"] = o if m == 0 else o[:, ::7]
+                    if multi:
+                        out[tag + "_imgcnt"] = torch.tensor([3, 1, 0, 2])
+                    case += 1
+    out["n_cases"] = np.array(case)
+    save("encoder", **out)
+
+
+# ------------------------------------------------------------------------ g6
+def build_model(args):
+    from builder.models import get_model
+    model = get_model(args)(args)
+    sd = model.state_dict()
+    model.load_state_dict(filler.fill_state_dict(sd))
+    return model
+
+
+def gen_swin(model):
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(2, 1, 224, 224, generator=g)
+    model.img_encoder.eval()
+    with torch.no_grad():
+        y = model.img_encoder(img)
+        # intermediate: stem output and first block output, for kernel-level checks
+        stem = model.img_encoder.features[0](img)
+        s1 = model.img_encoder.features[1](stem)
+    save("swin", seed=np.array(21), feat=y, stem=stem[:, ::8, ::8, :], stage1=s1[:, ::8, ::8, :])
+
+
+# --------------------------------------------------------------------- g5/g7
+class _Logger:
+    class _Ev:
+        def __init__(self):
+            self.calls = []
+
+        def add_batch(self, t, o):
+            self.calls.append((t.detach().clone(), o.detach().clone()))
+
+    def __init__(self):
+        self.evaluator, self.lrs = self._Ev(), []
+
+    def log_lr(self, lr, it):
+        self.lrs.append((it, lr))
+
+
+class _FloatIn(torch.nn.Module):
+    """CPU has no autocast: hand the real model fp32 views of the fp16-rounded inputs."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m, self.seen = m, {}
+
+    def forward(self, *a):
+        a = [x.float() if torch.is_tensor(x) and x.dtype == torch.float16 else x for x in a]
+        self.seen["missing_num"] = a[11].clone()
+        self.seen["input_lengths_in"] = a[7].clone()
+        return self.m(*a)
+
+
+def gen_model_step(multi: int, tag: str):
+    args = ref_args(multiimages=multi, batch_size=4, transformer_num_layers=2)
+    model = build_model(args)
+    if multi == 0:
+        gen_swin(model)
+    from builder.trainer import get_trainer
+    from builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    import builder.trainer.trainer as tr
+    import math
+    torch.Tensor.cuda = lambda self, *a, **k: self          # trainer.py:77,82,84 hard .cuda()
+    args.feature_means = torch.zeros(18)
+    B, T = 4, 32
+    bt = filler.make_batch(1234, B, T, ragged=True, missing_mode="mixed", multiimages=multi)
+    model.train()
+    model.img_encoder.eval()      # see DESIGN.md: goldens keep Swin in eval (StochasticDepth off)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.lr_init, weight_decay=args.weight_decay)
+    sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=args.t_0 * 10, cycle_mult=args.t_mult,
+                                          max_lr=args.lr_init * math.sqrt(args.batch_size), min_lr=1e-6,
+                                          warmup_steps=args.t_up * 10, gamma=args.gamma)
+    crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
+    wrapped = _FloatIn(model)
+    lg = _Logger()
+    static = torch.stack([bt["gen"], bt["age"]], 1)
+    # TIE forward/grad goldens (g5) through the real submodules, before the step
+    xx = bt["x"]
+    val = model.ie_vslt(xx[:, :, 1].unsqueeze(2))
+    tim = model.ie_time(xx[:, :, 0].unsqueeze(2))
+    emb = val + tim + model.ie_feat(xx[:, :, 2].type(torch.IntTensor))
+    gw = torch.Generator().manual_seed(5)
+    w = torch.randn(emb.shape, generator=gw)
+    (emb * w).sum().backward()
+    tie = dict(tie_emb=emb, tie_w=w, tie_dWv=model.ie_vslt[0].weight.grad.clone(),
+               tie_dbt=model.ie_time[0].bias.grad.clone(), tie_dgv=model.ie_vslt[1].weight.grad.clone(),
+               tie_dF=model.ie_feat.weight.grad.clone())
+    model.zero_grad()
+    # eval-mode logits first (BatchNorm running stats, no update)
+    model.eval()
+    with torch.no_grad():
+        ev_logits, _, _ = wrapped(bt["x"][:, :int(bt["input_lengths"].max())].half(), None, None, None, None,
+                                  bt["age"], bt["gen"], bt["input_lengths"].clone(), bt["txt"],
+                                  bt["txt_lengths"].clone(), bt["img"], bt["missing_num"], None,
+                                  bt["img_time"].half(), bt["txt_time"].half(), "test", None, None)
+    model.train()
+    model.img_encoder.eval()
+    in_len = bt["input_lengths"].clone()
+    _, loss = get_trainer(args=args, iteration=1, x=bt["x"].half(), static=static, input_lengths=in_len,
+                          y=bt["y"], output_lengths=None, model=wrapped, logger=lg, device=torch.device("cpu"),
+                          scheduler=sched, optimizer=opt, criterion=crit, x_txt=bt["txt"], x_img=bt["img"],
+                          txt_lengths=bt["txt_lengths"].clone(), imgtxt_time=(bt["img_time"], bt["txt_time"]),
+                          scaler=None, missing=bt["missing"], flow_type="train", reports_tokens=None,
+                          reports_lengths=None, criterion_aux=(None, None))
+    out = dict(seed=np.array(1234), B=np.array(B), T=np.array(T), loss=np.array(loss), eval_logits=ev_logits,
+               missing_num=wrapped.seen["missing_num"], lr_after=np.array(opt.param_groups[0]["lr"]),
+               input_lengths_after=in_len)
+    names, gd, pd, nograd = [], [], [], []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(n)
+            continue
+        names.append(n)
+        gd.append(digest(p.grad))
+        pd.append(digest(p))
+    out.update(grad_names=np.array(names), grad_digest=np.stack(gd), param_digest=np.stack(pd),
+               nograd_names=np.array(nograd), bn_running_mean=model.fc_list[1].running_mean,
+               bn_running_var=model.fc_list[1].running_var)
+    if multi == 0:
+        out.update(tie)
+    # second iteration's loss (after one AdamW step) pins the update end-to-end
+    _, loss2 = get_trainer(args=args, iteration=2, x=bt["x"].half(), static=static,
+                           input_lengths=bt["input_lengths"].clone(),
+                           y=bt["y"], output_lengths=None, model=wrapped, logger=lg, device=torch.device("cpu"),
+                           scheduler=sched, optimizer=opt, criterion=crit, x_txt=bt["txt"], x_img=bt["img"],
+                           txt_lengths=bt["txt_lengths"].clone(), imgtxt_time=(bt["img_time"], bt["txt_time"]),
+                           scaler=None, missing=bt["missing"], flow_type="train", reports_tokens=None,
+                           reports_lengths=None, criterion_aux=(None, None))
+    out["loss2"] = np.array(loss2)
+    # test-flow: loss + sigmoid outputs fed to the evaluator (trainer.py:192-240)
+    model.eval()
+    _, tl = get_trainer(args=args, iteration=3, x=bt["x"].half(), static=static,
+                        input_lengths=bt["input_lengths"].clone(), y=bt["y"], output_lengths=None, model=wrapped,
+                        logger=lg, device=torch.device("cpu"), scheduler=sched, optimizer=opt, criterion=crit,
+                        x_txt=bt["txt"], x_img=bt["img"], txt_lengths=bt["txt_lengths"].clone(),
+                        imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None, missing=bt["missing"],
+                        flow_type="test", reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+    out["test_loss"] = np.array(tl)
+    out["test_sigmoid"] = lg.evaluator.calls[-1][1]
+    save(tag, **out)
+
+
+def gen_misc():
+    """missing -> missing_num patterns (trainer.py:67-77 executed verbatim through torch.unique)
+    and the LR sequence of the real scheduler."""
+    from builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    import math
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-5)
+    s = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=500, cycle_mult=2, max_lr=1e-5 * math.sqrt(64),
+                                      min_lr=1e-6, warmup_steps=50, gamma=0.5)
+    its = list(range(1, 60)) + [275, 499, 500, 501, 550, 1499, 1500, 1501, 2000, 3499, 3500, 3501]
+    lrs = []
+    for it in its:
+        s.step(it)
+        lrs.append(opt.param_groups[0]["lr"])
+    save("sched", its=np.array(its), lrs=np.array(lrs, dtype=np.float64))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["blocks", "encoder", "model", "misc", "shapes"]
+    ref_args()
+    if "blocks" in which:
+        gen_blocks()
+    if "encoder" in which:
+        gen_encoder()
+    if "misc" in which:
+        gen_misc()
+    if "model" in which:
+        gen_model_step(0, "model_step")
+        gen_model_step(1, "model_step_multi")
+
+
+def gen_shapes():
+    """state_dict key -> shape (and dtype) of the real reference module at L=2 (data fixture)."""
+    import json
+    args = ref_args(multiimages=0, batch_size=4, transformer_num_layers=2)
+    from builder.models import get_model
+    model = get_model(args)(args)
+    d = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
+    with open(os.path.join(GOLD, "state_shapes_L2.json"), "w") as f:
+        json.dump(d, f, indent=0)
+    print("wrote state_shapes_L2.json", len(d))
+
+
+if __name__ == "__main__" and "shapes" in which:
+    gen_shapes()
