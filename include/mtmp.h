@@ -1,0 +1,104 @@
+/* mtmp.h -- C ABI of libmtmp_hip.so: the MI355X (gfx950) kernels behind the tri-modal
+ * training hot path of AITRICS/Medical_Tri_Modal_Pilot (model tri_mbt_vsltcls).
+ *
+ * The reference is 100 % Python/PyTorch: there is no FFI in it to mirror.  The boundary it
+ * does have is the sequence of ATen calls made by its nn.Modules; each entry point below
+ * replaces one such chain and cites it (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers owned by the
+ *     caller (including workspaces and saved-for-backward buffers); nothing here allocates,
+ *     synchronises or keeps global state.  Calls are asynchronous on `stream` (a hipStream_t
+ *     passed as void*), re-entrant across streams/devices.
+ *   - dtype: MTMP_F32 = parity build (fp32 storage, v_mfma_f32_32x32x2_f32, exact fp32 fma
+ *     chains), MTMP_BF16 = performance build (bf16 storage, v_mfma_f32_32x32x16_bf16, fp32
+ *     accumulate / softmax / LayerNorm statistics).  Same kernels, same indexing.
+ *   - return 0 on success; non-zero = argument or launch error, text via mtmp_last_error()
+ *     (thread-local).  Row strides ("ld") are in elements.
+ *   - d_model = 256 = 4 heads x 64 is fixed on this path (tri_mbt_vsltcls.py:117,227-228).
+ */
+#ifndef MTMP_H
+#define MTMP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTMP_F32 0
+#define MTMP_BF16 1
+
+int mtmp_abi_version(void);
+const char* mtmp_last_error(void);
+
+/* Modality-aware multi-head attention forward.
+ * Replaces builder/models/src/transformer/attention.py:24-49 (bmm, /sqrt(d), masked_fill(-65504),
+ * softmax, bmm), the head split/merge of attention.py:72-82 and the key-pad mask of
+ * builder/models/src/transformer/utils.py:79-125.
+ * q,k,v: [B,N,ld_qkv] (head h = columns [64h,64h+64)); o: [B,N,ld_o]; kv_len: int32[B] valid
+ * keys per sample (NULL = unmasked; 0 = fully masked -> uniform average, as the reference);
+ * lse: float[B,H,N] out (log2 units, consumed by mtmp_attn_bwd).  If res/o_res are non-NULL,
+ * o_res = o + res (the "outputs += residual" of encoder.py:27). */
+int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res, void* o_res,
+                  float* lse, const int32_t* kv_len, int B, int N, int H, int ld_qkv, int ld_o, float scale,
+                  void* stream);
+
+/* Backward of the above: dq,dk,dv [B,N,ld_dqkv] from d_o [B,N,ld_do]; o is the forward output.
+ * delta_ws: float[B*H*N] scratch. */
+int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                  const float* lse, const int32_t* kv_len, void* dq, void* dk, void* dv, float* delta_ws, int B,
+                  int N, int H, int ld_qkv, int ld_o, int ld_do, int ld_dqkv, float scale, void* stream);
+
+/* y[M,N] = act(LN(x[M,256]) w[N,256]^T + bias): custom LayerNorm (module.py:138-144: unbiased
+ * std, eps added to std) fused into the Q/K/V projections (attention.py:60-62,68-70; w = [Wq;Wk;Wv])
+ * or the first FFN conv + ReLU (module.py:74-77).  gamma/beta/bias fp32; w in `dtype`.
+ * Optional outputs: xn[M,256] = LN(x) (dtype), stats[M,2] = (mean, 1/(std+eps)).
+ * drop_p > 0 applies nn.Dropout (module.py:77-79 drop1) to the activated output with the
+ * counter-based mask keep(seed, row*N+col); the backward regenerates it (mtmp_dropout_bwd). */
+int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, const void* w, const float* bias,
+                 void* y, void* xn, float* stats, int M, int N, int ldx, int ldy, float eps, int relu, float drop_p,
+                 unsigned seed, void* stream);
+
+/* y[M,N] = drop(act(a[M,K] w[N,K]^T + bias)) (+ res[M,N]); K % 64 == 0, N % 32 == 0.
+ * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32). */
+int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N,
+                 int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed, void* stream);
+
+/* g_out[i] = keep(seed,i) ? g_in[i]/(1-p) : 0 over n contiguous elements: backward of the epilogue
+ * dropout above (n = M*N of that call, n % 4 == 0). */
+int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long long n, unsigned seed, float p, void* stream);
+
+/* Backward of the custom LayerNorm (module.py:138-144), plus the residual-branch gradient:
+ * dz[M,256] = LNbwd(dy[M,256]; z, stats, gamma) (+ d_res); dgamma_dbeta float[512] overwritten.
+ * ws: mtmp_ln_bwd_ws_floats(M) floats. */
+int mtmp_ln_bwd_ws_floats(int M);
+int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats, const float* gamma, const void* dy,
+                const void* d_res, int ldr, void* dz, float* dgamma_dbeta, float* ws, int M, float eps, void* stream);
+
+/* TIE/UMSE event embedding (tri_mbt_vsltcls.py:59-71,183-190):
+ * out[n,256] = ReLU(LN(value*w_v+b_v)) + ReLU(LN(time*w_t+b_t)) + ftab[feature].
+ * events float[n,3] = (time, value, feature index); params float[8][256] = ie_vslt.{0.weight,0.bias,
+ * 1.weight,1.bias} then ie_time.{same}; ftab float[20][256] = ie_feat.weight. */
+int mtmp_tie_embed_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out, int n,
+                       void* stream);
+/* grads float[28][256] overwritten (8 parameter vectors in `params` order, then d ftab). */
+int mtmp_tie_bwd_ws_floats(int n);
+int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
+                       float* ws, int n, void* stream);
+
+/* Swin-T patch-embedding stem: Conv2d(1,96,4,stride 4) -> NHWC -> LayerNorm(96)
+ * (builder/models/src/swin_transformer.py:559-567,646) as an implicit GEMM.
+ * img float[n_img,1,H,W]; out [n_img,H/4,W/4,96] in `dtype`. */
+int mtmp_swin_stem_fwd(int dtype, const float* img, const float* w, const float* bias, const float* ln_w,
+                       const float* ln_b, void* out, int n_img, int H, int W, void* stream);
+
+/* Fused AdamW (2_train.py:110, torch.optim.AdamW math) over flat fp32 buffers of n elements
+ * (n % 4 == 0); optional bf16 shadow copy of the parameters; grad is multiplied by grad_scale
+ * first (1/world_size after an RCCL all-reduce SUM). */
+int mtmp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_shadow,
+                    long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTMP_H */

@@ -1,0 +1,61 @@
+"""ctypes binding of libmtmp_hip.so (C ABI declared in include/mtmp.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is
+absent this module raises at import of the first op, and every non-zero status
+from the library becomes a RuntimeError carrying mtmp_last_error().
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_uint, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmtmp_hip.so")
+
+F32, BF16 = 0, 1
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/mtmp.h
+SIGNATURES = {
+    "mtmp_abi_version": (c_int, []),
+    "mtmp_last_error": (c_char_p, []),
+    "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
+    "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
+    "mtmp_ln_gemm": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_float, c_uint, c_void_p]),
+    "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p]),
+    "mtmp_ln_bwd_ws_floats": (c_int, [c_int]),
+    "mtmp_ln_bwd": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                            c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "mtmp_tie_embed_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
+    "mtmp_tie_bwd_ws_floats": (c_int, [c_int]),
+    "mtmp_tie_embed_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
+    "mtmp_swin_stem_fwd": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
+    "mtmp_adamw_step": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 5 + [c_int, c_float, c_void_p]),
+    "mtmp_dropout_bwd": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_uint, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C medical_tri_modal_pilot_amd/csrc`). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().mtmp_last_error()
+        raise RuntimeError(f"libmtmp_hip {what} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,13 @@
+"""Model registry with the reference's contract (builder/models/__init__.py:14-51):
+``get_model(args)`` imports ``builder.models.8_missing_models.<args.model>`` and returns the
+class named ``<args.model>.upper()``; the caller constructs it as ``Model(args)``."""
+import importlib
+
+
+def get_model(args):
+    try:
+        module = importlib.import_module(__name__ + ".8_missing_models." + args.model)
+    except ModuleNotFoundError as e:
+        raise NotImplementedError(
+            f"model '{args.model}' is not part of the MI355X hot path (only tri_mbt_vsltcls is built)") from e
+    return getattr(module, args.model.upper())

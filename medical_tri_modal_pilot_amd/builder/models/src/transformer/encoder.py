@@ -1,0 +1,93 @@
+"""TransformerEncoderLayer / MultiHeadAttention of the reference
+(builder/models/src/transformer/encoder.py:8-34, attention.py:52-84) as thin hosts of the
+fused HIP path: the modules own the parameters under the reference's names; forward()
+hands them to ops.EncoderLayerFn (LN+QKV GEMM, key-masked attention, LN+FFN).
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from medical_tri_modal_pilot_amd import ops
+from .module import FeedForwardUseConv, LayerNorm, Linear
+
+_seed_counter = [0]
+
+
+def next_dropout_seed() -> int:
+    """Stateless-mask seeds: murmur-mixed (torch.initial_seed(), call counter)."""
+    _seed_counter[0] += 1
+    x = (torch.initial_seed() * 0x9E3779B1 + _seed_counter[0] * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x
+
+
+def pad_mask_to_kv_len(mask: torch.Tensor) -> torch.Tensor:
+    """[B,N,N] (or [B,1,N]) key-pad mask of utils.py:116-125 (True = padded key) -> int32 valid-key counts.
+    Such masks are always a prefix of valid keys, identical for every query row."""
+    return (~mask[:, 0, :]).sum(-1).to(torch.int32)
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, dim: int = 512, num_heads: int = 8) -> None:
+        super().__init__()
+        assert dim % num_heads == 0, "hidden_dim % num_heads should be zero."
+        self.d_head = dim // num_heads
+        self.num_heads = num_heads
+        self.query_proj = Linear(dim, dim)
+        self.key_proj = Linear(dim, dim)
+        self.value_proj = Linear(dim, dim)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model: int = 512, num_heads: int = 8, d_ff: int = 2048, dropout_p: float = 0.3) -> None:
+        super().__init__()
+        if d_model != ops.D_MODEL or num_heads != ops.N_HEAD or d_ff != 4 * d_model:
+            raise NotImplementedError("the MI355X kernels are built for d_model 256 / 4 heads / d_ff 1024 "
+                                      "(tri_mbt_vsltcls.py:117,227-228 hard-code d_model 256)")
+        self.attention_prenorm = LayerNorm(d_model)
+        self.feed_forward_prenorm = LayerNorm(d_model)
+        self.self_attention = MultiHeadAttention(d_model, num_heads)
+        self.feed_forward = FeedForwardUseConv(d_model, d_ff, dropout_p)
+        self.dropout_p = dropout_p
+        self._fused_key = None
+        self._fused = None
+
+    def _fused_weights(self, dtype):
+        """[Wq;Wk;Wv] [768,256], its bias, W1 [1024,256], W2 [256,1024] in the compute dtype; rebuilt only
+        when a parameter changed (optimizer step / load_state_dict)."""
+        a, f = self.self_attention, self.feed_forward
+        ps = [a.query_proj.linear.weight, a.key_proj.linear.weight, a.value_proj.linear.weight,
+              a.query_proj.linear.bias, a.key_proj.linear.bias, a.value_proj.linear.bias, f.w_1.weight, f.w_2.weight]
+        key = (dtype,) + tuple((p._version, p.data_ptr()) for p in ps)
+        if key != self._fused_key:
+            with torch.no_grad():
+                self._fused = (torch.cat([ps[0], ps[1], ps[2]], 0).to(dtype).contiguous(),
+                               torch.cat([ps[3], ps[4], ps[5]], 0).float().contiguous(),
+                               ps[6].reshape(ps[6].shape[0], -1).to(dtype).contiguous(),
+                               ps[7].reshape(ps[7].shape[0], -1).to(dtype).contiguous())
+            self._fused_key = key
+        return self._fused
+
+    def forward(self, inputs: torch.Tensor, self_attn_mask: Optional[torch.Tensor] = None):
+        """inputs [B,N,256] (fp32 or bf16 on the GPU); self_attn_mask: int [B] valid-key counts, or the
+        reference's bool pad mask, or None.  Returns (outputs, None) like the reference (the attention
+        matrix is never materialised)."""
+        kv_len = self_attn_mask
+        if kv_len is not None and kv_len.dtype == torch.bool:
+            kv_len = pad_mask_to_kv_len(kv_len)
+        if kv_len is not None:
+            kv_len = kv_len.to(device=inputs.device, dtype=torch.int32).contiguous()
+        a, f = self.self_attention, self.feed_forward
+        p = self.dropout_p if self.training else 0.0
+        seeds = (next_dropout_seed(), next_dropout_seed()) if p > 0 else (0, 0)
+        out = ops.EncoderLayerFn.apply(
+            inputs, kv_len, self.attention_prenorm.gamma, self.attention_prenorm.beta,
+            a.query_proj.linear.weight, a.query_proj.linear.bias, a.key_proj.linear.weight, a.key_proj.linear.bias,
+            a.value_proj.linear.weight, a.value_proj.linear.bias,
+            self.feed_forward_prenorm.gamma, self.feed_forward_prenorm.beta,
+            f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias,
+            self._fused_weights(inputs.dtype), p, seeds)
+        return out, None

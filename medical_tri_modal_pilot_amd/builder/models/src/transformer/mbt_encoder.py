@@ -1,0 +1,120 @@
+"""TrimodalTransformerEncoder_MBT -- host orchestration of the modality-aware bottleneck
+fusion (reference: builder/models/src/transformer/mbt_encoder.py:636-784).
+
+Same constructor, parameter names and forward contract as the reference.  What differs is
+how the work reaches the GPU:
+  * raggedness is an int32 valid-key count per sample and stream ("kv_len"), computed on the
+    device with no host loop (the reference builds [B,N,N] bool masks in a Python loop over
+    the batch, utils.py:87-88, and tiles them x heads);
+  * each (layer, modality) block is one ops.EncoderLayerFn (fused HIP kernels);
+  * the caller's length tensors are NOT mutated (the reference does ``varying_lengths[n] += 1``
+    in place, :704 -- nothing downstream reads them again).
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .encoder import TransformerEncoderLayer
+from .module import PositionalEncoding
+
+
+class TrimodalTransformerEncoder_MBT(nn.Module):
+    def __init__(self, batch_size: int, n_modality: int, bottlenecks_n: int, fusion_startidx: int, d_input: int,
+                 n_layers: int, n_head: int, d_model: int, d_ff: int, dropout: float = 0.1, pe_maxlen: int = 10000,
+                 resbottle: bool = False, txt_idx: int = 2, vsltonly: int = 0, mbt_bottlenecks_type: str = "skip",
+                 use_pe: list = [True, True, True], mask: list = [True, False, True],
+                 compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        if n_modality != 3:
+            # the reference module builds n_modality CLS tokens but always consumes 3 streams
+            # (IndexError at mbt_encoder.py:699 for --input-types vslt); see DESIGN.md, config 1.
+            raise ValueError("TrimodalTransformerEncoder_MBT needs --input-types vslt_img_txt (3 streams)")
+        self.vsltonly = vsltonly
+        self.mbt_bottlenecks_type = mbt_bottlenecks_type
+        self.use_pe = use_pe
+        self.n_modality = n_modality
+        self.fusion_idx = fusion_startidx
+        self.txt_idx = txt_idx
+        self.n_layers = n_layers
+        self.d_model = d_model
+        self.bottlenecks_n = bottlenecks_n
+        self.mask = mask
+        self.resbottle = resbottle
+        self.compute_dtype = compute_dtype
+        self.idx_order = torch.arange(0, batch_size).type(torch.LongTensor)
+        self.layer_norms_after_concat = nn.LayerNorm(self.d_model)       # unused by forward, kept for state_dict parity
+        self.cls_token_per_modality = nn.ParameterList(
+            [nn.Parameter(torch.randn(1, 1, d_model)) for _ in range(n_modality)])
+        self.bottlenecks = nn.Parameter(torch.randn(1, bottlenecks_n, d_model))
+        self.layer_norms_in = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(n_modality)])
+        self.positional_encoding = PositionalEncoding(d_model, max_len=pe_maxlen)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_stacks = nn.ModuleList(nn.ModuleList([
+            TransformerEncoderLayer(d_model=d_model, num_heads=n_head, d_ff=d_ff, dropout_p=dropout)
+            for _ in range(n_modality)]) for _ in range(n_layers))
+
+    # ---- integer artefacts (bit-exact with the reference) ---------------------------------
+    def key_lengths(self, varying_lengths, device) -> List[Optional[torch.Tensor]]:
+        """Valid tokens per stream INCLUDING the CLS token, before the bottleneck prefix
+        (mbt_encoder.py:703-714): +1 for CLS; text length == 3 (i.e. txt_lengths == 0) -> 0;
+        None for an unmasked stream."""
+        out = []
+        for m in range(self.n_modality):
+            if not self.mask[m]:
+                out.append(None)
+                continue
+            v = varying_lengths[m]
+            v = torch.as_tensor(v, device=device).to(torch.int64) + 1
+            if m == self.txt_idx:
+                v = torch.where(v == 3, torch.zeros_like(v), v)
+            out.append(v)
+        return out
+
+    def forward(self, enc_outputs, fixed_lengths=None, varying_lengths=None, return_attns=False, fusion_idx=None,
+                missing=None):
+        dev = enc_outputs[0].device
+        B = enc_outputs[0].size(0)
+        dt = self.compute_dtype
+        lens = self.key_lengths(varying_lengths, dev)
+        if fusion_idx is not None:
+            self.fusion_idx = fusion_idx
+        # stream input: [CLS | tokens] -> nn.LayerNorm (+ sinusoid PE) -> dropout  (:697-729)
+        streams = []
+        for m, x in enumerate(enc_outputs):
+            x = torch.cat([self.cls_token_per_modality[m].expand(B, -1, -1).to(x.dtype), x], dim=1)
+            ln = self.layer_norms_in[m]
+            y = F.layer_norm(x.float(), (self.d_model,), ln.weight, ln.bias, ln.eps)
+            if self.use_pe[m]:
+                y = y + self.positional_encoding(x.size(1))
+            streams.append(self.dropout(y).to(dt))
+        bott = self.bottlenecks.expand(B, -1, -1).float()
+        kv_plain = [None if l is None else l.to(torch.int32) for l in lens]
+        kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32) for l in lens]
+        missing = missing.to(dev).long()
+        idx = torch.arange(B, device=dev)
+        outs = streams
+        for li, layers in enumerate(self.layer_stacks):
+            ins, outs = outs, []
+            if li < self.fusion_idx:                                          # (:734-737)
+                for m, layer in enumerate(layers):
+                    outs.append(layer(ins[m], kv_plain[m])[0])
+                continue
+            last = self.vsltonly == 1 and self.n_layers == li + 1
+            b_outs = []
+            for m, layer in enumerate(layers):
+                z = torch.cat([bott.to(dt), ins[m]], dim=1)                   # [bottleneck | CLS | tokens] (:745)
+                o = layer(z, kv_fused[m])[0]
+                b_outs.append(o[:, :self.bottlenecks_n].float())
+                outs.append(o[:, self.bottlenecks_n:])
+                if last:
+                    break
+            if last:
+                break
+            # bottleneck exchange (:764-779): candidates {tri, vslt+img, vslt+txt, vslt}, gathered per sample
+            st = torch.stack(b_outs)                                          # [3,B,4,d] fp32
+            cand = torch.stack([st.mean(0), st[:2].mean(0), (st[0] + st[2]) * 0.5, st[0]])
+            new_bott = cand[missing, idx]
+            bott = (new_bott + bott) * 0.5 if self.resbottle else new_bott
+        return outs, 0

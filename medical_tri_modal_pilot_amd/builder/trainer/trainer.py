@@ -1,0 +1,88 @@
+"""One optimisation / evaluation step with the contract of the reference's
+``missing_trainer`` (builder/trainer/trainer.py:20-241): same arguments, same order of
+effects (zero_grad, forward, BCE on output.squeeze(), backward, optimizer.step,
+scheduler.step(iteration), logger.log_lr), same return ``(model, float loss)``.
+
+Differences, all required to run off-CUDA-autocast and on any device:
+  * no hard ``.cuda()`` (reference :77,82,84) -- tensors go to ``device``;
+  * no ``torch.cuda.amp.autocast()``: the model owns its compute dtype (bf16 MFMA or fp32);
+    x / img_time / txt_time still pass through fp16 rounding like 2_train.py:164 and :26-27;
+  * gradient all-reduce (DDP) is waited for inside ``optimizer.step`` when a reducer is attached.
+"""
+import torch
+
+_TEMPLATE = {
+    3: [[0., 0., 0.], [0., 0., 1.], [0., 1., 0.], [0., 1., 1.]],
+    2: [[0., 0.], [0., 1.]],
+}
+
+
+def missing_to_num(missing: torch.Tensor, fullmodal_definition: str = "txt1_img1"):
+    """rows of 0/1 flags (vslt, img, txt) -> pattern id, computed like the reference (:53-77): the batch is
+    appended to the sorted template rows and ``torch.unique(dim=0, return_inverse=True)`` gives each row
+    the index of its pattern.  Returns (missing_num[B] int64, missing rows used)."""
+    if fullmodal_definition == "txt1":
+        missing = torch.stack([missing[:, 0], missing[:, 2]]).permute(1, 0)
+    elif fullmodal_definition == "img1":
+        missing = missing[:, :2]
+    missing = missing.detach().clone().float().cpu()
+    tmpl = torch.tensor(_TEMPLATE[missing.shape[1]])
+    _, inverse = torch.unique(torch.cat([tmpl, missing], dim=0), dim=0, sorted=True, return_inverse=True)
+    return inverse[tmpl.shape[0]:].type(torch.LongTensor), missing
+
+
+def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, model, logger, device,
+                    scheduler=None, optimizer=None, criterion=None, scaler=None, flow_type=None, output_lengths=None,
+                    seq_lengths=None, x_img=None, x_txt=None, txt_lengths=None, imgtxt_time=None, missing=None,
+                    reports_tokens=None, reports_lengths=None, criterion_aux=None):
+    img_time, txt_time = imgtxt_time
+    img_time = img_time.half().float().to(device, non_blocking=True)          # fp16 rounding, trainer.py:26-27
+    txt_time = txt_time.half().float().to(device, non_blocking=True)
+    if args.vslt_type == "carryforward":
+        train_x = train_x.permute(1, 0, 2, 3)
+        data = train_x[0]
+    else:
+        max_len = int(torch.max(input_lengths))                               # ragged trim, trainer.py:41-42
+        data = train_x[:, :max_len, :]
+    data = data.half().float().to(device, non_blocking=True)                  # 2_train.py:164
+    if "rmse" in args.auxiliary_loss_type:
+        final_target = train_y[0].float().to(device, non_blocking=True)
+    else:
+        final_target = train_y.float().to(device, non_blocking=True)
+    missing_num, _ = missing_to_num(missing, args.fullmodal_definition)
+    if args.input_types == "vslt_txt":                                        # trainer.py:99-104
+        missing_num[missing_num == 2] = 0
+        missing_num[missing_num == 3] = 1
+    elif args.input_types == "vslt_img":
+        missing_num[missing_num == 1] = 0
+        missing_num[missing_num == 3] = 1
+    missing_num = missing_num.to(device, non_blocking=True)
+    static_x = static_x.permute(1, 0)
+    age = static_x[1].float().to(device, non_blocking=True)
+    gender = static_x[0].float().to(device, non_blocking=True)
+    x_txt = x_txt.to(device, non_blocking=True)
+    x_img = x_img.to(device, non_blocking=True)
+    input_lengths = input_lengths.to(device, non_blocking=True)
+    txt_lengths = txt_lengths.to(device, non_blocking=True)
+    feasible = None if output_lengths is None else output_lengths.type(torch.IntTensor).to(device, non_blocking=True)
+
+    def run_model():
+        out, _, _ = model(data, None, None, None, None, age, gender, input_lengths, x_txt, txt_lengths, x_img,
+                          missing_num, feasible, img_time, txt_time, flow_type, reports_tokens, reports_lengths)
+        return out.squeeze()
+
+    if flow_type == "train":
+        optimizer.zero_grad()
+        output = run_model()
+        loss = criterion(output, final_target)
+        loss.backward()
+        optimizer.step()
+        scheduler.step(iteration)
+        logger.log_lr(scheduler.get_lr()[0], iteration)
+    else:
+        with torch.no_grad():
+            output = run_model()
+            loss = criterion(output, final_target)
+            output = torch.sigmoid(output)
+        logger.evaluator.add_batch(final_target, output)
+    return model, loss.item()

@@ -1,0 +1,448 @@
+// Modality-aware multi-head attention for gfx950, forward + backward.
+//
+// Replaces builder/models/src/transformer/attention.py:24-84 (ScaledDotProductAttention +
+// the head split/merge of MultiHeadAttention) together with the key-pad mask of
+// builder/models/src/transformer/utils.py:79-125:
+//     per (b, h):  O = softmax(Q K^T / sqrt(64) + keymask(kv_len[b])) V
+// No N x N tensor is materialised; keys j >= kv_len[b] are never read.  A fully
+// masked sample (kv_len == 0) reproduces the reference's masked_fill(-65504) +
+// softmax result, i.e. the uniform average over all N keys.
+//
+// Layout: Q/K/V/O are [B, N, ld] with head h at columns [64h, 64h+64) ("head-major
+// free": the reference's [H*B, N, 64] permute/contiguous copies are not observable).
+// LSE is [B, H, N] fp32 in log2 units of the scaled score (internal format).
+//
+// Tiling (wave64, MFMA 32x32): one workgroup = 4 waves = 128 query rows (fwd, dQ)
+// or 128 keys (dK/dV); K/V (or Q/dO) tiles of 64 rows are staged through LDS.
+// The score tile is computed transposed (S^T = K Q^T) so that a query is a lane:
+// row max / row sum are in-register, the online-softmax rescale of O^T is a
+// per-lane multiply, and P^T is consumed by the P.V MFMA directly from the
+// accumulator registers (common.cuh: acc -> Frag).
+#include "common.cuh"
+#include <math.h>
+
+namespace {
+
+constexpr int DH = 64;       // head dim: d_model 256 / 4 heads (tri_mbt_vsltcls.py:29-30)
+constexpr int KT = 64;       // rows per LDS tile
+constexpr int LDT = DH + 8;  // padded LDS row, elements (keeps 16-byte alignment, spreads banks)
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <typename T> struct AttnArgs {
+    const T* q; const T* k; const T* v;
+    T* o; const T* res; T* o_res;
+    float* lse; const int* kv_len;
+    int B, N, H, ld_qkv, ld_o;
+    float scale;
+};
+
+// ---- LDS staging helpers (256 threads, 64-row x 64-col tile) ----------------
+// row-major copy: thread -> (row = tid>>3 (+32), 16-byte chunk = tid&7); rows >= limit are zero.
+template <typename T>
+MTMP_DEV void stage_rows(T* dst, const T* src, int ld, int row0, int limit, int tid) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = (tid >> 3) + 32 * pass;
+        const int ch = (tid & 7) * 8;
+        Frag<T> f = (row0 + row < limit) ? frag_load<T>(src + (size_t)(row0 + row) * ld + ch) : frag_zero<T>();
+        frag_store<T>(dst + row * LDT + ch, f);
+    }
+}
+template <typename T> MTMP_DEV void store_pair(T* p, T a, T b);
+template <> MTMP_DEV void store_pair<bf16>(bf16* p, bf16 a, bf16 b) {
+    *reinterpret_cast<bf16x2*>(p) = bf16x2{a, b};
+}
+template <> MTMP_DEV void store_pair<float>(float* p, float a, float b) {
+    *reinterpret_cast<f32x2*>(p) = f32x2{a, b};
+}
+// transposed copy dst[col][row]: thread -> (row pair = tid&31, 8-column group = tid>>5);
+// a wave writes 32 consecutive dwords per instruction (bank-conflict free).
+template <typename T>
+MTMP_DEV void stage_transposed(T* dst, const T* src, int ld, int row0, int limit, int tid) {
+    const int rp = (tid & 31) * 2;
+    const int cg = (tid >> 5) * 8;
+    Frag<T> fa = (row0 + rp < limit) ? frag_load<T>(src + (size_t)(row0 + rp) * ld + cg) : frag_zero<T>();
+    Frag<T> fb = (row0 + rp + 1 < limit) ? frag_load<T>(src + (size_t)(row0 + rp + 1) * ld + cg) : frag_zero<T>();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) store_pair<T>(dst + (cg + e) * LDT + rp, fa.v[e], fb.v[e]);
+}
+
+// 32x32 tile: acc += A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
+template <typename T>
+MTMP_DEV void tile_qk(f32x16& acc, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
+    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mma<T>(acc, frag_load<T>(arow + 16 * c), bf[c]);
+}
+
+// =============================== forward ====================================
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
+    T* sVt = sK + KT * LDT;                   // [DH][LDT]   dh x keys
+    const int nqt = (p.N + 127) >> 7;
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const bool uniform = kvl <= 0;            // all keys masked -> reference gives the uniform average
+    if (uniform) kvl = p.N;
+    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
+    const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
+    const int qrow = qt * 128 + wave * 32 + r;
+    Frag<T> qf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        qf[c] = (qrow < p.N) ? frag_load<T>(Qb + (size_t)qrow * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
+    f32x16 o0 = {0}, o1 = {0};
+    float m = -INFINITY, l = 0.f;
+    const float c2 = p.scale * LOG2E;
+    const int ntiles = (kvl + KT - 1) / KT;
+    for (int it = 0; it < ntiles; ++it) {
+        const int k0 = it * KT;
+        __syncthreads();
+        stage_rows<T>(sK, Kb, p.ld_qkv, k0, kvl, tid);
+        stage_transposed<T>(sVt, Vb, p.ld_qkv, k0, kvl, tid);
+        __syncthreads();
+        f32x16 st[2] = {{0}, {0}};
+        if (!uniform) {
+            tile_qk<T>(st[0], sK, r, half, qf);
+            tile_qk<T>(st[1], sK + 32 * LDT, r, half, qf);
+        }
+        if (k0 + KT > kvl) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (k0 + 32 * kb + acc_row_swz(t, half) >= kvl) st[kb][t] = -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(st[0][t], st[1][t]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * c2);
+        const float alpha = fast_exp2(m - m_new);
+        l *= alpha; o0 *= alpha; o1 *= alpha;
+        m = m_new;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float pv = fast_exp2(fmaf(st[kb][t], c2, -m));
+                l += pv;
+                st[kb][t] = pv;
+            }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag<T> pf = frag_from_acc<T>(st[kb], s);
+                const T* vrow = sVt + r * LDT + 32 * kb + 16 * s + 8 * half;
+                mma<T>(o0, frag_load<T>(vrow), pf);
+                mma<T>(o1, frag_load<T>(vrow + 32 * LDT), pf);
+            }
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (qrow < p.N) {
+        const float inv = 1.0f / l;
+        const size_t orow = ((size_t)b * p.N + qrow) * p.ld_o + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& o = dt ? o1 : o0;
+                const int d0 = 32 * dt + 8 * g + 4 * half;
+                float a0 = o[4 * g] * inv, a1 = o[4 * g + 1] * inv, a2 = o[4 * g + 2] * inv, a3 = o[4 * g + 3] * inv;
+                store4<T>(p.o + orow + d0, a0, a1, a2, a3);
+                if (p.o_res) {
+                    // residual epilogue (encoder.py:27 "outputs += residual"): the residual adds the
+                    // value of O as stored (i.e. rounded to T), like the reference's tensor add.
+                    f32x4 rv = load4<T>(p.res + orow + d0);
+                    store4<T>(p.o_res + orow + d0, round_as<T>(a0) + rv[0], round_as<T>(a1) + rv[1],
+                              round_as<T>(a2) + rv[2], round_as<T>(a3) + rv[3]);
+                }
+            }
+        if (half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m + log2f(l);
+    }
+}
+
+// =============================== backward ===================================
+template <typename T> struct AttnBwdArgs {
+    const T* q; const T* k; const T* v; const T* d_o;
+    const float* lse; const float* delta; const int* kv_len;
+    T* dq; T* dk; T* dv;
+    int B, N, H, ld_qkv, ld_do, ld_dqkv;
+    float scale;
+};
+
+// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]; one wave per token row (4 heads x 64).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* d_o, float* delta, int B, int N, int H,
+                                                         int ld_o, int ld_do) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * N) return;
+    f32x4 a = load4<T>(o + (size_t)row * ld_o + 4 * lane);
+    f32x4 g = load4<T>(d_o + (size_t)row * ld_do + 4 * lane);
+    float s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((lane & 15) == 0) {
+        const int b = row / N, q = row - b * N, hd = lane >> 4;
+        if (hd < H) delta[((size_t)b * H + hd) * N + q] = s;
+    }
+}
+
+// dQ: workgroup = 128 query rows, loops over key tiles (S^T and dP^T with the query on the lane).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]
+    T* sV = sK + KT * LDT;                    // [KT][LDT]
+    T* sKt = sV + KT * LDT;                   // [DH][LDT]  dh x keys
+    const int nqt = (p.N + 127) >> 7;
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const bool uniform = kvl <= 0;
+    if (uniform) kvl = p.N;
+    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
+    const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
+    const int qrow = qt * 128 + wave * 32 + r;
+    Frag<T> qf[4], dof[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qf[c] = (qrow < p.N) ? frag_load<T>(Qb + (size_t)qrow * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
+        dof[c] = (qrow < p.N) ? frag_load<T>(p.d_o + ((size_t)b * p.N + qrow) * p.ld_do + hd * DH + 16 * c + 8 * half)
+                              : frag_zero<T>();
+    }
+    const size_t sidx = ((size_t)b * p.H + hd) * p.N + qrow;
+    const float L2 = (qrow < p.N) ? p.lse[sidx] : INFINITY;
+    const float dl = (qrow < p.N) ? p.delta[sidx] : 0.f;
+    const float c2 = p.scale * LOG2E;
+    f32x16 dq0 = {0}, dq1 = {0};
+    const int ntiles = (kvl + KT - 1) / KT;
+    for (int it = 0; it < ntiles && !uniform; ++it) {   // uniform: scores are constants -> dQ = 0
+        const int k0 = it * KT;
+        __syncthreads();
+        stage_rows<T>(sK, Kb, p.ld_qkv, k0, kvl, tid);
+        stage_rows<T>(sV, Vb, p.ld_qkv, k0, kvl, tid);
+        stage_transposed<T>(sKt, Kb, p.ld_qkv, k0, kvl, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 st = {0}, dp = {0};
+            tile_qk<T>(st, sK + 32 * kb * LDT, r, half, qf);
+            tile_qk<T>(dp, sV + 32 * kb * LDT, r, half, dof);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const bool valid = k0 + 32 * kb + acc_row_swz(t, half) < kvl;
+                const float pv = valid ? fast_exp2(fmaf(st[t], c2, -L2)) : 0.f;
+                st[t] = pv * (dp[t] - dl);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Frag<T> dsf = frag_from_acc<T>(st, s);
+                const T* krow = sKt + r * LDT + 32 * kb + 16 * s + 8 * half;
+                mma<T>(dq0, frag_load<T>(krow), dsf);
+                mma<T>(dq1, frag_load<T>(krow + 32 * LDT), dsf);
+            }
+        }
+    }
+    if (qrow < p.N) {
+        const size_t orow = ((size_t)b * p.N + qrow) * p.ld_dqkv + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& o = dt ? dq1 : dq0;
+                const int d0 = 32 * dt + 8 * g + 4 * half;
+                store4<T>(p.dq + orow + d0, o[4 * g] * p.scale, o[4 * g + 1] * p.scale, o[4 * g + 2] * p.scale,
+                          o[4 * g + 3] * p.scale);
+            }
+    }
+}
+
+// dK/dV: workgroup = 128 keys (a wave owns 32 and keeps dK, dV in registers), loops over query tiles
+// (S and dP with the key on the lane; P^T and dS^T feed the dV / dK MFMAs from the accumulators).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sQ = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]  q x dh
+    T* sdO = sQ + KT * LDT;                   // [KT][LDT]
+    T* sQt = sdO + KT * LDT;                  // [DH][LDT]  dh x q
+    T* sdOt = sQt + DH * LDT;                 // [DH][LDT]
+    float* sL = reinterpret_cast<float*>(sdOt + DH * LDT);   // [KT] lse (log2 units), +inf past N
+    float* sD = sL + KT;                                     // [KT] delta
+    const int nkt = (p.N + 127) >> 7;
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int kt = w % nkt, bh = w / nkt, hd = bh % p.H, b = bh / p.H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const bool uniform = kvl <= 0;
+    if (uniform) kvl = p.N;
+    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
+    const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
+    const T* dOb = p.d_o + (size_t)b * p.N * p.ld_do + hd * DH;
+    const float* Lb = p.lse + ((size_t)b * p.H + hd) * p.N;
+    const float* Db = p.delta + ((size_t)b * p.H + hd) * p.N;
+    const int kw0 = kt * 128 + wave * 32;      // first key of this wave
+    const int key = kw0 + r;                   // this lane's key (column of S)
+    const bool key_ok = key < kvl;
+    f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+    if (kt * 128 < kvl) {                      // workgroup-uniform: keys past kv_len get zero gradients
+        Frag<T> kf[4], vf[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            kf[c] = key_ok ? frag_load<T>(Kb + (size_t)key * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
+            vf[c] = key_ok ? frag_load<T>(Vb + (size_t)key * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
+        }
+        const float c2 = p.scale * LOG2E;
+        const int nq = (p.N + KT - 1) / KT;
+        for (int it = 0; it < nq; ++it) {
+            const int q0 = it * KT;
+            __syncthreads();
+            stage_rows<T>(sQ, Qb, p.ld_qkv, q0, p.N, tid);
+            stage_rows<T>(sdO, dOb, p.ld_do, q0, p.N, tid);
+            stage_transposed<T>(sQt, Qb, p.ld_qkv, q0, p.N, tid);
+            stage_transposed<T>(sdOt, dOb, p.ld_do, q0, p.N, tid);
+            if (tid < KT) {
+                sL[tid] = (q0 + tid < p.N) ? Lb[q0 + tid] : INFINITY;
+                sD[tid] = (q0 + tid < p.N) ? Db[q0 + tid] : 0.f;
+            }
+            __syncthreads();
+            if (kw0 < kvl) {                   // wave-uniform
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x16 st = {0}, dp = {0};
+                    if (!uniform) tile_qk<T>(st, sQ + 32 * qb * LDT, r, half, kf);
+                    tile_qk<T>(dp, sdO + 32 * qb * LDT, r, half, vf);
+                    f32x16 ds;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int qi = 32 * qb + acc_row_swz(t, half);
+                        // uniform case: st == 0 and the forward stored lse = log2(N), so pv = 1/N
+                        const float pv = key_ok ? fast_exp2(fmaf(st[t], c2, -sL[qi])) : 0.f;
+                        st[t] = pv;
+                        ds[t] = uniform ? 0.f : pv * (dp[t] - sD[qi]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const Frag<T> pf = frag_from_acc<T>(st, s);
+                        const Frag<T> dsf = frag_from_acc<T>(ds, s);
+                        const int off = r * LDT + 32 * qb + 16 * s + 8 * half;
+                        mma<T>(dv0, pf, frag_load<T>(sdOt + off));
+                        mma<T>(dv1, pf, frag_load<T>(sdOt + off + 32 * LDT));
+                        mma<T>(dk0, dsf, frag_load<T>(sQt + off));
+                        mma<T>(dk1, dsf, frag_load<T>(sQt + off + 32 * LDT));
+                    }
+                }
+            }
+        }
+    }
+    // rows = keys (registers), cols = dh (lanes)
+    const size_t obase = (size_t)b * p.N * p.ld_dqkv + hd * DH;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int krow = kw0 + acc_row(t, half);
+        if (krow < p.N) {
+            T* dkp = p.dk + obase + (size_t)krow * p.ld_dqkv;
+            T* dvp = p.dv + obase + (size_t)krow * p.ld_dqkv;
+            dkp[r] = from_f32<T>(dk0[t] * p.scale);
+            dkp[32 + r] = from_f32<T>(dk1[t] * p.scale);
+            dvp[r] = from_f32<T>(dv0[t]);
+            dvp[32 + r] = from_f32<T>(dv1[t]);
+        }
+    }
+}
+
+template <typename T> size_t fwd_smem() { return (size_t)(KT + DH) * LDT * sizeof(T); }
+template <typename T> size_t dq_smem() { return (size_t)(2 * KT + DH) * LDT * sizeof(T); }
+template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT + 2 * DH) * LDT * sizeof(T) + 2 * KT * sizeof(float); }
+
+template <typename K> int set_smem(K kern, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) != hipSuccess) {
+            mtmp_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu) failed", bytes);
+            return MTMP_ERR_LAUNCH;
+        }
+    }
+    return MTMP_OK;
+}
+
+template <typename T>
+int launch_fwd(const void* q, const void* k, const void* v, void* o, const void* res, void* o_res, float* lse,
+               const int* kv_len, int B, int N, int H, int ld_qkv, int ld_o, float scale, hipStream_t st) {
+    AttnArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (T*)o, (const T*)res, (T*)o_res, lse, kv_len,
+                  B, N, H, ld_qkv, ld_o, scale};
+    const int nwg = ((N + 127) / 128) * H * B;
+    const size_t sm = fwd_smem<T>();
+    if (int e = set_smem(attn_fwd_kernel<T>, sm)) return e;
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(nwg), dim3(256), sm, st, a);
+    MTMP_CHECK_LAUNCH("mtmp_attn_fwd");
+    return MTMP_OK;
+}
+
+template <typename T>
+int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+               const int* kv_len, void* dq, void* dk, void* dv, float* delta, int B, int N, int H, int ld_qkv,
+               int ld_o, int ld_do, int ld_dqkv, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((B * N + 3) / 4), dim3(256), 0, st, (const T*)o, (const T*)d_o,
+                       delta, B, N, H, ld_o, ld_do);
+    MTMP_CHECK_LAUNCH("mtmp_attn_bwd(delta)");
+    AttnBwdArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, kv_len,
+                     (T*)dq, (T*)dk, (T*)dv, B, N, H, ld_qkv, ld_do, ld_dqkv, scale};
+    const int nwg = ((N + 127) / 128) * H * B;
+    if (int e = set_smem(attn_bwd_dkdv_kernel<T>, dkdv_smem<T>())) return e;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(nwg), dim3(256), dkdv_smem<T>(), st, a);
+    MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dkdv)");
+    if (int e = set_smem(attn_bwd_dq_kernel<T>, dq_smem<T>())) return e;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(nwg), dim3(256), dq_smem<T>(), st, a);
+    MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dq)");
+    return MTMP_OK;
+}
+
+bool attn_shape_ok(int B, int N, int H, int ld_a, int ld_b) {
+    return B > 0 && N > 0 && H > 0 && H <= 4 && ld_a >= H * DH && ld_b >= H * DH && (ld_a % 8) == 0 && (ld_b % 8) == 0;
+}
+
+}  // namespace
+
+extern "C" int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res,
+                             void* o_res, float* lse, const int32_t* kv_len, int B, int N, int H, int ld_qkv,
+                             int ld_o, float scale, void* stream) {
+    MTMP_CHECK_ARG(q && k && v && o && lse, "mtmp_attn_fwd: null pointer");
+    MTMP_CHECK_ARG((res == nullptr) == (o_res == nullptr), "mtmp_attn_fwd: res and o_res must be given together");
+    MTMP_CHECK_ARG(attn_shape_ok(B, N, H, ld_qkv, ld_o), "mtmp_attn_fwd: bad shape B=%d N=%d H=%d ld=%d/%d", B, N, H,
+                   ld_qkv, ld_o);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) return launch_fwd<float>(q, k, v, o, res, o_res, lse, kv_len, B, N, H, ld_qkv, ld_o, scale, st);
+    if (dtype == 1) return launch_fwd<bf16>(q, k, v, o, res, o_res, lse, kv_len, B, N, H, ld_qkv, ld_o, scale, st);
+    mtmp_set_error("mtmp_attn_fwd: unknown dtype %d", dtype);
+    return MTMP_ERR_ARG;
+}
+
+extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                             const float* lse, const int32_t* kv_len, void* dq, void* dk, void* dv, float* delta_ws,
+                             int B, int N, int H, int ld_qkv, int ld_o, int ld_do, int ld_dqkv, float scale,
+                             void* stream) {
+    MTMP_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv && delta_ws, "mtmp_attn_bwd: null pointer");
+    MTMP_CHECK_ARG(attn_shape_ok(B, N, H, ld_qkv, ld_o) && attn_shape_ok(B, N, H, ld_do, ld_dqkv),
+                   "mtmp_attn_bwd: bad shape B=%d N=%d H=%d", B, N, H);
+    MTMP_CHECK_ARG(H == 4, "mtmp_attn_bwd: the delta pass assumes 4 heads x 64 (d_model 256), got H=%d", H);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return launch_bwd<float>(q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, B, N, H, ld_qkv, ld_o, ld_do,
+                                 ld_dqkv, scale, st);
+    if (dtype == 1)
+        return launch_bwd<bf16>(q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, B, N, H, ld_qkv, ld_o, ld_do,
+                                ld_dqkv, scale, st);
+    mtmp_set_error("mtmp_attn_bwd: unknown dtype %d", dtype);
+    return MTMP_ERR_ARG;
+}

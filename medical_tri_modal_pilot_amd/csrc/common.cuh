@@ -1,0 +1,164 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels.
+//
+// Every contraction on the hot path goes through ONE fragment convention so
+// that the fp32 "parity" build of a kernel and its bf16 "perf" build share all
+// indexing code and differ only in the MFMA instruction:
+//
+//   Frag<T>   : 8 elements of T per lane = the k-slice  k = 16*c + 8*(lane>>5) + j,
+//               j = 0..7, of row/col (lane & 31) of the operand.
+//   mma<T>    : acc(32x32 f32) += A(32 x 16) * B(16 x 32)
+//               bf16 -> one v_mfma_f32_32x32x16_bf16
+//               f32  -> eight v_mfma_f32_32x32x2_f32 (element u of each half-wave
+//                       pairs k = 16c+u with k = 16c+8+u) : bit-exact f32 fma chain.
+//   acc layout: lane (col = lane&31, half = lane>>5), register t holds
+//               row (t&3) + 8*(t>>2) + 4*half   (dtype independent on gfx950).
+//   acc -> Frag: registers 8s..8s+7 of an accumulator are, unchanged, the k-step-s
+//               fragment of a following product that contracts over the
+//               accumulator's ROW index (row 16s + 8(j>>2) + 4*half + (j&3)).
+//               Kernels read the FIRST product's A rows through swz23() so that
+//               this becomes the contiguous index 16s + 8*half + j.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MTMP_DEV __device__ __forceinline__
+
+template <typename T> struct Frag;
+template <> struct Frag<bf16> { bf16x8 v; };
+template <> struct Frag<float> { f32x8 v; };
+
+template <typename T> MTMP_DEV Frag<T> frag_zero() {
+    Frag<T> f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (T)0.0f;
+    return f;
+}
+
+// 8 contiguous elements (16-byte aligned for bf16, 32-byte for f32) from global or LDS.
+template <typename T> MTMP_DEV Frag<T> frag_load(const T* p);
+template <> MTMP_DEV Frag<bf16> frag_load<bf16>(const bf16* p) {
+    Frag<bf16> f;
+    f.v = *reinterpret_cast<const bf16x8*>(p);
+    return f;
+}
+template <> MTMP_DEV Frag<float> frag_load<float>(const float* p) {
+    Frag<float> f;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    f.v = f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return f;
+}
+template <typename T> MTMP_DEV void frag_store(T* p, const Frag<T>& f);
+template <> MTMP_DEV void frag_store<bf16>(bf16* p, const Frag<bf16>& f) {
+    *reinterpret_cast<bf16x8*>(p) = f.v;
+}
+template <> MTMP_DEV void frag_store<float>(float* p, const Frag<float>& f) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{f.v[0], f.v[1], f.v[2], f.v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{f.v[4], f.v[5], f.v[6], f.v[7]};
+}
+
+template <typename T> MTMP_DEV void mma(f32x16& acc, const Frag<T>& a, const Frag<T>& b);
+template <> MTMP_DEV void mma<bf16>(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+template <> MTMP_DEV void mma<float>(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u], b.v[u], acc, 0, 0, 0);
+}
+
+// accumulator registers 8s..8s+7 -> operand fragment of k-step s (see header comment)
+template <typename T> MTMP_DEV Frag<T> frag_from_acc(const f32x16& x, int s);
+template <> MTMP_DEV Frag<float> frag_from_acc<float>(const f32x16& x, int s) {
+    Frag<float> f;
+    if (s == 0) f.v = f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]};
+    else        f.v = f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]};
+    return f;
+}
+template <> MTMP_DEV Frag<bf16> frag_from_acc<bf16>(const f32x16& x, int s) {
+    Frag<bf16> f;
+    f32x8 y = (s == 0) ? f32x8{x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]}
+                       : f32x8{x[8], x[9], x[10], x[11], x[12], x[13], x[14], x[15]};
+    f.v = __builtin_convertvector(y, bf16x8);     // v_cvt_pk_bf16_f32 (RNE, NaN preserving)
+    return f;
+}
+
+// swap bits 2 and 3 of a 5-bit index: the A-row permutation described above.
+MTMP_DEV int swz23(int i) { return (i & 0x13) | ((i & 4) << 1) | ((i & 8) >> 1); }
+// logical (contiguous) index of accumulator register t in lane-half `half` when the
+// first product's A rows were read through swz23: 16*(t>>3) + 8*half + (t&7).
+MTMP_DEV int acc_row_swz(int t, int half) { return ((t >> 3) << 4) + (half << 3) + (t & 7); }
+// natural accumulator row of register t.
+MTMP_DEV int acc_row(int t, int half) { return (t & 3) + ((t >> 2) << 3) + (half << 2); }
+
+MTMP_DEV float to_f32(float x) { return x; }
+MTMP_DEV float to_f32(bf16 x) { return (float)x; }
+template <typename T> MTMP_DEV T from_f32(float x) { return (T)x; }
+template <typename T> MTMP_DEV float round_as(float x) { return to_f32((T)x); }
+
+// store 4 consecutive outputs (one accumulator register group) as T
+template <typename T> MTMP_DEV void store4(T* p, float a, float b, float c, float d);
+template <> MTMP_DEV void store4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+template <> MTMP_DEV void store4<bf16>(bf16* p, float a, float b, float c, float d) {
+    *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(f32x4{a, b, c, d}, bf16x4);
+}
+template <typename T> MTMP_DEV f32x4 load4(const T* p);
+template <> MTMP_DEV f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> MTMP_DEV f32x4 load4<bf16>(const bf16* p) {
+    return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
+}
+
+MTMP_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MTMP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Counter-based dropout mask: element `idx` of a call seeded with `seed` is kept iff
+// fmix32(idx * golden ^ seed) >= p * 2^32.  Stateless, so the backward regenerates the
+// same mask from (seed, idx) instead of storing it.
+MTMP_DEV unsigned dropout_threshold(float p) { return p <= 0.f ? 0u : (unsigned)((double)p * 4294967296.0); }
+MTMP_DEV bool dropout_keep(unsigned seed, unsigned idx, unsigned thr) {
+    unsigned x = (idx * 0x9E3779B1u) ^ seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x >= thr;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8)
+// get a contiguous chunk of the work list, so neighbours share that XCD's L2.
+MTMP_DEV int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+// ---- host side ----
+#define MTMP_OK 0
+#define MTMP_ERR_ARG 1
+#define MTMP_ERR_LAUNCH 2
+void mtmp_set_error(const char* fmt, ...);
+#define MTMP_CHECK_ARG(cond, ...)                         \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            mtmp_set_error(__VA_ARGS__);                  \
+            return MTMP_ERR_ARG;                          \
+        }                                                 \
+    } while (0)
+#define MTMP_CHECK_LAUNCH(name)                                                  \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            mtmp_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return MTMP_ERR_LAUNCH;                                              \
+        }                                                                        \
+    } while (0)

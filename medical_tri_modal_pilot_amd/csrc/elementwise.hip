@@ -1,0 +1,277 @@
+// HBM-bound kernels of the hot path for gfx950: custom-LayerNorm backward (K5), TIE/UMSE event
+// embedding forward/backward (K1) and the fused AdamW update (K11).  All are one-wave-per-row
+// streaming kernels: a lane owns 4 consecutive feature columns (16-byte fp32 / 8-byte bf16
+// accesses, 1 KiB / 512 B contiguous per wave instruction), row statistics are wave reductions,
+// parameter gradients are accumulated in registers over a grid-stride loop and combined through
+// a [blocks][cols] partial slab + a second pass (bitwise reproducible, no float atomics in HBM).
+#include "common.cuh"
+
+namespace {
+
+constexpr int D = 256;   // d_model, fixed on this path (tri_mbt_vsltcls.py:117,227-228 hard-code it)
+
+MTMP_DEV f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// sum two values across the wave at once
+MTMP_DEV void wave_sum2(float& a, float& b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+}
+
+// block partials: every wave adds its per-lane accumulators acc[NV][4] into LDS, block writes one slab row
+template <int NV>
+MTMP_DEV void flush_partials(float (&acc)[NV][4], float* slab_row, float* lds, int lane, int wave) {
+    // lds: [4 waves][NV*256]
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        *reinterpret_cast<f32x4*>(lds + (wave * NV + v) * D + 4 * lane) = f32x4{acc[v][0], acc[v][1], acc[v][2], acc[v][3]};
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV * D; i += 256)
+        slab_row[i] = lds[i] + lds[NV * D + i] + lds[2 * NV * D + i] + lds[3 * NV * D + i];
+}
+
+// out[c] = sum_r slab[r][c]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int rows, int cols, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += slab[(size_t)r * cols + c];
+    out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// custom LayerNorm backward (module.py:138-144):  y = gamma * (z - mu) / (sigma + eps) + beta,
+// sigma = unbiased std.  With xh = (z - mu) * rs, rs = 1/(sigma+eps), g = dy * gamma:
+//     dz = (g - mean(g)) * rs - xh * sum(g * xh) / ((D-1) * sigma)
+//     dgamma = sum_rows dy * xh ;  dbeta = sum_rows dy
+// dz_out = dz (+ d_res): the residual branch of encoder.py:24-32 is added here.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* z, int ldz, const float* stats, const float* gamma,
+                                                     const T* dy, const T* d_res, int ldr, T* dz, int M, float eps,
+                                                     float* slab) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 gm = ld4f(gamma + 4 * lane);
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float mu = stats[2 * (size_t)row], rs = stats[2 * (size_t)row + 1];
+        const float sigma = 1.0f / rs - eps;
+        const f32x4 zv = load4<T>(z + (size_t)row * ldz + 4 * lane);
+        const f32x4 dv = load4<T>(dy + (size_t)row * D + 4 * lane);
+        float xh[4], g[4], sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xh[i] = (zv[i] - mu) * rs;
+            g[i] = dv[i] * gm[i];
+            sg += g[i];
+            sgx += g[i] * xh[i];
+            acc[0][i] += dv[i] * xh[i];
+            acc[1][i] += dv[i];
+        }
+        wave_sum2(sg, sgx);
+        const float mg = sg * (1.0f / D);
+        const float kx = sgx / ((float)(D - 1) * sigma);
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (d_res) rv = load4<T>(d_res + (size_t)row * ldr + 4 * lane);
+        store4<T>(dz + (size_t)row * D + 4 * lane, (g[0] - mg) * rs - xh[0] * kx + rv[0], (g[1] - mg) * rs - xh[1] * kx + rv[1],
+                  (g[2] - mg) * rs - xh[2] * kx + rv[2], (g[3] - mg) * rs - xh[3] * kx + rv[3]);
+    }
+    flush_partials<2>(acc, slab + (size_t)blockIdx.x * 2 * D, lds, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------
+// TIE / UMSE event embedding (tri_mbt_vsltcls.py:59-71,183-190):
+//   E[e,:] = ReLU(LN(v_e * w_v + b_v)) + ReLU(LN(tau_e * w_t + b_t)) + F[f_e]
+// events: [n,3] fp32 (time, value, feature index); params: 8 vectors of 256 (w,b,ln_w,ln_b for the
+// value chain then the time chain) packed [8][256]; F [20][256].  nn.LayerNorm: biased var, eps 1e-5.
+struct TieChain { f32x4 w, b, g, be; };
+
+MTMP_DEV TieChain tie_load_chain(const float* prm, int chain, int lane) {
+    const float* base = prm + chain * 4 * D + 4 * lane;
+    return TieChain{ld4f(base), ld4f(base + D), ld4f(base + 2 * D), ld4f(base + 3 * D)};
+}
+// forward of one chain for one event; returns pre-ReLU y, and xh / rstd for the backward
+MTMP_DEV void tie_chain_fwd(const TieChain& c, float s, float (&y)[4], float (&xh)[4], float& rstd) {
+    float u[4], su = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i] = fmaf(s, c.w[i], c.b[i]); su += u[i]; }
+    su = wave_sum(su);
+    const float mu = su * (1.0f / D);
+    float sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float d = u[i] - mu; sv += d * d; }
+    sv = wave_sum(sv);
+    rstd = rsqrtf(sv * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xh[i] = (u[i] - mu) * rstd; y[i] = fmaf(xh[i], c.g[i], c.be[i]); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tie_fwd_kernel(const float* ev, const float* prm, const float* ftab, T* out, int n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TieChain cv = tie_load_chain(prm, 0, lane), ct = tie_load_chain(prm, 1, lane);
+    for (int e = blockIdx.x * 4 + wave; e < n; e += gridDim.x * 4) {
+        const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
+        const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);          // x[:,:,2].type(IntTensor), :187
+        float yv[4], yt[4], xh[4], rstd;
+        tie_chain_fwd(cv, val, yv, xh, rstd);
+        tie_chain_fwd(ct, tau, yt, xh, rstd);
+        const f32x4 fe = ld4f(ftab + f * D + 4 * lane);
+        store4<T>(out + (size_t)e * D + 4 * lane, fmaxf(yv[0], 0.f) + fmaxf(yt[0], 0.f) + fe[0],
+                  fmaxf(yv[1], 0.f) + fmaxf(yt[1], 0.f) + fe[1], fmaxf(yv[2], 0.f) + fmaxf(yt[2], 0.f) + fe[2],
+                  fmaxf(yv[3], 0.f) + fmaxf(yt[3], 0.f) + fe[3]);
+    }
+}
+
+// backward of one chain for one event: accumulates dW, dB, dLNw, dLNb (acc[0..3])
+MTMP_DEV void tie_chain_bwd(const TieChain& c, float s, const f32x4& dE, float (&acc)[8][4], int o) {
+    float y[4], xh[4], rstd, g[4], sg = 0.f, sgx = 0.f;
+    tie_chain_fwd(c, s, y, xh, rstd);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float dy = y[i] > 0.f ? dE[i] : 0.f;
+        acc[o + 2][i] += dy * xh[i];
+        acc[o + 3][i] += dy;
+        g[i] = dy * c.g[i];
+        sg += g[i];
+        sgx += g[i] * xh[i];
+    }
+    wave_sum2(sg, sgx);
+    const float mg = sg * (1.0f / D), mgx = sgx * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float du = rstd * (g[i] - mg - xh[i] * mgx);
+        acc[o][i] += du * s;
+        acc[o + 1][i] += du;
+    }
+}
+
+// slab row layout: [8][256] chain grads (same order as prm) then [20][256] feature-table grads
+template <typename T>
+__global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const float* prm, const T* dE, int n, float* slab) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 8 * D];          // 32 KiB (also used for the table)
+    __shared__ __attribute__((aligned(16))) float ftab_acc[20 * D];        // 20 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TieChain cv = tie_load_chain(prm, 0, lane), ct = tie_load_chain(prm, 1, lane);
+    for (int i = threadIdx.x; i < 20 * D; i += 256) ftab_acc[i] = 0.f;
+    __syncthreads();
+    float acc[8][4];
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
+    for (int e = blockIdx.x * 4 + wave; e < n; e += gridDim.x * 4) {
+        const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
+        const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);
+        const f32x4 g = load4<T>(dE + (size_t)e * D + 4 * lane);
+        tie_chain_bwd(cv, val, g, acc, 0);
+        tie_chain_bwd(ct, tau, g, acc, 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&ftab_acc[f * D + 4 * lane + i], g[i]);   // LDS ds_add_f32
+    }
+    float* row = slab + (size_t)blockIdx.x * 28 * D;
+    flush_partials<8>(acc, row, lds, lane, wave);
+    for (int i = threadIdx.x; i < 20 * D; i += 256) row[8 * D + i] = ftab_acc[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// AdamW (2_train.py:110; torch.optim.AdamW single-tensor math) over one flat fp32 buffer, optionally
+// refreshing the bf16 shadow copy the MFMA kernels read.
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16* shadow, size_t n,
+                                                    float lr, float beta1, float beta2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float grad_scale) {
+    const size_t n4 = n >> 2;
+    const float step = lr / bc1, decay = 1.0f - lr * wd;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 pv = ld4f(p + 4 * i), gv = ld4f(g + 4 * i), mv = ld4f(m + 4 * i), vv = ld4f(v + 4 * i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gv[k] * grad_scale;
+            pv[k] *= decay;
+            mv[k] = mv[k] + (gk - mv[k]) * (1.0f - beta1);          // exp_avg.lerp_(grad, 1-beta1)
+            vv[k] = fmaf(vv[k], beta2, (1.0f - beta2) * gk * gk);
+            pv[k] -= step * (mv[k] / (sqrtf(vv[k]) / bc2_sqrt + eps));
+        }
+        *reinterpret_cast<f32x4*>(p + 4 * i) = pv;
+        *reinterpret_cast<f32x4*>(m + 4 * i) = mv;
+        *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+        if (shadow) *reinterpret_cast<bf16x4*>(shadow + 4 * i) = __builtin_convertvector(pv, bf16x4);
+    }
+}
+
+int grid_for_rows(int rows) { return max(1, min((rows + 3) / 4, 1024)); }
+
+}  // namespace
+
+extern "C" int mtmp_ln_bwd_ws_floats(int M) { return grid_for_rows(M) * 2 * D; }
+
+// dz[M,256] = LNbackward(dy; z, stats, gamma) (+ d_res);  dgamma[256], dbeta[256] overwritten.
+// ws: mtmp_ln_bwd_ws_floats(M) floats.  Backward of module.py:138-144 (+ the residual of encoder.py:24-32).
+extern "C" int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats, const float* gamma, const void* dy,
+                           const void* d_res, int ldr, void* dz, float* dgamma_dbeta, float* ws, int M, float eps,
+                           void* stream) {
+    MTMP_CHECK_ARG(z && stats && gamma && dy && dz && dgamma_dbeta && ws, "mtmp_ln_bwd: null pointer");
+    MTMP_CHECK_ARG(M > 0 && ldz >= D && ldz % 4 == 0 && (!d_res || (ldr >= D && ldr % 4 == 0)), "mtmp_ln_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = grid_for_rows(M);
+    if (dtype == 0)
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)z, ldz, stats, gamma,
+                           (const float*)dy, (const float*)d_res, ldr, (float*)dz, M, eps, ws);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)z, ldz, stats, gamma,
+                           (const bf16*)dy, (const bf16*)d_res, ldr, (bf16*)dz, M, eps, ws);
+    else { mtmp_set_error("mtmp_ln_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_ln_bwd");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(2), dim3(256), 0, st, ws, nb, 2 * D, dgamma_dbeta);
+    MTMP_CHECK_LAUNCH("mtmp_ln_bwd(reduce)");
+    return MTMP_OK;
+}
+
+// out[n,256] = TIE embedding of events[n,3]; params [8][256] fp32, ftab [20][256] fp32.
+extern "C" int mtmp_tie_embed_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out,
+                                  int n, void* stream) {
+    MTMP_CHECK_ARG(events && params && ftab && out && n > 0, "mtmp_tie_embed_fwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = max(1, min((n + 3) / 4, 2048));
+    if (dtype == 0) hipLaunchKernelGGL(tie_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, ftab, (float*)out, n);
+    else if (dtype == 1) hipLaunchKernelGGL(tie_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, ftab, (bf16*)out, n);
+    else { mtmp_set_error("mtmp_tie_embed_fwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_tie_embed_fwd");
+    return MTMP_OK;
+}
+
+extern "C" int mtmp_tie_bwd_ws_floats(int n) { return max(1, min((n + 3) / 4, 512)) * 28 * D; }
+
+// grads[28][256] fp32 (8 chain vectors in params order, then the 20 feature-table rows) overwritten.
+extern "C" int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
+                                  float* ws, int n, void* stream) {
+    MTMP_CHECK_ARG(events && params && d_out && grads && ws && n > 0, "mtmp_tie_embed_bwd: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = max(1, min((n + 3) / 4, 512));
+    if (dtype == 0) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, n, ws);
+    else if (dtype == 1) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, n, ws);
+    else { mtmp_set_error("mtmp_tie_embed_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(28), dim3(256), 0, st, ws, nb, 28 * D, grads);
+    MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd(reduce)");
+    return MTMP_OK;
+}
+
+// In-place AdamW step over flat fp32 buffers of n elements (n % 4 == 0); bf16_shadow may be null.
+// grad_scale multiplies the gradient first (1/world_size after an all-reduce SUM).
+extern "C" int mtmp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_shadow,
+                               long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int step, float grad_scale, void* stream) {
+    MTMP_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && (n % 4) == 0 && step >= 1,
+                   "mtmp_adamw_step: bad argument (n=%lld must be a positive multiple of 4, step >= 1)", n);
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int nb = (int)max((long long)1, min((n / 4 + 255) / 256, (long long)2048));
+    hipLaunchKernelGGL(adamw_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                       (bf16*)bf16_shadow, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2),
+                       grad_scale);
+    MTMP_CHECK_LAUNCH("mtmp_adamw_step");
+    return MTMP_OK;
+}

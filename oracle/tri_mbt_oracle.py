@@ -80,13 +80,35 @@ def multi_head_attention(sd: SD, prefix: str, x: torch.Tensor, mask: Optional[to
         return y
 
     q, k, v = proj("query"), proj("key"), proj("value")
+    ctx = scaled_dot_attention_headmajor(q, k, v, mask, n_head)
+    ctx = ctx.view(n_head, B, N, dh).permute(1, 2, 0, 3).contiguous().view(B, N, D)
+    return ctx
+
+
+def scaled_dot_attention_headmajor(q, k, v, mask, n_head):
+    """attention.py:24-49 on head-major [H*B, N, dh] batches."""
+    dh = q.shape[-1]
     score = torch.bmm(q, k.transpose(1, 2)) / float(math.sqrt(dh))
     if mask is not None:
         score = score.masked_fill(mask.repeat(n_head, 1, 1), MASK_FILL)
     attn = torch.softmax(score, dim=-1)
-    ctx = torch.bmm(attn, v)
-    ctx = ctx.view(n_head, B, N, dh).permute(1, 2, 0, 3).contiguous().view(B, N, D)
-    return ctx
+    return torch.bmm(attn, v)
+
+
+def attention_core(qkv: torch.Tensor, kv_len: Optional[torch.Tensor], n_head: int = 4) -> torch.Tensor:
+    """The attention of attention.py:65-84 given already-projected qkv [B,N,3*D] (q|k|v): head split to
+    [H*B,N,dh], masked softmax attention, head merge -> [B,N,D].  kv_len None = no mask."""
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // n_head
+
+    def heads(t):
+        return t.reshape(B, N, n_head, dh).permute(2, 0, 1, 3).contiguous().view(n_head * B, N, dh)
+
+    mask = None if kv_len is None else key_pad_mask(N, kv_len)
+    ctx = scaled_dot_attention_headmajor(heads(qkv[..., :D]), heads(qkv[..., D:2 * D]), heads(qkv[..., 2 * D:]),
+                                         mask, n_head)
+    return ctx.view(n_head, B, N, dh).permute(1, 2, 0, 3).contiguous().view(B, N, D)
 
 
 def ffn_conv1x1(sd: SD, prefix: str, x: torch.Tensor, dropout_p: float = 0.0,

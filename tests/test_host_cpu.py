@@ -1,0 +1,200 @@
+"""CPU-only checks of the host side: C-ABI surface, state_dict / flag parity with the
+reference, trainer integer logic, scheduler, flat parameter storage, and the 2-rank
+gradient reducer over gloo.  No HIP kernel is launched here (there is no GPU)."""
+import ctypes
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "medical_tri_modal_pilot_amd", "libmtmp_hip.so")
+
+
+def _args(*extra):
+    from medical_tri_modal_pilot_amd.control.config import parse_args
+    a = parse_args(["--input-types", "vslt_img_txt", "--model", "tri_mbt_vsltcls", "--modality-inclusion",
+                    "train-missing_test-missing", "--batch-size", "4", "--transformer-num-layers", "2",
+                    "--imgtxt-time", "1", "--mbt-only-vslt", "1", *extra])
+    a.device = torch.device("cpu")
+    return a
+
+
+def test_c_abi_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as ge
+        ge.build()
+    hdr = open(os.path.join(ROOT, "include", "mtmp.h")).read()
+    declared = set(re.findall(r"\b(mtmp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    lib = ctypes.CDLL(LIB)                       # loads without a GPU: HIP initialises lazily
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/mtmp.h but not exported"
+    from medical_tri_modal_pilot_amd import _lib
+    assert set(_lib.SIGNATURES) == declared
+    lib.mtmp_abi_version.restype = ctypes.c_int
+    assert lib.mtmp_abi_version() == 1
+
+
+def test_ops_fail_loudly_without_gpu():
+    from medical_tri_modal_pilot_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.attn_fwd(torch.zeros(1, 8, 768), None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm_nt(torch.zeros(8, 64), torch.zeros(32, 64))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "medical_tri_modal_pilot_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), f"{f} mentions the oracle"
+
+
+def test_state_dict_and_flag_surface_match_reference():
+    from medical_tri_modal_pilot_amd.builder.models import get_model
+    a = _args()
+    model = get_model(a)(a)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_shapes_L2.json")))
+    sd = model.state_dict()
+    assert set(sd) == set(ref)
+    for k, (shape, dtype) in ref.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+        assert str(sd[k].dtype).replace("torch.", "") == dtype, k
+    # parameters that receive gradients = the golden's grad set (static unused set excluded)
+    G = np.load(os.path.join(ROOT, "tests", "golden", "model_step.npz"))
+    assert sorted(n for n, _ in model.hot_parameters()) == sorted(str(s) for s in G["grad_names"])
+    # README.md:44 command line parses unchanged
+    from medical_tri_modal_pilot_amd.control.config import parse_args
+    r = parse_args("--input-types vslt_img_txt --model tri_mbt_vsltcls --modality-inclusion train-missing_test-missing "
+                   "--lr-init 1e-5 --output-type intubation --batch-size 64 --epochs 50 --transformer-num-layers 6 "
+                   "--vslt-type TIE --model-types detection --imgtxt-time 1 --mbt-only-vslt 1 --num-workers 16 "
+                   "--multiimages 1".split())
+    assert r.batch_size == 64 and r.transformer_num_layers == 6 and r.weight_decay == 1e-6 and r.dropout == 0.1
+    with pytest.raises(ValueError):
+        get_model(_args("--input-types", "vslt"))(_args("--input-types", "vslt"))      # reference: IndexError
+
+
+def test_missing_num_bit_exact():
+    from medical_tri_modal_pilot_amd.builder.trainer import missing_to_num
+    from oracle import tri_mbt_oracle as O
+    import filler
+    G = np.load(os.path.join(ROOT, "tests", "golden", "model_step.npz"))
+    bt = filler.make_batch(int(G["seed"]), int(G["B"]), int(G["T"]))
+    mn, _ = missing_to_num(bt["missing"])
+    assert torch.equal(mn, torch.from_numpy(G["missing_num"]))
+    for rows in ([[0, 1, 1], [0, 0, 0]], [[0, 0, 1]] * 5, [[0, 1, 0], [0, 1, 1], [0, 0, 1], [0, 0, 0]]):
+        m = torch.tensor(rows, dtype=torch.float32)
+        assert torch.equal(missing_to_num(m)[0], O.missing_to_num(m))
+
+
+def test_key_lengths_bit_exact():
+    from medical_tri_modal_pilot_amd.builder.models.src.transformer.mbt_encoder import TrimodalTransformerEncoder_MBT
+    from oracle import tri_mbt_oracle as O
+    for multi in (0, 1):
+        enc = TrimodalTransformerEncoder_MBT(4, 3, 4, 0, 256, 1, 4, 256, 1024, mask=[True, bool(multi), True])
+        in_len, txt_len = torch.tensor([20, 3, 1000, 7]), torch.tensor([20, 0, 126, 1])
+        img_time = torch.tensor([[1., 10, 10], [10, 10, 10], [-1, -2, -3], [0.5, 10, 2]])
+        img_len = torch.count_nonzero(img_time - 10, dim=1) * 49 if multi else 49
+        lens = enc.key_lengths([in_len, img_len, txt_len + 2], "cpu")
+        ref = O.fusion_kv_lengths(in_len, txt_len, img_time, multi, 49)
+        for got, want in zip(lens, ref):
+            if want is None:
+                assert got is None
+            else:
+                assert torch.equal(got + 4, want)
+        assert torch.equal(in_len, torch.tensor([20, 3, 1000, 7]))        # caller's tensor is not mutated
+
+
+def test_scheduler_matches_reference_sequence():
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    G = np.load(os.path.join(ROOT, "tests", "golden", "sched.npz"))
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-5)
+    s = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=500, cycle_mult=2, max_lr=1e-5 * math.sqrt(64),
+                                      min_lr=1e-6, warmup_steps=50, gamma=0.5)
+    assert opt.param_groups[0]["lr"] == 1e-6
+    for it, lr in zip(G["its"], G["lrs"]):
+        s.step(int(it))
+        assert opt.param_groups[0]["lr"] == pytest.approx(float(lr), rel=1e-12, abs=0)
+
+
+def test_flat_params_views_and_grads():
+    from medical_tri_modal_pilot_amd.optim import FlatParams
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    before = {n: p.detach().clone() for n, p in lin.named_parameters()}
+    flat = FlatParams(lin.named_parameters())
+    for n, p in lin.named_parameters():
+        assert torch.equal(p, before[n]) and p.data_ptr() >= flat.data.data_ptr()
+    assert all(o % 4 == 0 for o in flat.offsets)
+    lin(torch.randn(7, 5)).sum().backward()
+    for i, p in enumerate(flat.params):
+        lo, hi = flat.slice_of(i)
+        assert torch.equal(flat.grad[lo:hi].view_as(p), p.grad) and p.grad.abs().sum() > 0
+    flat.zero_grad()
+    assert float(flat.grad.abs().sum()) == 0 and all(p.grad.data_ptr() >= flat.grad.data_ptr() for p in flat.params)
+    sd = lin.state_dict()
+    lin.load_state_dict({k: v + 1 for k, v in sd.items()})                # in-place: views survive
+    assert float(flat.data[: 15].sum()) == pytest.approx(float(before["0.weight"].sum()) + 15, rel=1e-5)
+
+
+DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MTMP_ROOT"])
+from medical_tri_modal_pilot_amd.optim import FlatParams
+from medical_tri_modal_pilot_amd.ddp import GradReducer, broadcast_module_state
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(100 + rank)                      # replicas start different ...
+net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1))
+unused = torch.nn.Linear(4, 4)                      # a parameter that never gets a gradient (static unused set)
+broadcast_module_state(net, 0)                      # ... and are made identical
+flat = FlatParams(list(net.named_parameters()) + [("unused." + n, p) for n, p in unused.named_parameters()])
+red = GradReducer(flat, bucket_bytes=1024, overlap=True)
+assert len(red.buckets) >= 2
+ref = [p.detach().clone() for p in net.parameters()]
+g = torch.Generator().manual_seed(7)
+xs = [torch.randn(6, 16, generator=g) for _ in range(world)]     # every rank can rebuild every shard
+for step in range(2):
+    flat.zero_grad()
+    net(xs[rank]).pow(2).mean().backward()
+    red.wait()
+    # expected: sum over ranks of single-rank gradients on identical replicas
+    exp = [torch.zeros_like(p) for p in ref]
+    for r in range(world):
+        m = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1))
+        with torch.no_grad():
+            for q, s in zip(m.parameters(), ref):
+                q.copy_(s)
+        m(xs[r]).pow(2).mean().backward()
+        for e, q in zip(exp, m.parameters()):
+            e += q.grad
+    for p, e in zip(net.parameters(), exp):
+        assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6), (rank, step)
+    assert float(sum(p.grad.abs().sum() for p in unused.parameters())) == 0.0
+gathered = [torch.zeros_like(flat.grad) for _ in range(world)]
+dist.all_gather(gathered, flat.grad)
+assert all(torch.equal(gathered[0], t) for t in gathered)       # every rank holds the same reduced buffer
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_grad_reducer_two_ranks_gloo(tmp_path):
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER)
+    env = dict(os.environ, MTMP_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2",
+               OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o
