@@ -394,15 +394,27 @@ def test_full_training_step_fp32_vs_golden(ops, multi, tag, fused):
     assert sorted(names) == sorted(grads.keys()), set(names) ^ set(grads.keys())
     if fused:
         assert sorted(n for n, _ in model.hot_parameters()) == sorted(names)      # static no-grad set is right
+    # Some gradients are mathematically zero (key bias: softmax is shift invariant; biases feeding
+    # BatchNorm): the reference holds rounding noise there (norm ~1e-9 vs a median of ~1e-1), so
+    # those tensors are only required to be noise-sized too.  AdamW's first update is lr*sign(g):
+    # on noise-sized elements the sign is arbitrary, so parameters may differ by up to 2*lr.
+    med = float(np.median(Gd["grad_digest"][:, 0]))
+    lr1 = 1e-6
     worst_g = worst_p = 0.0
     for n_, gd, pd in zip(names, Gd["grad_digest"], Gd["param_digest"]):
-        eg = _rel(_digest(grads[n_]), torch.from_numpy(gd))
-        ep = _rel(_digest(params1[n_]), torch.from_numpy(pd))
-        worst_g, worst_p = max(worst_g, eg), max(worst_p, ep)
-        assert eg < 2e-3, f"grad {n_}: {eg}"
-        assert ep < 1e-5, f"param {n_}: {ep}"
+        got_g, got_p = _digest(grads[n_]), _digest(params1[n_])
+        if gd[0] < 1e-4 * med:
+            assert float(got_g[0]) < 1e-3 * med, f"grad {n_} should be ~0, norm {float(got_g[0])}"
+        else:
+            eg = _rel(got_g, torch.from_numpy(gd))
+            worst_g = max(worst_g, eg)
+            assert eg < 2e-3, f"grad {n_}: {eg}"
+        dp = float((got_p[1:] - torch.from_numpy(pd)[1:]).abs().max())
+        worst_p = max(worst_p, dp)
+        assert dp <= 2.2 * lr1, f"param {n_}: |diff| {dp}"
+        assert abs(float(got_p[0]) - pd[0]) <= 1e-5 * pd[0] + 1e-9, f"param norm {n_}"
     REPORT[t + ".worst_grad_digest"] = {"rel_err": worst_g, "tol": 2e-3}
-    REPORT[t + ".worst_param_digest"] = {"rel_err": worst_p, "tol": 1e-5}
+    REPORT[t + ".worst_param_abs_diff_after_adamw"] = {"rel_err": worst_p, "tol": 2.2 * lr1}
     assert abs(loss2 - float(Gd["loss2"])) < 1e-4
     assert abs(tl - float(Gd["test_loss"])) < 1e-4
     check(t + ".test_sigmoid", lg.evaluator.calls[-1][1], torch.from_numpy(Gd["test_sigmoid"]), 1e-4)
@@ -416,9 +428,13 @@ def test_full_training_step_bf16_tolerance(ops):
     assert abs(loss1 - float(Gd["loss"])) < 3e-2
     names = [str(s) for s in Gd["grad_names"]]
     worst = 0.0
+    med = float(np.median(Gd["grad_digest"][:, 0]))
     for n_, gd in zip(names, Gd["grad_digest"]):
         got, ref = float(_digest(grads[n_])[0]), float(gd[0])          # gradient L2 norms
-        worst = max(worst, abs(got - ref) / (abs(ref) + 1e-12))
+        if ref < 1e-4 * med:                                           # mathematically-zero gradients: noise
+            assert got < 1e-2 * med, n_
+            continue
+        worst = max(worst, abs(got - ref) / abs(ref))
     REPORT["step[bf16].worst_grad_norm_rel_err"] = {"rel_err": worst, "tol": 0.15}
     assert worst < 0.15
     assert abs(tl - float(Gd["test_loss"])) < 5e-2
