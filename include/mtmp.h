@@ -63,6 +63,14 @@ int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta
 int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N,
                  int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed, void* stream);
 
+/* Weight / bias gradient of the Linear and k=1 Conv1d layers (attention.py:60-62, module.py:74-78):
+ * dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db[N] (fp32, may be NULL) = column sums of dy.
+ * N % 128 == 0, K % 128 == 0; the contraction runs over the M tokens (split over workgroups,
+ * partial slabs in ws, one reduce pass).  ws: mtmp_gemm_tn_ws_floats(M,N,K) floats. */
+long long mtmp_gemm_tn_ws_floats(int M, int N, int K);
+int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K,
+                 int ldy, int ldx, void* stream);
+
 /* g_out[i] = keep(seed,i) ? g_in[i]/(1-p) : 0 over n contiguous elements: backward of the epilogue
  * dropout above (n = M*N of that call, n % 4 == 0). */
 int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long long n, unsigned seed, float p, void* stream);

@@ -36,17 +36,26 @@ template <typename T> struct AttnArgs {
     float scale;
 };
 
-// ---- LDS staging helpers (256 threads, 64-row x 64-col tile) ----------------
-// row-major copy: thread -> (row = tid>>3 (+32), 16-byte chunk = tid&7); rows >= limit are zero.
-template <typename T>
-MTMP_DEV void stage_rows(T* dst, const T* src, int ld, int row0, int limit, int tid) {
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const int row = (tid >> 3) + 32 * pass;
-        const int ch = (tid & 7) * 8;
-        Frag<T> f = (row0 + row < limit) ? frag_load<T>(src + (size_t)(row0 + row) * ld + ch) : frag_zero<T>();
-        frag_store<T>(dst + row * LDT + ch, f);
-    }
+// ---- LDS staging of a 64-row x 64-col tile by 256 threads, split into FETCH (global ->
+// registers, issued one tile ahead so the loads fly under the MFMAs of the current tile) and
+// PUT (registers -> LDS, after the barrier).  Thread -> (row pair rp = 2*(tid&31), 8-column
+// group cg = 8*(tid>>5)): a wave-load reads 32 rows x 32 contiguous bytes; the transposed put
+// writes 32 consecutive dwords per instruction (bank-conflict free); one fetch can feed both
+// the row-major and the transposed image of the same tile.  Rows >= limit are zero.
+template <typename T> struct Tile2 { Frag<T> a, b; };
+
+template <typename T> MTMP_DEV Tile2<T> tile_fetch(const T* src, int ld, int row0, int limit, int tid) {
+    const int rp = row0 + (tid & 31) * 2;
+    const int cg = (tid >> 5) * 8;
+    Tile2<T> t;
+    t.a = (rp < limit) ? frag_load<T>(src + (size_t)rp * ld + cg) : frag_zero<T>();
+    t.b = (rp + 1 < limit) ? frag_load<T>(src + (size_t)(rp + 1) * ld + cg) : frag_zero<T>();
+    return t;
+}
+template <typename T> MTMP_DEV void put_rows(T* dst, const Tile2<T>& t, int tid) {
+    T* d = dst + (tid & 31) * 2 * LDT + (tid >> 5) * 8;
+    frag_store<T>(d, t.a);
+    frag_store<T>(d + LDT, t.b);
 }
 template <typename T> MTMP_DEV void store_pair(T* p, T a, T b);
 template <> MTMP_DEV void store_pair<bf16>(bf16* p, bf16 a, bf16 b) {
@@ -55,16 +64,10 @@ template <> MTMP_DEV void store_pair<bf16>(bf16* p, bf16 a, bf16 b) {
 template <> MTMP_DEV void store_pair<float>(float* p, float a, float b) {
     *reinterpret_cast<f32x2*>(p) = f32x2{a, b};
 }
-// transposed copy dst[col][row]: thread -> (row pair = tid&31, 8-column group = tid>>5);
-// a wave writes 32 consecutive dwords per instruction (bank-conflict free).
-template <typename T>
-MTMP_DEV void stage_transposed(T* dst, const T* src, int ld, int row0, int limit, int tid) {
-    const int rp = (tid & 31) * 2;
-    const int cg = (tid >> 5) * 8;
-    Frag<T> fa = (row0 + rp < limit) ? frag_load<T>(src + (size_t)(row0 + rp) * ld + cg) : frag_zero<T>();
-    Frag<T> fb = (row0 + rp + 1 < limit) ? frag_load<T>(src + (size_t)(row0 + rp + 1) * ld + cg) : frag_zero<T>();
+template <typename T> MTMP_DEV void put_transposed(T* dst, const Tile2<T>& t, int tid) {
+    T* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) store_pair<T>(dst + (cg + e) * LDT + rp, fa.v[e], fb.v[e]);
+    for (int e = 0; e < 8; ++e) store_pair<T>(d + e * LDT, t.a.v[e], t.b.v[e]);
 }
 
 // 32x32 tile: acc += A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
@@ -100,12 +103,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
     float m = -INFINITY, l = 0.f;
     const float c2 = p.scale * LOG2E;
     const int ntiles = (kvl + KT - 1) / KT;
+    Tile2<T> kreg = tile_fetch<T>(Kb, p.ld_qkv, 0, kvl, tid);
+    Tile2<T> vreg = tile_fetch<T>(Vb, p.ld_qkv, 0, kvl, tid);
     for (int it = 0; it < ntiles; ++it) {
         const int k0 = it * KT;
         __syncthreads();
-        stage_rows<T>(sK, Kb, p.ld_qkv, k0, kvl, tid);
-        stage_transposed<T>(sVt, Vb, p.ld_qkv, k0, kvl, tid);
+        put_rows<T>(sK, kreg, tid);
+        put_transposed<T>(sVt, vreg, tid);
         __syncthreads();
+        if (it + 1 < ntiles) {                 // next tile's loads fly under this tile's MFMAs
+            kreg = tile_fetch<T>(Kb, p.ld_qkv, k0 + KT, kvl, tid);
+            vreg = tile_fetch<T>(Vb, p.ld_qkv, k0 + KT, kvl, tid);
+        }
         f32x16 st[2] = {{0}, {0}};
         if (!uniform) {
             tile_qk<T>(st[0], sK, r, half, qf);
@@ -225,14 +234,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
     const float dl = (qrow < p.N) ? p.delta[sidx] : 0.f;
     const float c2 = p.scale * LOG2E;
     f32x16 dq0 = {0}, dq1 = {0};
-    const int ntiles = (kvl + KT - 1) / KT;
-    for (int it = 0; it < ntiles && !uniform; ++it) {   // uniform: scores are constants -> dQ = 0
+    const int ntiles = uniform ? 0 : (kvl + KT - 1) / KT;   // uniform: scores are constants -> dQ = 0
+    Tile2<T> kreg = tile_fetch<T>(Kb, p.ld_qkv, 0, kvl, tid);
+    Tile2<T> vreg = tile_fetch<T>(Vb, p.ld_qkv, 0, kvl, tid);
+    for (int it = 0; it < ntiles; ++it) {
         const int k0 = it * KT;
         __syncthreads();
-        stage_rows<T>(sK, Kb, p.ld_qkv, k0, kvl, tid);
-        stage_rows<T>(sV, Vb, p.ld_qkv, k0, kvl, tid);
-        stage_transposed<T>(sKt, Kb, p.ld_qkv, k0, kvl, tid);
+        put_rows<T>(sK, kreg, tid);
+        put_transposed<T>(sKt, kreg, tid);
+        put_rows<T>(sV, vreg, tid);
         __syncthreads();
+        if (it + 1 < ntiles) {
+            kreg = tile_fetch<T>(Kb, p.ld_qkv, k0 + KT, kvl, tid);
+            vreg = tile_fetch<T>(Vb, p.ld_qkv, k0 + KT, kvl, tid);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 st = {0}, dp = {0};
@@ -304,18 +319,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
         }
         const float c2 = p.scale * LOG2E;
         const int nq = (p.N + KT - 1) / KT;
+        Tile2<T> qreg = tile_fetch<T>(Qb, p.ld_qkv, 0, p.N, tid);
+        Tile2<T> oreg = tile_fetch<T>(dOb, p.ld_do, 0, p.N, tid);
+        float lreg = (tid < KT) ? ((tid < p.N) ? Lb[tid] : INFINITY) : 0.f;
+        float dreg = (tid < KT && tid < p.N) ? Db[tid] : 0.f;
         for (int it = 0; it < nq; ++it) {
             const int q0 = it * KT;
             __syncthreads();
-            stage_rows<T>(sQ, Qb, p.ld_qkv, q0, p.N, tid);
-            stage_rows<T>(sdO, dOb, p.ld_do, q0, p.N, tid);
-            stage_transposed<T>(sQt, Qb, p.ld_qkv, q0, p.N, tid);
-            stage_transposed<T>(sdOt, dOb, p.ld_do, q0, p.N, tid);
-            if (tid < KT) {
-                sL[tid] = (q0 + tid < p.N) ? Lb[q0 + tid] : INFINITY;
-                sD[tid] = (q0 + tid < p.N) ? Db[q0 + tid] : 0.f;
-            }
+            put_rows<T>(sQ, qreg, tid);
+            put_transposed<T>(sQt, qreg, tid);
+            put_rows<T>(sdO, oreg, tid);
+            put_transposed<T>(sdOt, oreg, tid);
+            if (tid < KT) { sL[tid] = lreg; sD[tid] = dreg; }
             __syncthreads();
+            if (it + 1 < nq) {
+                qreg = tile_fetch<T>(Qb, p.ld_qkv, q0 + KT, p.N, tid);
+                oreg = tile_fetch<T>(dOb, p.ld_do, q0 + KT, p.N, tid);
+                if (tid < KT) {
+                    lreg = (q0 + KT + tid < p.N) ? Lb[q0 + KT + tid] : INFINITY;
+                    dreg = (q0 + KT + tid < p.N) ? Db[q0 + KT + tid] : 0.f;
+                }
+            }
             if (kw0 < kvl) {                   // wave-uniform
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {

@@ -33,13 +33,18 @@ MTMP_DEV void flush_partials(float (&acc)[NV][4], float* slab_row, float* lds, i
         slab_row[i] = lds[i] + lds[NV * D + i] + lds[2 * NV * D + i] + lds[3 * NV * D + i];
 }
 
-// out[c] = sum_r slab[r][c]
+// out[c] = sum_r slab[r][c]: a block owns 64 columns; 4 row-lanes sum interleaved rows (coalesced
+// 256-byte reads) and combine through LDS in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int rows, int cols, float* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += slab[(size_t)r * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 4) s += slab[(size_t)r * cols + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
-int grid_for_rows(int rows) { return max(1, min((rows + 3) / 4, 1024)); }
+int grid_for_rows(int rows) { return max(1, min((rows + 3) / 4, 512)); }
 
 }  // namespace
 
@@ -225,7 +230,7 @@ extern "C" int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats
                            (const bf16*)dy, (const bf16*)d_res, ldr, (bf16*)dz, M, eps, ws);
     else { mtmp_set_error("mtmp_ln_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_ln_bwd");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(2), dim3(256), 0, st, ws, nb, 2 * D, dgamma_dbeta);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(2 * D / 64), dim3(256), 0, st, ws, nb, 2 * D, dgamma_dbeta);
     MTMP_CHECK_LAUNCH("mtmp_ln_bwd(reduce)");
     return MTMP_OK;
 }
@@ -255,7 +260,7 @@ extern "C" int mtmp_tie_embed_bwd(int dtype, const float* events, const float* p
     else if (dtype == 1) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, n, ws);
     else { mtmp_set_error("mtmp_tie_embed_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(28), dim3(256), 0, st, ws, nb, 28 * D, grads);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(28 * D / 64), dim3(256), 0, st, ws, nb, 28 * D, grads);
     MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd(reduce)");
     return MTMP_OK;
 }

@@ -6,15 +6,20 @@
 //        * the Q/K/V projections, attention.py:60-62,68-70 (W = [Wq;Wk;Wv], N = 768), and
 //        * the first position-wise FFN conv + ReLU, module.py:74-77 (N = 1024).
 //      K = d_model = 256 is the whole row, so a wave keeps its 32 normalised rows as MFMA
-//      A-fragments in registers (two lanes share a row: statistics need one cross-lane add)
+//      fragments in registers (two lanes share a row: statistics need one cross-lane add)
 //      and only the weight tiles go through LDS.  Also writes LN(X) (the backward's GEMM
 //      operand) and the per-row (mean, 1/(std+eps)).
 //  mtmp_gemm_nt : Y = act( A W^T + b ) (+ R) for any K % 64 == 0 -- second FFN conv with the
-//      residual add of encoder.py:32 (K = 1024, N = 256).
+//      residual add of encoder.py:32 (K = 1024, N = 256); also dX = dY (W^T)^T.
+//  mtmp_gemm_tn : dW[N,K] = dY[M,N]^T X[M,K] (+ column sums of dY = bias gradient): the
+//      weight-gradient product, whose contraction index is the token index M (64 320 at
+//      config 2) while the output is tiny -- split over M into partial slabs + one reduce pass.
 //
-// Both are "NT": activations and weights are contiguous along the contraction index, which
-// is exactly the MFMA fragment shape (common.cuh).  Weights arrive in the compute dtype
-// (bf16 shadow copy or fp32 master), gamma/beta/bias always fp32.
+// "NT" operands are contiguous along the contraction index, which is exactly the MFMA fragment
+// shape (common.cuh).  The product is computed as W-rows x token-columns so that a TOKEN is a
+// lane: each lane then owns 4 consecutive output features per accumulator group and stores
+// 8/16-byte pieces of its own row.  Weights arrive in the compute dtype (bf16 shadow copy or
+// fp32 master), gamma/beta/bias always fp32.
 #include "common.cuh"
 
 namespace {
@@ -44,39 +49,46 @@ template <typename T> MTMP_DEV void tile_commit(T* dst, const Frag<T> (&reg)[4],
     for (int ps = 0; ps < 4; ++ps) frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, reg[ps]);
 }
 
+// acc[nt]: rows = output features n0 + 32nt + acc_row(t, half), column = this lane's token row.
 template <typename T, bool RELU>
-MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row_base, int n0, int r, int half) {
+MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, int n0, int half) {
+    if (row >= p.M) return;
+    const unsigned thr = dropout_threshold(p.drop_p);
+    const float keep_scale = 1.0f / (1.0f - p.drop_p);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        const int col = n0 + 32 * nt + r;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        const unsigned thr = dropout_threshold(p.drop_p);
-        const float keep_scale = 1.0f / (1.0f - p.drop_p);
+        if (n0 + 32 * nt >= p.N) continue;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int row = row_base + acc_row(t, half);
-            if (row < p.M) {
-                float v = acc[nt][t] + bv;
-                if (RELU) v = fmaxf(v, 0.f);
+        for (int g = 0; g < 4; ++g) {
+            const int col = n0 + 32 * nt + 8 * g + 4 * half;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[nt][4 * g + i] + bv[i];
+                if (RELU) v[i] = fmaxf(v[i], 0.f);
                 if (p.drop_p > 0.f)
-                    v = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)col, thr) ? v * keep_scale : 0.f;
-                if (p.res) v = round_as<T>(v) + to_f32(p.res[(size_t)row * p.ldr + col]);
-                p.y[(size_t)row * p.ldy + col] = from_f32<T>(v);
+                    v[i] = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)(col + i), thr) ? v[i] * keep_scale : 0.f;
             }
+            if (p.res) {
+                const f32x4 rv = load4<T>(p.res + (size_t)row * p.ldr + col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = round_as<T>(v[i]) + rv[i];
+            }
+            store4<T>(p.y + (size_t)row * p.ldy + col, v[0], v[1], v[2], v[3]);
         }
     }
 }
 
 // ---------------------------------------------------------------------------
 template <typename T, bool RELU>
-__global__ __launch_bounds__(256, 2) void ln_gemm_kernel(GemmArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(GemmArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sW = reinterpret_cast<T*>(smem_raw);                      // [BN][LDW]
     float* sG = reinterpret_cast<float*>(sW + BN * LDW);         // gamma[256], beta[256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
-    const int row_base = blockIdx.x * BM + wave * 32;
-    const int row = row_base + r;
+    const int row = blockIdx.x * BM + wave * 32 + r;
     sG[tid] = p.gamma[tid];
     sG[256 + tid] = p.beta[tid];
     // ---- LayerNorm prologue, in registers: lane (r, half) holds k = 16c + 8*half + j of row r
@@ -111,27 +123,27 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(GemmArgs<T> p) {
         p.stats[2 * (size_t)row] = mean;
         p.stats[2 * (size_t)row + 1] = rs;
     }
-    // ---- Y tiles: for each 128-column block, 4 k-chunks of 64
-    const int nsteps = ((p.N + BN - 1) / BN) * 4;
+    // ---- Y tiles: for each 128-column block, 4 k-chunks of 64 (kc unrolled: af[] stays in registers)
+    const int nblk = (p.N + BN - 1) / BN;
     Frag<T> wreg[4];
     tile_fetch<T>(wreg, p.w, 256, 0, p.N, 0, tid);
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-    for (int step = 0; step < nsteps; ++step) {
-        const int n0 = (step >> 2) * BN, kc = step & 3;
-        __syncthreads();
-        tile_commit<T>(sW, wreg, tid);
-        __syncthreads();
-        if (step + 1 < nsteps) tile_fetch<T>(wreg, p.w, 256, ((step + 1) >> 2) * BN, p.N, ((step + 1) & 3) * BK, tid);
+    for (int nb = 0; nb < nblk; ++nb) {
+        const int n0 = nb * BN;
+        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int kc = 0; kc < 4; ++kc) {
+            __syncthreads();
+            tile_commit<T>(sW, wreg, tid);
+            __syncthreads();
+            if (kc < 3) tile_fetch<T>(wreg, p.w, 256, n0, p.N, (kc + 1) * BK, tid);
+            else if (nb + 1 < nblk) tile_fetch<T>(wreg, p.w, 256, n0 + BN, p.N, 0, tid);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                mma<T>(acc[nt], af[4 * kc + c], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half));
-        if (kc == 3) {
-            epilogue<T, RELU>(acc, p, row_base, n0, r, half);
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x16{0};
+                for (int nt = 0; nt < 4; ++nt)
+                    mma<T>(acc[nt], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half), af[4 * kc + c]);
         }
+        epilogue<T, RELU>(acc, p, row, n0, half);
     }
 }
 
@@ -164,10 +176,132 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
             const Frag<T> a = frag_load<T>(sA + (32 * wave + r) * LDW + 16 * c + 8 * half);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                mma<T>(acc[nt], a, frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half));
+                mma<T>(acc[nt], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half), a);
         }
     }
-    epilogue<T, RELU>(acc, p, m0 + 32 * wave, n0, r, half);
+    epilogue<T, RELU>(acc, p, m0 + 32 * wave + r, n0, half);
+}
+
+// ---------------------------------------------------------------------------
+// dW = dY^T X.  Tile 128 (n) x 128 (k); the workgroup's M range is walked in steps of 64 tokens
+// whose dY / X tiles are staged TRANSPOSED in LDS ([col][token], 4 tokens per ds_write) so that
+// fragments are contiguous along the contraction (token) index.  4 waves as 2 x 2, 64 x 64 each.
+constexpr int TK = 64, LDX = TK + 8;
+
+template <typename T> struct TnArgs {
+    const T* dy; const T* x; float* slab;
+    int M, N, K, ldy, ldx, splits, rows_per_split;
+};
+
+template <typename T> MTMP_DEV void store_quad(T* p, T a, T b, T c, T d);
+template <> MTMP_DEV void store_quad<bf16>(bf16* p, bf16 a, bf16 b, bf16 c, bf16 d) {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{a, b, c, d};
+}
+template <> MTMP_DEV void store_quad<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+
+// 64 tokens x 128 cols -> registers: thread (q = tid&15: tokens 4q..4q+3, cg = tid>>4: cols 8cg..8cg+7)
+template <typename T>
+MTMP_DEV void tn_fetch(Frag<T> (&reg)[4], const T* src, int ld, int m0, int m_end, int c0, int tid) {
+    const int q = (tid & 15) * 4, cg = (tid >> 4) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        reg[i] = (m0 + q + i < m_end) ? frag_load<T>(src + (size_t)(m0 + q + i) * ld + c0 + cg) : frag_zero<T>();
+}
+template <typename T> MTMP_DEV void tn_commit(T* dst, const Frag<T> (&reg)[4], int tid) {
+    const int q = (tid & 15) * 4, cg = (tid >> 4) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) store_quad<T>(dst + (cg + e) * LDX + q, reg[0].v[e], reg[1].v[e], reg[2].v[e], reg[3].v[e]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sY = reinterpret_cast<T*>(smem_raw);   // [128 n][LDX tokens]
+    T* sX = sY + 128 * LDX;                   // [128 k][LDX tokens]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int tn = p.N / 128, tk = p.K / 128;
+    int w = blockIdx.x;
+    const int split = w / (tn * tk);
+    w -= split * tn * tk;
+    const int n0 = (w / tk) * 128, k0 = (w % tk) * 128;
+    const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // column sums of dY (bias gradient)
+    Frag<T> yreg[4], xreg[4];
+    tn_fetch<T>(yreg, p.dy, p.ldy, m_lo, m_end, n0, tid);
+    tn_fetch<T>(xreg, p.x, p.ldx, m_lo, m_end, k0, tid);
+    for (int m0 = m_lo; m0 < m_end; m0 += TK) {
+        __syncthreads();
+        tn_commit<T>(sY, yreg, tid);
+        tn_commit<T>(sX, xreg, tid);
+        if (k0 == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                csum[e] += to_f32(yreg[0].v[e]) + to_f32(yreg[1].v[e]) + to_f32(yreg[2].v[e]) + to_f32(yreg[3].v[e]);
+        }
+        __syncthreads();
+        if (m0 + TK < m_end) {
+            tn_fetch<T>(yreg, p.dy, p.ldy, m0 + TK, m_end, n0, tid);
+            tn_fetch<T>(xreg, p.x, p.ldx, m0 + TK, m_end, k0, tid);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const Frag<T> a0 = frag_load<T>(sY + (wn + r) * LDX + 16 * c + 8 * half);
+            const Frag<T> a1 = frag_load<T>(sY + (wn + 32 + r) * LDX + 16 * c + 8 * half);
+            const Frag<T> b0 = frag_load<T>(sX + (wk + r) * LDX + 16 * c + 8 * half);
+            const Frag<T> b1 = frag_load<T>(sX + (wk + 32 + r) * LDX + 16 * c + 8 * half);
+            mma<T>(acc[0][0], a0, b0); mma<T>(acc[0][1], a0, b1);
+            mma<T>(acc[1][0], a1, b0); mma<T>(acc[1][1], a1, b1);
+        }
+    }
+    // partial slab row: [N*K] products then [N] column sums
+    float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + wk + 32 * j + r] = acc[i][j][t];
+    if (k0 == 0) {
+        // threads with equal (tid>>4) hold the same 8 columns for different token quads: lanes 16g..16g+15
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = csum[e];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if ((tid & 15) == 0) out[(size_t)p.N * p.K + n0 + (tid >> 4) * 8 + e] = s;
+        }
+    }
+}
+
+// out[c] = sum_s slab[s][c]; a block owns 64 columns, 4 row-lanes reduce through LDS
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, int splits, size_t cols, float* dw, float* db,
+                                                        size_t nk) {
+    __shared__ float part[4][64];
+    const size_t c = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int q = rl; q < splits; q += 4) s += slab[(size_t)q * cols + c];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (c < nk) dw[c] = s;
+        else if (db) db[c - nk] = s;
+    }
+}
+
+int tn_splits(int M, int N, int K) {
+    const int tiles = (N / 128) * (K / 128);
+    int s = 640 / tiles;                                   // ~2.5 workgroups per CU in total
+    const int max_s = (M + 4 * TK - 1) / (4 * TK);         // at least 4 token steps per split
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
 }
 
 template <typename T>
@@ -195,6 +329,26 @@ int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
     MTMP_CHECK_LAUNCH("mtmp_gemm_nt");
     return MTMP_OK;
 }
+template <typename T>
+int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
+                   hipStream_t st) {
+    const int splits = tn_splits(M, N, K);
+    int rps = (M + splits - 1) / splits;
+    rps = (rps + TK - 1) / TK * TK;
+    TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
+    const size_t sm = (size_t)256 * LDX * sizeof(T);
+    if (sm > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+        mtmp_set_error("mtmp_gemm_tn: cannot raise dynamic LDS to %zu", sm);
+        return MTMP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(splits * (N / 128) * (K / 128)), dim3(256), sm, st, a);
+    MTMP_CHECK_LAUNCH("mtmp_gemm_tn");
+    const size_t nk = (size_t)N * K, cols = nk + N;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, ws, splits, cols, dw, db, nk);
+    MTMP_CHECK_LAUNCH("mtmp_gemm_tn(reduce)");
+    return MTMP_OK;
+}
 
 }  // namespace
 
@@ -205,7 +359,7 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
                             const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
                             float eps, int relu, float drop_p, unsigned seed, void* stream) {
     MTMP_CHECK_ARG(x && gamma && beta && w && y, "mtmp_ln_gemm: null pointer");
-    MTMP_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && ldx >= 256 && ldx % 8 == 0 && ldy >= N,
+    MTMP_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && ldx >= 256 && ldx % 8 == 0 && ldy >= N && ldy % 4 == 0,
                    "mtmp_ln_gemm: bad shape M=%d N=%d ldx=%d ldy=%d (K is fixed at 256)", M, N, ldx, ldy);
     MTMP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (double)M * N < 4294967296.0, "mtmp_ln_gemm: bad dropout %f", drop_p);
     hipStream_t st = (hipStream_t)stream;
@@ -223,14 +377,14 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
     return MTMP_ERR_ARG;
 }
 
-// Y[M,N] = act(A[M,K] W[N,K]^T + bias) (+ R[M,N]).  Replaces module.py:78 + encoder.py:32
-// (Conv1d(1024,256,1) + residual) and is the generic NT projection of the path.
+// Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32
+// (Conv1d(1024,256,1) + drop2 + residual) and is the generic NT projection of the path.
 extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
                             int M, int N, int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed,
                             void* stream) {
     MTMP_CHECK_ARG(a && w && y, "mtmp_gemm_nt: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
-                       (!res || ldr >= N),
+                       ldy % 4 == 0 && (!res || (ldr >= N && ldr % 4 == 0)),
                    "mtmp_gemm_nt: bad shape M=%d N=%d K=%d lda=%d ldy=%d ldr=%d", M, N, K, lda, ldy, ldr);
     MTMP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (double)M * N < 4294967296.0, "mtmp_gemm_nt: bad dropout %f", drop_p);
     hipStream_t st = (hipStream_t)stream;
@@ -245,6 +399,25 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
         return launch_gemm_nt<bf16>(g, relu, st);
     }
     mtmp_set_error("mtmp_gemm_nt: unknown dtype %d", dtype);
+    return MTMP_ERR_ARG;
+}
+
+extern "C" long long mtmp_gemm_tn_ws_floats(int M, int N, int K) {
+    return (long long)tn_splits(M, N, K) * ((long long)N * K + N);
+}
+
+// dW[N,K] (fp32) = dY[M,N]^T X[M,K];  db[N] (fp32, optional) = column sums of dY.  N, K multiples of
+// 128.  ws: mtmp_gemm_tn_ws_floats(M,N,K) floats.  The weight / bias gradients of the Linear and
+// k=1 Conv1d layers of attention.py:60-62 and module.py:74-78.
+extern "C" int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N,
+                            int K, int ldy, int ldx, void* stream) {
+    MTMP_CHECK_ARG(dy && x && dw && ws, "mtmp_gemm_tn: null pointer");
+    MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && ldy >= N && ldx >= K && ldy % 8 == 0 &&
+                       ldx % 8 == 0, "mtmp_gemm_tn: bad shape M=%d N=%d K=%d ldy=%d ldx=%d", M, N, K, ldy, ldx);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) return launch_gemm_tn<float>(dy, x, dw, db, ws, M, N, K, ldy, ldx, st);
+    if (dtype == 1) return launch_gemm_tn<bf16>(dy, x, dw, db, ws, M, N, K, ldy, ldx, st);
+    mtmp_set_error("mtmp_gemm_tn: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
 

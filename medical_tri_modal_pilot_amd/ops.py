@@ -70,6 +70,19 @@ def gemm_nt(a2d, w, bias=None, res2d=None, relu=False, drop_p=0.0, seed=0):
     return y
 
 
+def gemm_tn(dy2d, x2d, want_bias=True):
+    """(dW[N,K], db[N] | None) in fp32: dW = dy^T x, db = column sums of dy (split over the M tokens)."""
+    _gpu(dy2d, x2d)
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy2d.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy2d.device) if want_bias else None
+    ws = torch.empty(_lib.lib().mtmp_gemm_tn_ws_floats(M, N, K), dtype=torch.float32, device=dy2d.device)
+    call("mtmp_gemm_tn", _dt(dy2d), _p(dy2d), _p(x2d), _p(dw), _p(db), _p(ws), M, N, K, dy2d.stride(0),
+         x2d.stride(0), _stream())
+    return dw, db
+
+
 def attn_fwd(qkv, kv_len, res=None):
     """qkv [B,N,768] (q|k|v), kv_len int32[B] or None -> (o[B,N,256], o+res | None, lse[B,4,N])."""
     _gpu(qkv)
@@ -215,20 +228,17 @@ class EncoderLayerFn(torch.autograd.Function):
             d_out = d_out.to(z.dtype)
         # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
         dy2 = dropout_bwd(d_out, ctx.seeds[1], p) if p > 0 else d_out
-        dw2 = _mm_f32(dy2.t(), h)                         # [256,1024]
-        dc2 = dy2.sum(0, dtype=torch.float32)
+        dw2, dc2 = gemm_tn(dy2, h)                        # [256,1024], [256]
         dh = dy2 @ w2c                                    # [M,1024]
         dh = torch.where(h > 0, dh, torch.zeros((), dtype=dh.dtype, device=dh.device))
         if p > 0:
             dh = dh * (1.0 / (1.0 - p))                   # h > 0 already encodes relu AND drop1's mask
-        dw1 = _mm_f32(dh.t(), xn2)                        # [1024,256]
-        dc1 = dh.sum(0, dtype=torch.float32)
+        dw1, dc1 = gemm_tn(dh, xn2)                       # [1024,256], [1024]
         dxn2 = dh @ w1c                                   # [M,256]
         dr1, dg2, db2 = ln_bwd(r1.view(M, D), st2, g2, dxn2, d_res2d=d_out)
         # ---- attention: r1 = z + o  ->  d_o = dr1
         dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
-        dwqkv = _mm_f32(dqkv.t(), xn1)                    # [768,256]
-        dbqkv = dqkv.sum(0, dtype=torch.float32)
+        dwqkv, dbqkv = gemm_tn(dqkv, xn1)                 # [768,256], [768]
         dxn1 = dqkv @ wqkv                                # [M,256]
         dz, dg1, db1 = ln_bwd(z.view(M, D), st1, g1, dxn1, d_res2d=dr1)
         return (dz.view(B, N, D), None, dg1, db1,

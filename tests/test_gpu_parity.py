@@ -143,6 +143,18 @@ def test_ln_gemm_and_gemm_nt(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(3456, 768, 256), (1000, 256, 1024), (70, 1024, 256), (20033, 256, 1024)])
+def test_gemm_tn_weight_gradient(ops, dt, M, N, K):
+    g = torch.Generator().manual_seed(M)
+    dy = torch.randn(M, N, generator=g).to(dt).float()
+    x = torch.randn(M, K, generator=g).to(dt).float()
+    dw, db = ops.gemm_tn(dy.to(DEV, dt), x.to(DEV, dt))
+    t = f"gemm_tn[{str(dt)[6:]},M={M},N={N}]"
+    check(t + ".dw", dw, dy.double().t() @ x.double(), 1e-4 if dt == torch.float32 else 1e-4)   # fp32 accumulate either way
+    check(t + ".db", db, dy.double().sum(0), 1e-4)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_ln_bwd(ops, dt, golden_dir):
     g = torch.Generator().manual_seed(9)
     M = 777
