@@ -209,10 +209,29 @@ MTMP_DEV void tn_fetch(Frag<T> (&reg)[4], const T* src, int ld, int m0, int m_en
     for (int i = 0; i < 4; ++i)
         reg[i] = (m0 + q + i < m_end) ? frag_load<T>(src + (size_t)(m0 + q + i) * ld + c0 + cg) : frag_zero<T>();
 }
-template <typename T> MTMP_DEV void tn_commit(T* dst, const Frag<T> (&reg)[4], int tid) {
+// registers (4 tokens x 8 cols) -> LDS [col][token]: a 4x8 in-register transpose.  For bf16 it is
+// spelled with v_perm_b32 on the packed dwords (element-wise bf16 vector shuffles make hipcc
+// round-trip through scratch memory).
+template <typename T> MTMP_DEV void tn_commit(T* dst, const Frag<T> (&reg)[4], int tid);
+template <> MTMP_DEV void tn_commit<float>(float* dst, const Frag<float> (&reg)[4], int tid) {
     const int q = (tid & 15) * 4, cg = (tid >> 4) * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) store_quad<T>(dst + (cg + e) * LDX + q, reg[0].v[e], reg[1].v[e], reg[2].v[e], reg[3].v[e]);
+    for (int e = 0; e < 8; ++e) store_quad<float>(dst + (cg + e) * LDX + q, reg[0].v[e], reg[1].v[e], reg[2].v[e], reg[3].v[e]);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <> MTMP_DEV void tn_commit<bf16>(bf16* dst, const Frag<bf16> (&reg)[4], int tid) {
+    const int q = (tid & 15) * 4, cg = (tid >> 4) * 8;
+    const u32x4 r0 = __builtin_bit_cast(u32x4, reg[0].v), r1 = __builtin_bit_cast(u32x4, reg[1].v);
+    const u32x4 r2 = __builtin_bit_cast(u32x4, reg[2].v), r3 = __builtin_bit_cast(u32x4, reg[3].v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // v_perm_b32(src0, src1, sel): byte i of the result = byte sel[i] of {src0 (4..7), src1 (0..3)}
+        const u32x2 even = {__builtin_amdgcn_perm(r1[k], r0[k], 0x05040100u), __builtin_amdgcn_perm(r3[k], r2[k], 0x05040100u)};
+        const u32x2 odd = {__builtin_amdgcn_perm(r1[k], r0[k], 0x07060302u), __builtin_amdgcn_perm(r3[k], r2[k], 0x07060302u)};
+        *reinterpret_cast<u32x2*>(dst + (cg + 2 * k) * LDX + q) = even;
+        *reinterpret_cast<u32x2*>(dst + (cg + 2 * k + 1) * LDX + q) = odd;
+    }
 }
 
 template <typename T>
