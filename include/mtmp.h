@@ -59,9 +59,12 @@ int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta
                  unsigned seed, void* stream);
 
 /* y[M,N] = drop(act(a[M,K] w[N,K]^T + bias)) (+ res[M,N]); K % 64 == 0, N % 32 == 0.
- * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32). */
+ * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32).  With gate[M,N] != NULL the
+ * result is gated: y = gate > 0 ? y * gate_scale : 0 -- the backward of ReLU (+ drop1) applied to
+ * dH = dY W2 in the same pass (gate = the stored post-dropout activations). */
 int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N,
-                 int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed, void* stream);
+                 int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed, const void* gate,
+                 float gate_scale, void* stream);
 
 /* Weight / bias gradient of the Linear and k=1 Conv1d layers (attention.py:60-62, module.py:74-78):
  * dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db[N] (fp32, may be NULL) = column sums of dy.

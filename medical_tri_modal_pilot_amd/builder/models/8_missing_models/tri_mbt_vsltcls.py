@@ -173,7 +173,8 @@ class TRI_MBT_VSLTCLS(nn.Module):
             fixed_lengths=[vslt_embedding.size(1), img_embedding.size(1), txt_embedding.size(1)],
             varying_lengths=[input_lengths, img_len, txt_lengths + 2], fusion_idx=None, missing=missing)
         # ---- head (:248-255), fp32
-        cls = outputs[0][:, 0, :].float()
+        cls = self.fusion_transformer.last_cls             # outputs[0][:, 0, :] as a dedicated autograd output
+        cls = (outputs[0][:, 0, :] if cls is None else cls).float()
         class_input = self.layer_norms_after_concat(cls)
         if self.args.vslt_type != "QIE":
             class_input = torch.cat([class_input, demo_embedding], dim=1)

@@ -64,12 +64,22 @@ class TransformerEncoderLayer(nn.Module):
         key = (dtype,) + tuple((p._version, p.data_ptr()) for p in ps)
         if key != self._fused_key:
             with torch.no_grad():
+                w2 = ps[7].reshape(ps[7].shape[0], -1).to(dtype).contiguous()
                 self._fused = (torch.cat([ps[0], ps[1], ps[2]], 0).to(dtype).contiguous(),
                                torch.cat([ps[3], ps[4], ps[5]], 0).float().contiguous(),
                                ps[6].reshape(ps[6].shape[0], -1).to(dtype).contiguous(),
-                               ps[7].reshape(ps[7].shape[0], -1).to(dtype).contiguous())
+                               w2, w2.t().contiguous())
             self._fused_key = key
         return self._fused
+
+    def param_list(self):
+        """The 14 parameters in ops.PARAMS order."""
+        a, f = self.self_attention, self.feed_forward
+        return [self.attention_prenorm.gamma, self.attention_prenorm.beta,
+                a.query_proj.linear.weight, a.query_proj.linear.bias, a.key_proj.linear.weight, a.key_proj.linear.bias,
+                a.value_proj.linear.weight, a.value_proj.linear.bias,
+                self.feed_forward_prenorm.gamma, self.feed_forward_prenorm.beta,
+                f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias]
 
     def forward(self, inputs: torch.Tensor, self_attn_mask: Optional[torch.Tensor] = None):
         """inputs [B,N,256] (fp32 or bf16 on the GPU); self_attn_mask: int [B] valid-key counts, or the
@@ -80,14 +90,10 @@ class TransformerEncoderLayer(nn.Module):
             kv_len = pad_mask_to_kv_len(kv_len)
         if kv_len is not None:
             kv_len = kv_len.to(device=inputs.device, dtype=torch.int32).contiguous()
-        a, f = self.self_attention, self.feed_forward
-        p = self.dropout_p if self.training else 0.0
-        seeds = (next_dropout_seed(), next_dropout_seed()) if p > 0 else (0, 0)
-        out = ops.EncoderLayerFn.apply(
-            inputs, kv_len, self.attention_prenorm.gamma, self.attention_prenorm.beta,
-            a.query_proj.linear.weight, a.query_proj.linear.bias, a.key_proj.linear.weight, a.key_proj.linear.bias,
-            a.value_proj.linear.weight, a.value_proj.linear.bias,
-            self.feed_forward_prenorm.gamma, self.feed_forward_prenorm.beta,
-            f.w_1.weight, f.w_1.bias, f.w_2.weight, f.w_2.bias,
-            self._fused_weights(inputs.dtype), p, seeds)
+        p, seeds = self.dropout_args()
+        out = ops.EncoderLayerFn.apply(inputs, kv_len, *self.param_list(), self._fused_weights(inputs.dtype), p, seeds)
         return out, None
+
+    def dropout_args(self):
+        p = self.dropout_p if self.training else 0.0
+        return p, ((next_dropout_seed(), next_dropout_seed()) if p > 0 else (0, 0))

@@ -35,16 +35,30 @@ MTMP_DEV void flush_partials(float (&acc)[NV][4], float* slab_row, float* lds, i
 
 // out[c] = sum_r slab[r][c]: a block owns 64 columns; 4 row-lanes sum interleaved rows (coalesced
 // 256-byte reads) and combine through LDS in a fixed order (bitwise reproducible).
+// blockIdx.y = row group g of gridDim.y: rows g, g + G, g + 2G ... ; out is [gridDim.y][cols].
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int rows, int cols, float* out) {
     __shared__ float part[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
+    const int G = gridDim.y;
     float s = 0.f;
     if (c < cols)
-        for (int r = rl; r < rows; r += 4) s += slab[(size_t)r * cols + c];
+        for (int r = blockIdx.y + rl * G; r < rows; r += 4 * G) s += slab[(size_t)r * cols + c];
     part[rl][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rl == 0 && c < cols) out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (rl == 0 && c < cols)
+        out[(size_t)blockIdx.y * cols + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+constexpr int RED_GROUPS = 16;
+// two-level tree: [rows][cols] -> [16][cols] (in ws_tail) -> out[cols]
+inline void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_tail, float* out, hipStream_t st) {
+    const int gx = (cols + 63) / 64;
+    if (rows <= 4 * RED_GROUPS) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, slab, rows, cols, out);
+    } else {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, RED_GROUPS), dim3(256), 0, st, slab, rows, cols, ws_tail);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)ws_tail, RED_GROUPS, cols, out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -211,7 +225,7 @@ int grid_for_rows(int rows) { return max(1, min((rows + 3) / 4, 512)); }
 
 }  // namespace
 
-extern "C" int mtmp_ln_bwd_ws_floats(int M) { return grid_for_rows(M) * 2 * D; }
+extern "C" int mtmp_ln_bwd_ws_floats(int M) { return (grid_for_rows(M) + RED_GROUPS) * 2 * D; }
 
 // dz[M,256] = LNbackward(dy; z, stats, gamma) (+ d_res);  dgamma[256], dbeta[256] overwritten.
 // ws: mtmp_ln_bwd_ws_floats(M) floats.  Backward of module.py:138-144 (+ the residual of encoder.py:24-32).
@@ -230,7 +244,7 @@ extern "C" int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats
                            (const bf16*)dy, (const bf16*)d_res, ldr, (bf16*)dz, M, eps, ws);
     else { mtmp_set_error("mtmp_ln_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_ln_bwd");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(2 * D / 64), dim3(256), 0, st, ws, nb, 2 * D, dgamma_dbeta);
+    launch_slab_reduce(ws, nb, 2 * D, ws + (size_t)nb * 2 * D, dgamma_dbeta, st);
     MTMP_CHECK_LAUNCH("mtmp_ln_bwd(reduce)");
     return MTMP_OK;
 }
@@ -248,7 +262,7 @@ extern "C" int mtmp_tie_embed_fwd(int dtype, const float* events, const float* p
     return MTMP_OK;
 }
 
-extern "C" int mtmp_tie_bwd_ws_floats(int n) { return max(1, min((n + 3) / 4, 512)) * 28 * D; }
+extern "C" int mtmp_tie_bwd_ws_floats(int n) { return (max(1, min((n + 3) / 4, 512)) + RED_GROUPS) * 28 * D; }
 
 // grads[28][256] fp32 (8 chain vectors in params order, then the 20 feature-table rows) overwritten.
 extern "C" int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
@@ -260,7 +274,7 @@ extern "C" int mtmp_tie_embed_bwd(int dtype, const float* events, const float* p
     else if (dtype == 1) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, n, ws);
     else { mtmp_set_error("mtmp_tie_embed_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd");
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(28 * D / 64), dim3(256), 0, st, ws, nb, 28 * D, grads);
+    launch_slab_reduce(ws, nb, 28 * D, ws + (size_t)nb * 28 * D, grads, st);
     MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd(reduce)");
     return MTMP_OK;
 }

@@ -33,6 +33,8 @@ template <typename T> struct GemmArgs {
     float eps;
     float drop_p;        // nn.Dropout probability applied after act (0 = off), module.py:77-79
     unsigned seed;       // per-call seed of the counter-based mask (common.cuh: dropout_keep)
+    const T* gate;       // optional [M,N]: y = gate > 0 ? y * gate_scale : 0  (ReLU/dropout backward)
+    float gate_scale;
 };
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread); rows >= limit give zeros.
@@ -70,6 +72,11 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, in
                 if (RELU) v[i] = fmaxf(v[i], 0.f);
                 if (p.drop_p > 0.f)
                     v[i] = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)(col + i), thr) ? v[i] * keep_scale : 0.f;
+            }
+            if (p.gate) {
+                const f32x4 gv = load4<T>(p.gate + (size_t)row * p.N + col);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = gv[i] > 0.f ? v[i] * p.gate_scale : 0.f;
             }
             if (p.res) {
                 const f32x4 rv = load4<T>(p.res + (size_t)row * p.ldr + col);
@@ -384,12 +391,12 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> a{(const float*)x, (const float*)w, bias, nullptr, (float*)y, gamma, beta, (float*)xn, stats,
-                          M, N, 256, ldx, ldy, 0, eps, drop_p, seed};
+                          M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f};
         return launch_ln_gemm<float>(a, relu, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, gamma, beta, (bf16*)xn, stats,
-                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed};
+                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f};
         return launch_ln_gemm<bf16>(a, relu, st);
     }
     mtmp_set_error("mtmp_ln_gemm: unknown dtype %d", dtype);
@@ -400,7 +407,7 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
 // (Conv1d(1024,256,1) + drop2 + residual) and is the generic NT projection of the path.
 extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
                             int M, int N, int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed,
-                            void* stream) {
+                            const void* gate, float gate_scale, void* stream) {
     MTMP_CHECK_ARG(a && w && y, "mtmp_gemm_nt: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
                        ldy % 4 == 0 && (!res || (ldr >= N && ldr % 4 == 0)),
@@ -409,12 +416,12 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> g{(const float*)a, (const float*)w, bias, (const float*)res, (float*)y, nullptr, nullptr,
-                          nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed};
+                          nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const float*)gate, gate_scale};
         return launch_gemm_nt<float>(g, relu, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, bias, (const bf16*)res, (bf16*)y, nullptr, nullptr, nullptr,
-                         nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed};
+                         nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const bf16*)gate, gate_scale};
         return launch_gemm_nt<bf16>(g, relu, st);
     }
     mtmp_set_error("mtmp_gemm_nt: unknown dtype %d", dtype);

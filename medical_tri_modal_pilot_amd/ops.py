@@ -59,14 +59,15 @@ def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, wa
     return y, xn, stats
 
 
-def gemm_nt(a2d, w, bias=None, res2d=None, relu=False, drop_p=0.0, seed=0):
-    """y = drop(act(a w^T + bias)) (+ res)."""
+def gemm_nt(a2d, w, bias=None, res2d=None, relu=False, drop_p=0.0, seed=0, gate=None, gate_scale=1.0):
+    """y = drop(act(a w^T + bias)) (+ res); with gate[M,N]: y = gate > 0 ? y*gate_scale : 0."""
     _gpu(a2d, w)
     M, K = a2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=a2d.dtype, device=a2d.device)
     call("mtmp_gemm_nt", _dt(a2d), _p(a2d), _p(w), _p(bias), _p(res2d), _p(y), M, N, K, a2d.stride(0), N,
-         0 if res2d is None else res2d.stride(0), int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _stream())
+         0 if res2d is None else res2d.stride(0), int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _p(gate),
+         float(gate_scale), _stream())
     return y
 
 
@@ -185,62 +186,226 @@ class TieEmbed(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- encoder layer
+# One pre-LN encoder block (builder/models/src/transformer/encoder.py:23-34) on a [B, N, 256]
+# stream with per-sample valid-key counts:
+#     r1  = z + MHA(LN1(z); kv_len)          mtmp_ln_gemm(QKV) + mtmp_attn_fwd(+residual)
+#     out = r1 + FFN(LN2(r1))                mtmp_ln_gemm(ReLU, drop1) + mtmp_gemm_nt(drop2, +residual)
+# The backward is written out by hand (no autograd graph inside): HIP kernels for attention,
+# LayerNorm, dropout, dW (split-M "TN" GEMM with the bias gradient fused) and the ReLU-gated
+# dH; plain BLAS GEMMs for the two remaining dX products.  Activations needed by the backward
+# are kept (HBM is 288 GB; one vslt layer at B=64, T=1000 keeps ~0.4 GB in bf16).
+PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, c2
+
+
+def layer_forward(z, kv_len, P, fused, drop_p, seeds):
+    """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T) in compute dtype.
+    Returns (out [B,N,256], saved tuple)."""
+    B, N, D = z.shape
+    M = B * N
+    g1, b1, g2, b2, c1, c2 = P[0], P[1], P[8], P[9], P[11], P[13]
+    wqkv, bqkv, w1c, w2c, w2t = fused
+    z2 = z.view(M, D)
+    qkv, xn1, st1 = ln_gemm(z2, g1, b1, wqkv, bqkv, 3 * D)
+    qkv = qkv.view(B, N, 3 * D)
+    o, r1, lse = attn_fwd(qkv, kv_len, res=z)
+    r1_2 = r1.view(M, D)
+    h, xn2, st2 = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0])
+    out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
+    saved = (z, kv_len, g1, g2, wqkv, w1c, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds)
+    return out.view(B, N, D), saved
+
+
+def layer_backward(saved, d_out):
+    """d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
+    in PARAMS order; weights as 2-D [out,in]))."""
+    z, kv_len, g1, g2, wqkv, w1c, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds = saved
+    B, N, D = z.shape
+    M = B * N
+    d_out = d_out.view(M, D)
+    # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
+    dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
+    dw2, dc2 = gemm_tn(dy2, h)                              # [256,1024], [256]
+    # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue
+    dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
+    dw1, dc1 = gemm_tn(dh, xn2)                             # [1024,256], [1024]
+    dxn2 = dh @ w1c                                         # [M,256]   (plain BLAS)
+    dr1, dg2, db2 = ln_bwd(r1.view(M, D), st2, g2, dxn2, d_res2d=d_out)
+    # ---- attention: r1 = z + o  ->  d_o = dr1
+    dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
+    dwqkv, dbqkv = gemm_tn(dqkv, xn1)                       # [768,256], [768]
+    dxn1 = dqkv @ wqkv                                      # [M,256]   (plain BLAS)
+    dz, dg1, db1 = ln_bwd(z.view(M, D), st1, g1, dxn1, d_res2d=dr1)
+    grads = (dg1, db1, dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
+             dg2, db2, dw1, dc1, dw2, dc2)
+    return dz.view(B, N, D), grads
+
+
 class EncoderLayerFn(torch.autograd.Function):
-    """One pre-LN encoder block (builder/models/src/transformer/encoder.py:23-34) on a
-    [B, N, 256] stream with per-sample valid-key counts:
-
-        r1  = z + MHA(LN1(z); kv_len)          mtmp_ln_gemm(QKV) + mtmp_attn_fwd(+residual)
-        out = r1 + FFN(LN2(r1))                mtmp_ln_gemm(ReLU, drop1) + mtmp_gemm_nt(drop2, +residual)
-
-    Backward is written out by hand (no autograd graph inside): HIP kernels for attention,
-    LayerNorm and dropout; plain BLAS GEMMs for dW / dX.  Activations needed by the backward
-    are kept (HBM is 288 GB; one vslt layer at B=64, T=1000 keeps ~0.4 GB in bf16).
-    """
+    """layer_forward / layer_backward as one autograd node (layer-level API and tests)."""
 
     @staticmethod
-    def forward(ctx, z, kv_len, g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, c2, fused, drop_p, seeds):
+    def forward(ctx, z, kv_len, *rest):
         _gpu(z)
-        z = _c(z)
-        B, N, D = z.shape
-        M = B * N
-        dt = z.dtype
-        wqkv, bqkv, w1c, w2c = fused           # compute-dtype weights prepared by the module
-        z2 = z.view(M, D)
-        qkv, xn1, st1 = ln_gemm(z2, g1, b1, wqkv, bqkv, 3 * D)
-        qkv = qkv.view(B, N, 3 * D)
-        o, r1, lse = attn_fwd(qkv, kv_len, res=z)
-        r1_2 = r1.view(M, D)
-        h, xn2, st2 = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0])
-        out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
-        ctx.save_for_backward(z, kv_len, g1, g2, wqkv, w1c, w2c, xn1, st1, qkv, o, lse, r1, xn2, st2, h)
-        ctx.drop_p, ctx.seeds = drop_p, seeds
-        ctx.wshapes = (w1.shape, w2.shape)
-        return out.view(B, N, D)
+        P, (fused, drop_p, seeds) = rest[:PARAMS_PER_LAYER], rest[PARAMS_PER_LAYER:]
+        out, saved = layer_forward(_c(z), kv_len, P, fused, drop_p, seeds)
+        ctx.saved = saved
+        ctx.wshapes = (P[10].shape, P[12].shape)
+        return out
 
     @staticmethod
     def backward(ctx, d_out):
-        z, kv_len, g1, g2, wqkv, w1c, w2c, xn1, st1, qkv, o, lse, r1, xn2, st2, h = ctx.saved_tensors
-        B, N, D = z.shape
-        M = B * N
-        p = ctx.drop_p
-        d_out = _c(d_out).view(M, D)
+        z = ctx.saved[0]
+        d_out = _c(d_out)
         if d_out.dtype != z.dtype:
             d_out = d_out.to(z.dtype)
-        # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
-        dy2 = dropout_bwd(d_out, ctx.seeds[1], p) if p > 0 else d_out
-        dw2, dc2 = gemm_tn(dy2, h)                        # [256,1024], [256]
-        dh = dy2 @ w2c                                    # [M,1024]
-        dh = torch.where(h > 0, dh, torch.zeros((), dtype=dh.dtype, device=dh.device))
-        if p > 0:
-            dh = dh * (1.0 / (1.0 - p))                   # h > 0 already encodes relu AND drop1's mask
-        dw1, dc1 = gemm_tn(dh, xn2)                       # [1024,256], [1024]
-        dxn2 = dh @ w1c                                   # [M,256]
-        dr1, dg2, db2 = ln_bwd(r1.view(M, D), st2, g2, dxn2, d_res2d=d_out)
-        # ---- attention: r1 = z + o  ->  d_o = dr1
-        dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
-        dwqkv, dbqkv = gemm_tn(dqkv, xn1)                 # [768,256], [768]
-        dxn1 = dqkv @ wqkv                                # [M,256]
-        dz, dg1, db1 = ln_bwd(z.view(M, D), st1, g1, dxn1, d_res2d=dr1)
-        return (dz.view(B, N, D), None, dg1, db1,
-                dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
-                dg2, db2, dw1.view(ctx.wshapes[0]), dc1, dw2.view(ctx.wshapes[1]), dc2, None, None, None)
+        dz, g = layer_backward(ctx.saved, d_out)
+        g = list(g)
+        g[10], g[12] = g[10].view(ctx.wshapes[0]), g[12].view(ctx.wshapes[1])
+        return (dz, None, *g, None, None, None)
+
+
+# ----------------------------------------------------------------------------- fusion stack engine
+_EXCHANGE_W = torch.tensor([[1 / 3, 1 / 3, 1 / 3], [0.5, 0.5, 0.0], [0.5, 0.0, 0.5], [1.0, 0.0, 0.0]])
+NB = 4   # bottleneck tokens
+
+
+class FusionStackFn(torch.autograd.Function):
+    """All fusion layers of TrimodalTransformerEncoder_MBT (mbt_encoder.py:731-779) as ONE autograd
+    node with explicit buffers.  Every stream lives in a [B, 4+N, 256] buffer whose first four rows
+    are the bottleneck tokens; a layer writes a new buffer, the bottleneck exchange overwrites its
+    rows 0..3 in place, and that buffer IS the next layer's input -- no torch.cat / slice copies
+    (the reference re-concatenates every stream in every layer, :745).  The three modality streams
+    of a layer are issued on separate HIP streams (the 54- and 133-token streams cannot fill 256 CUs
+    on their own).  The backward replays the stack in reverse with the hand-written layer backward.
+
+    apply(xv, xi, xt, bottlenecks, *layer_params, cfg) -> (out_v, out_i, out_t, cls_v); cfg is a dict:
+      n_layers, vsltonly, resbottle, kv (list of int32[B] | None per stream, bottleneck prefix
+      included), missing (int64[B]), drop_p, seeds[l][m], fused[l][m], dtype, side_streams
+    """
+
+    @staticmethod
+    def forward(ctx, xv, xi, xt, bott, *rest):
+        cfg = rest[-1]
+        params = rest[:-1]
+        L, dt = cfg["n_layers"], cfg["dtype"]
+        xs = [xv, xi, xt]
+        _gpu(xv)
+        B, dev = xv.shape[0], xv.device
+        Ns = [x.shape[1] + NB for x in xs]
+        z = []
+        for m, x in enumerate(xs):
+            buf = torch.empty(B, Ns[m], D_MODEL, dtype=dt, device=dev)
+            buf[:, NB:] = x
+            buf[:, :NB] = bott.to(dt)
+            z.append(buf)
+        wsel = _EXCHANGE_W.to(dev)[cfg["missing"]]                      # [B,3] exchange weights per sample
+        streams = cfg.get("side_streams")
+        cur = torch.cuda.current_stream()
+        saved, active = [], []
+        prev_bott = bott.expand(B, -1, -1).float()
+        for li in range(L):
+            last = cfg["vsltonly"] == 1 and li == L - 1
+            ms = [0] if last else [0, 1, 2]
+            outs = [None, None, None]
+            row = [None, None, None]
+            if streams is not None and len(ms) > 1:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            for m in ms:
+                P = params[(li * 3 + m) * PARAMS_PER_LAYER:(li * 3 + m + 1) * PARAMS_PER_LAYER]
+                if streams is not None and m > 0:
+                    s = streams[m - 1]
+                    s.wait_event(ev)
+                    with torch.cuda.stream(s):
+                        outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
+                                                        cfg["seeds"][li][m])
+                else:
+                    outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
+                                                    cfg["seeds"][li][m])
+            if streams is not None and len(ms) > 1:
+                for s in streams:
+                    cur.wait_stream(s)
+            saved.append(row)
+            active.append(ms)
+            if last:
+                z = outs
+                break
+            # bottleneck exchange (:764-779) on the [B,4,256] prefixes, written back in place
+            bo = torch.stack([outs[m][:, :NB].float() for m in range(3)], 1)        # [B,3,4,256]
+            newb = (bo * wsel[:, :, None, None]).sum(1)
+            if cfg["resbottle"]:
+                newb = (newb + prev_bott) * 0.5
+            prev_bott = newb
+            nb_dt = newb.to(dt)
+            for m in range(3):
+                outs[m][:, :NB] = nb_dt
+            z = outs
+        ctx.saved, ctx.active, ctx.cfg, ctx.wsel = saved, active, cfg, wsel
+        ctx.shapes = (B, Ns, [p.shape for p in params])
+        ctx.set_materialize_grads(False)
+        outs_full = [z[m] if z[m] is not None else torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) for m in range(3)]
+        ctx.mark_non_differentiable(*[o for m, o in enumerate(outs_full) if z[m] is None])
+        cls_v = outs_full[0][:, NB, :].clone()
+        return outs_full[0], outs_full[1], outs_full[2], cls_v
+
+    @staticmethod
+    def backward(ctx, d_v, d_i, d_t, d_cls):
+        cfg, saved, active, wsel = ctx.cfg, ctx.saved, ctx.active, ctx.wsel
+        B, Ns, pshapes = ctx.shapes
+        L, dt = cfg["n_layers"], cfg["dtype"]
+        dev = wsel.device
+        streams = cfg.get("side_streams")
+        cur = torch.cuda.current_stream()
+        n_run = len(saved)
+        # gradient w.r.t. the last executed layer's outputs
+        dz = [None, None, None]
+        for m, g in enumerate((d_v, d_i, d_t)):
+            if m in active[-1]:
+                dz[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) if g is None else _c(g).to(dt).clone()
+        if d_cls is not None:
+            dz[0][:, NB, :] += d_cls.to(dt)
+        pgrads = [None] * len(pshapes)
+        d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
+        for li in range(n_run - 1, -1, -1):
+            ms = active[li]
+            if not (cfg["vsltonly"] == 1 and li == L - 1):
+                # this layer's outputs went through an exchange before feeding layer li+1:
+                # d_newb = sum over consumers' bottleneck rows; distribute by the exchange weights
+                d_newb = sum(dz[m][:, :NB].float() for m in range(3) if dz[m] is not None)
+                if d_prev_bott is not None:
+                    d_newb = d_newb + d_prev_bott
+                if cfg["resbottle"]:
+                    d_prev_bott = d_newb * 0.5
+                    d_newb = d_newb * 0.5
+                for m in range(3):
+                    dz[m][:, :NB] = (d_newb * wsel[:, m, None, None]).to(dt)
+            nxt = [None, None, None]
+            if streams is not None and len(ms) > 1:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+            for m in ms:
+                if streams is not None and m > 0:
+                    s = streams[m - 1]
+                    s.wait_event(ev)
+                    with torch.cuda.stream(s):
+                        nxt[m], g = layer_backward(saved[li][m], dz[m])
+                else:
+                    nxt[m], g = layer_backward(saved[li][m], dz[m])
+                base = (li * 3 + m) * PARAMS_PER_LAYER
+                for k in range(PARAMS_PER_LAYER):
+                    pgrads[base + k] = g[k].view(pshapes[base + k])
+            if streams is not None and len(ms) > 1:
+                for s in streams:
+                    cur.wait_stream(s)
+            saved[li] = None
+            # streams skipped by the vslt-only last layer re-enter here with zero gradient
+            if len(ms) == 1 and li > 0:
+                for m in (1, 2):
+                    nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
+            dz = nxt
+        d_bott = sum(dz[m][:, :NB].float() for m in range(3) if dz[m] is not None)
+        if d_prev_bott is not None:
+            d_bott = d_bott + d_prev_bott
+        d_bott = d_bott.sum(0, keepdim=True)
+        dx = [None if dz[m] is None else dz[m][:, NB:] for m in range(3)]
+        return (dx[0], dx[1], dx[2], d_bott, *pgrads, None)
