@@ -378,8 +378,11 @@ def _run_steps(dtype, multi, tag, fused):
               x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None, missing=bt["missing"],
               reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
     grads = {}
-    hooks = [p.register_post_accumulate_grad_hook(lambda p_, n_=n: grads.__setitem__(n_, p_.grad.detach().clone()))
-             for n, p in model.named_parameters()]
+    def keep(p_, n_):
+        if p_.grad is not None:       # parameters of skipped blocks reach the hook with an undefined gradient
+            grads[n_] = p_.grad.detach().clone()
+
+    hooks = [p.register_post_accumulate_grad_hook(lambda p_, n_=n: keep(p_, n_)) for n, p in model.named_parameters()]
     _, loss1 = get_trainer(iteration=1, input_lengths=bt["input_lengths"].clone(),
                            txt_lengths=bt["txt_lengths"].clone(), flow_type="train", **kw)
     for h in hooks:
