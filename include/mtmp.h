@@ -62,9 +62,12 @@ int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta
  * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32).  With gate[M,N] != NULL the
  * result is gated: y = gate > 0 ? y * gate_scale : 0 -- the backward of ReLU (+ drop1) applied to
  * dH = dY W2 in the same pass (gate = the stored post-dropout activations). */
+/* act: 0 none, 1 ReLU, 2 exact GELU; K % 8 == 0 (a 64-wide chunk's tail reads as zero);
+ * row_scale[M / rows_per_scale] (may be NULL) multiplies row blocks before the residual add
+ * (row-mode StochasticDepth of the Swin blocks). */
 int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N,
-                 int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed, const void* gate,
-                 float gate_scale, void* stream);
+                 int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed, const void* gate,
+                 float gate_scale, const float* row_scale, int rows_per_scale, void* stream);
 
 /* Weight / bias gradient of the Linear and k=1 Conv1d layers (attention.py:60-62, module.py:74-78):
  * dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db[N] (fp32, may be NULL) = column sums of dy.
@@ -101,6 +104,19 @@ int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, cons
  * img float[n_img,1,H,W]; out [n_img,H/4,W/4,96] in `dtype`. */
 int mtmp_swin_stem_fwd(int dtype, const float* img, const float* w, const float* bias, const float* ln_w,
                        const float* ln_b, void* out, int n_img, int H, int W, void* stream);
+
+/* nn.LayerNorm(C) over rows (Swin norm1/norm2/final norm, swin_transformer.py:428-449,611-612);
+ * merge != 0 fuses the 2x2 patch-merging gather of swin_transformer.py:34-44: x is [n,H,W,C/4],
+ * rows = n*(H/2)*(W/2).  w,b fp32; C even, <= 1536. */
+int mtmp_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* y, long long rows, int C,
+                        float eps, int merge, int H, int W, void* stream);
+
+/* Shifted-window attention (swin_transformer.py:115-225, V1 branch) on the un-shifted NHWC map:
+ * qkv [n,H,W,3C] -> out [n,H,W,C]; window 7x7, head_dim 32, H % 7 == W % 7 == 0.
+ * table [4 window types][heads][64][64] in `dtype` = relative-position bias + shift mask
+ * (type = 2*(last window row) + (last window col), 0 when shift == 0), -30000 on pad keys. */
+int mtmp_swin_window_attn(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W, int C,
+                          int heads, int shift, float scale, void* stream);
 
 /* Fused AdamW (2_train.py:110, torch.optim.AdamW math) over flat fp32 buffers of n elements
  * (n % 4 == 0); optional bf16 shadow copy of the parameters; grad is multiplied by grad_scale

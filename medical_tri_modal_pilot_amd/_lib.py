@@ -20,7 +20,10 @@ SIGNATURES = {
     "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
     "mtmp_ln_gemm": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_float, c_uint, c_void_p]),
-    "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_float, c_void_p]),
+    "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_float, c_void_p, c_int,
+                             c_void_p]),
+    "mtmp_layernorm_rows": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p]),
+    "mtmp_swin_window_attn": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "mtmp_gemm_tn_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "mtmp_gemm_tn": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "mtmp_ln_bwd_ws_floats": (c_int, [c_int]),

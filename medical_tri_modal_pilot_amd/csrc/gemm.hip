@@ -35,15 +35,19 @@ template <typename T> struct GemmArgs {
     unsigned seed;       // per-call seed of the counter-based mask (common.cuh: dropout_keep)
     const T* gate;       // optional [M,N]: y = gate > 0 ? y * gate_scale : 0  (ReLU/dropout backward)
     float gate_scale;
+    int act;             // 0 none, 1 ReLU, 2 exact GELU (Swin MLP, swin_transformer.py:439)
+    const float* row_scale;   // optional per-sample factor (row-mode StochasticDepth): y *= row_scale[row / rows_per_scale]
+    int rows_per_scale;
 };
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread); rows >= limit give zeros.
 template <typename T>
-MTMP_DEV void tile_fetch(Frag<T> (&reg)[4], const T* src, int ld, int row0, int limit, int k0, int tid) {
+MTMP_DEV void tile_fetch(Frag<T> (&reg)[4], const T* src, int ld, int row0, int limit, int k0, int tid, int kmax = 1 << 30) {
+    const int kc = k0 + (tid & 7) * 8;             // columns >= kmax (K tail of a 64-wide chunk) read as zero
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int row = row0 + (tid >> 3) + 32 * ps;
-        reg[ps] = (row < limit) ? frag_load<T>(src + (size_t)row * ld + k0 + (tid & 7) * 8) : frag_zero<T>();
+        reg[ps] = (row < limit && kc < kmax) ? frag_load<T>(src + (size_t)row * ld + kc) : frag_zero<T>();
     }
 }
 template <typename T> MTMP_DEV void tile_commit(T* dst, const Frag<T> (&reg)[4], int tid) {
@@ -69,7 +73,8 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, in
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i] = acc[nt][4 * g + i] + bv[i];
-                if (RELU) v[i] = fmaxf(v[i], 0.f);
+                if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
+                if (p.act == 2) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
                 if (p.drop_p > 0.f)
                     v[i] = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)(col + i), thr) ? v[i] * keep_scale : 0.f;
             }
@@ -77,6 +82,11 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, in
                 const f32x4 gv = load4<T>(p.gate + (size_t)row * p.N + col);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = gv[i] > 0.f ? v[i] * p.gate_scale : 0.f;
+            }
+            if (p.row_scale) {
+                const float rsv = p.row_scale[row / p.rows_per_scale];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] *= rsv;
             }
             if (p.res) {
                 const f32x4 rv = load4<T>(p.res + (size_t)row * p.ldr + col);
@@ -164,10 +174,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
     const int ntn = (p.N + BN - 1) / BN;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (w / ntn) * BM, n0 = (w % ntn) * BN;
-    const int nk = p.K / BK;
+    const int nk = (p.K + BK - 1) / BK;
     Frag<T> areg[4], wreg[4];
-    tile_fetch<T>(areg, p.a, p.lda, m0, p.M, 0, tid);
-    tile_fetch<T>(wreg, p.w, p.K, n0, p.N, 0, tid);
+    tile_fetch<T>(areg, p.a, p.lda, m0, p.M, 0, tid, p.K);
+    tile_fetch<T>(wreg, p.w, p.K, n0, p.N, 0, tid, p.K);
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
     for (int kc = 0; kc < nk; ++kc) {
         __syncthreads();
@@ -175,8 +185,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
         tile_commit<T>(sW, wreg, tid);
         __syncthreads();
         if (kc + 1 < nk) {
-            tile_fetch<T>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid);
-            tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 1) * BK, tid);
+            tile_fetch<T>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid, p.K);
+            tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 1) * BK, tid, p.K);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -391,12 +401,12 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> a{(const float*)x, (const float*)w, bias, nullptr, (float*)y, gamma, beta, (float*)xn, stats,
-                          M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f};
+                          M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f, 0, nullptr, 1};
         return launch_ln_gemm<float>(a, relu, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, gamma, beta, (bf16*)xn, stats,
-                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f};
+                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f, 0, nullptr, 1};
         return launch_ln_gemm<bf16>(a, relu, st);
     }
     mtmp_set_error("mtmp_ln_gemm: unknown dtype %d", dtype);
@@ -406,23 +416,27 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
 // Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32
 // (Conv1d(1024,256,1) + drop2 + residual) and is the generic NT projection of the path.
 extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
-                            int M, int N, int K, int lda, int ldy, int ldr, int relu, float drop_p, unsigned seed,
-                            const void* gate, float gate_scale, void* stream) {
+                            int M, int N, int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed,
+                            const void* gate, float gate_scale, const float* row_scale, int rows_per_scale,
+                            void* stream) {
     MTMP_CHECK_ARG(a && w && y, "mtmp_gemm_nt: null pointer");
-    MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
+    MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
                        ldy % 4 == 0 && (!res || (ldr >= N && ldr % 4 == 0)),
                    "mtmp_gemm_nt: bad shape M=%d N=%d K=%d lda=%d ldy=%d ldr=%d", M, N, K, lda, ldy, ldr);
     MTMP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (double)M * N < 4294967296.0, "mtmp_gemm_nt: bad dropout %f", drop_p);
+    MTMP_CHECK_ARG(act >= 0 && act <= 2 && (!row_scale || rows_per_scale > 0), "mtmp_gemm_nt: bad act %d / row_scale", act);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> g{(const float*)a, (const float*)w, bias, (const float*)res, (float*)y, nullptr, nullptr,
-                          nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const float*)gate, gate_scale};
-        return launch_gemm_nt<float>(g, relu, st);
+                          nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const float*)gate, gate_scale, act, row_scale,
+                          rows_per_scale};
+        return launch_gemm_nt<float>(g, 0, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, bias, (const bf16*)res, (bf16*)y, nullptr, nullptr, nullptr,
-                         nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const bf16*)gate, gate_scale};
-        return launch_gemm_nt<bf16>(g, relu, st);
+                         nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const bf16*)gate, gate_scale, act, row_scale,
+                         rows_per_scale};
+        return launch_gemm_nt<bf16>(g, 0, st);
     }
     mtmp_set_error("mtmp_gemm_nt: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;

@@ -59,16 +59,49 @@ def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, wa
     return y, xn, stats
 
 
-def gemm_nt(a2d, w, bias=None, res2d=None, relu=False, drop_p=0.0, seed=0, gate=None, gate_scale=1.0):
-    """y = drop(act(a w^T + bias)) (+ res); with gate[M,N]: y = gate > 0 ? y*gate_scale : 0."""
+ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+
+
+def gemm_nt(a2d, w, bias=None, res2d=None, act=None, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, row_scale=None,
+            rows_per_scale=1):
+    """y = drop(act(a w^T + bias)) [* row_scale] (+ res); with gate[M,N]: y = gate > 0 ? y*gate_scale : 0."""
     _gpu(a2d, w)
     M, K = a2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=a2d.dtype, device=a2d.device)
     call("mtmp_gemm_nt", _dt(a2d), _p(a2d), _p(w), _p(bias), _p(res2d), _p(y), M, N, K, a2d.stride(0), N,
-         0 if res2d is None else res2d.stride(0), int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _p(gate),
-         float(gate_scale), _stream())
+         0 if res2d is None else res2d.stride(0), ACT[act], float(drop_p), int(seed) & 0xFFFFFFFF, _p(gate),
+         float(gate_scale), _p(row_scale), int(rows_per_scale), _stream())
     return y
+
+
+def layernorm_rows(x, w, b, eps=1e-5, merge_hw=None):
+    """nn.LayerNorm over the last dim of x (any leading dims) -> same shape; merge_hw=(H,W): x is [n,H,W,Cs] and
+    the result is the LayerNorm of the 2x2 patch-merging concat, [n,H/2,W/2,4Cs]."""
+    _gpu(x)
+    x = _c(x)
+    if merge_hw is None:
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        call("mtmp_layernorm_rows", _dt(x), _p(x), _p(w), _p(b), _p(y), x.numel() // C, C, float(eps), 0, 0, 0, _stream())
+        return y
+    H, W = merge_hw
+    n, Cs = x.shape[0], x.shape[-1]
+    y = torch.empty(n, H // 2, W // 2, 4 * Cs, dtype=x.dtype, device=x.device)
+    call("mtmp_layernorm_rows", _dt(x), _p(x), _p(w), _p(b), _p(y), n * (H // 2) * (W // 2), 4 * Cs, float(eps), 1, H, W,
+         _stream())
+    return y
+
+
+def swin_window_attn(qkv, table, heads, shift):
+    """qkv [n,H,W,3C] -> [n,H,W,C]; table [4][heads][64][64] (bias + shift mask, -30000 on pad keys)."""
+    _gpu(qkv)
+    n, H, W, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty(n, H, W, C, dtype=qkv.dtype, device=qkv.device)
+    call("mtmp_swin_window_attn", _dt(qkv), _p(qkv), _p(table), _p(out), n, H, W, C, heads, int(shift),
+         float((C // heads) ** -0.5), _stream())
+    return out
 
 
 def gemm_tn(dy2d, x2d, want_bias=True):
