@@ -47,9 +47,9 @@ template <typename T> struct Tile2 { Frag<T> a, b; };
 template <typename T> MTMP_DEV Tile2<T> tile_fetch(const T* src, int ld, int row0, int limit, int tid) {
     const int rp = row0 + (tid & 31) * 2;
     const int cg = (tid >> 5) * 8;
-    Tile2<T> t;
-    t.a = (rp < limit) ? frag_load<T>(src + (size_t)rp * ld + cg) : frag_zero<T>();
-    t.b = (rp + 1 < limit) ? frag_load<T>(src + (size_t)(rp + 1) * ld + cg) : frag_zero<T>();
+    Tile2<T> t;                                    // clamped (valid) addresses + masks: no branch per load
+    t.a = frag_keep(frag_load<T>(src + (size_t)min(rp, limit - 1) * ld + cg), rp < limit);
+    t.b = frag_keep(frag_load<T>(src + (size_t)min(rp + 1, limit - 1) * ld + cg), rp + 1 < limit);
     return t;
 }
 template <typename T> MTMP_DEV void put_rows(T* dst, const Tile2<T>& t, int tid) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
     Frag<T> qf[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        qf[c] = (qrow < p.N) ? frag_load<T>(Qb + (size_t)qrow * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
+        qf[c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), qrow < p.N);
     f32x16 o0 = {0}, o1 = {0};
     float m = -INFINITY, l = 0.f;
     const float c2 = p.scale * LOG2E;
@@ -225,9 +225,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
     Frag<T> qf[4], dof[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        qf[c] = (qrow < p.N) ? frag_load<T>(Qb + (size_t)qrow * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
-        dof[c] = (qrow < p.N) ? frag_load<T>(p.d_o + ((size_t)b * p.N + qrow) * p.ld_do + hd * DH + 16 * c + 8 * half)
-                              : frag_zero<T>();
+        qf[c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), qrow < p.N);
+        dof[c] = frag_keep(frag_load<T>(p.d_o + ((size_t)b * p.N + min(qrow, p.N - 1)) * p.ld_do + hd * DH + 16 * c + 8 * half),
+                           qrow < p.N);
     }
     const size_t sidx = ((size_t)b * p.H + hd) * p.N + qrow;
     const float L2 = (qrow < p.N) ? p.lse[sidx] : INFINITY;
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
         Frag<T> kf[4], vf[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            kf[c] = key_ok ? frag_load<T>(Kb + (size_t)key * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
-            vf[c] = key_ok ? frag_load<T>(Vb + (size_t)key * p.ld_qkv + 16 * c + 8 * half) : frag_zero<T>();
+            kf[c] = frag_keep(frag_load<T>(Kb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), key_ok);
+            vf[c] = frag_keep(frag_load<T>(Vb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), key_ok);
         }
         const float c2 = p.scale * LOG2E;
         const int nq = (p.N + KT - 1) / KT;

@@ -66,6 +66,25 @@ template <> MTMP_DEV void frag_store<float>(float* p, const Frag<float>& f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f.v[4], f.v[5], f.v[6], f.v[7]};
 }
 
+// ok ? f : 0, spelled as a bitwise AND so that it can never become a branch around the load that
+// produced f.  Guarded loads written as `cond ? load(p) : zero` make hipcc branch around EACH load
+// and wait for it (vmcnt(0)) before the next one -- a tile fetch then costs 8 serial memory round
+// trips.  Kernels therefore load from a CLAMPED (always valid) address and mask the result.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
+MTMP_DEV Frag<bf16> frag_keep(const Frag<bf16>& f, bool ok) {
+    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+    Frag<bf16> r;
+    r.v = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4_t, f.v) & u32x4_t{m, m, m, m});
+    return r;
+}
+MTMP_DEV Frag<float> frag_keep(const Frag<float>& f, bool ok) {
+    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+    Frag<float> r;
+    r.v = __builtin_bit_cast(f32x8, __builtin_bit_cast(u32x8_t, f.v) & u32x8_t{m, m, m, m, m, m, m, m});
+    return r;
+}
+
 template <typename T> MTMP_DEV void mma(f32x16& acc, const Frag<T>& a, const Frag<T>& b);
 template <> MTMP_DEV void mma<bf16>(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);

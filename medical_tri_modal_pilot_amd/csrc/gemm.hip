@@ -42,12 +42,13 @@ template <typename T> struct GemmArgs {
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread); rows >= limit give zeros.
 template <typename T>
-MTMP_DEV void tile_fetch(Frag<T> (&reg)[4], const T* src, int ld, int row0, int limit, int k0, int tid, int kmax = 1 << 30) {
+MTMP_DEV void tile_fetch(Frag<T> (&reg)[4], const T* src, int ld, int row0, int limit, int k0, int tid, int kmax) {
     const int kc = k0 + (tid & 7) * 8;             // columns >= kmax (K tail of a 64-wide chunk) read as zero
+    const int kcc = min(kc, kmax - 8);             // clamped (valid) address + mask: no branch per load
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int row = row0 + (tid >> 3) + 32 * ps;
-        reg[ps] = (row < limit && kc < kmax) ? frag_load<T>(src + (size_t)row * ld + kc) : frag_zero<T>();
+        reg[ps] = frag_keep(frag_load<T>(src + (size_t)min(row, limit - 1) * ld + kcc), row < limit && kc < kmax);
     }
 }
 template <typename T> MTMP_DEV void tile_commit(T* dst, const Frag<T> (&reg)[4], int tid) {
@@ -111,9 +112,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     // ---- LayerNorm prologue, in registers: lane (r, half) holds k = 16c + 8*half + j of row r
     Frag<T> af[16];
     float s1 = 0.f;
+    const T* arow = p.a + (size_t)min(row, p.M - 1) * p.lda + 8 * half;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        af[c] = (row < p.M) ? frag_load<T>(p.a + (size_t)row * p.lda + 16 * c + 8 * half) : frag_zero<T>();
+        af[c] = frag_keep(frag_load<T>(arow + 16 * c), row < p.M);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
     }
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     // ---- Y tiles: for each 128-column block, 4 k-chunks of 64 (kc unrolled: af[] stays in registers)
     const int nblk = (p.N + BN - 1) / BN;
     Frag<T> wreg[4];
-    tile_fetch<T>(wreg, p.w, 256, 0, p.N, 0, tid);
+    tile_fetch<T>(wreg, p.w, 256, 0, p.N, 0, tid, 256);
     for (int nb = 0; nb < nblk; ++nb) {
         const int n0 = nb * BN;
         f32x16 acc[4] = {{0}, {0}, {0}, {0}};
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
             __syncthreads();
             tile_commit<T>(sW, wreg, tid);
             __syncthreads();
-            if (kc < 3) tile_fetch<T>(wreg, p.w, 256, n0, p.N, (kc + 1) * BK, tid);
-            else if (nb + 1 < nblk) tile_fetch<T>(wreg, p.w, 256, n0 + BN, p.N, 0, tid);
+            if (kc < 3) tile_fetch<T>(wreg, p.w, 256, n0, p.N, (kc + 1) * BK, tid, 256);
+            else if (nb + 1 < nblk) tile_fetch<T>(wreg, p.w, 256, n0 + BN, p.N, 0, tid, 256);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -223,8 +225,10 @@ template <typename T>
 MTMP_DEV void tn_fetch(Frag<T> (&reg)[4], const T* src, int ld, int m0, int m_end, int c0, int tid) {
     const int q = (tid & 15) * 4, cg = (tid >> 4) * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        reg[i] = (m0 + q + i < m_end) ? frag_load<T>(src + (size_t)(m0 + q + i) * ld + c0 + cg) : frag_zero<T>();
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + q + i;                  // clamped address + mask (no branch per load)
+        reg[i] = frag_keep(frag_load<T>(src + (size_t)min(m, max(m_end - 1, 0)) * ld + c0 + cg), m < m_end);
+    }
 }
 // registers (4 tokens x 8 cols) -> LDS [col][token]: a 4x8 in-register transpose.  For bf16 it is
 // spelled with v_perm_b32 on the packed dwords (element-wise bf16 vector shuffles make hipcc

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* 
         const T* pk = qkv + pix(tk < L ? tk : 0) * C3 + C + head * DH + 8 * half;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            qf[blk][c] = (live && tq < L) ? frag_load<T>(pq + 16 * c) : frag_zero<T>();
-            kf[blk][c] = (live && tk < L) ? frag_load<T>(pk + 16 * c) : frag_zero<T>();
+            qf[blk][c] = frag_keep(frag_load<T>(pq + 16 * c), live && tq < L);
+            kf[blk][c] = frag_keep(frag_load<T>(pk + 16 * c), live && tk < L);
         }
     }
     // ---- V -> LDS transposed: lane = (key pair, 8-dim group), two passes over the 32 dims
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* 
         const T* pb = qkv + pix(kp + 1 < L ? kp + 1 : 0) * C3 + 2 * C + head * DH + dg;
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
-            const Frag<T> fa = (live && kp < L) ? frag_load<T>(pa + 16 * ps) : frag_zero<T>();
-            const Frag<T> fb = (live && kp + 1 < L) ? frag_load<T>(pb + 16 * ps) : frag_zero<T>();
+            const Frag<T> fa = frag_keep(frag_load<T>(pa + 16 * ps), live && kp < L);
+            const Frag<T> fb = frag_keep(frag_load<T>(pb + 16 * ps), live && kp + 1 < L);
 #pragma unroll
             for (int e = 0; e < 8; ++e) store_pair2<T>(sVt + (dg + 16 * ps + e) * LDV + kp, fa.v[e], fb.v[e]);
         }
