@@ -42,20 +42,22 @@ template <typename T> struct AttnArgs {
 // group cg = 8*(tid>>5)): a wave-load reads 32 rows x 32 contiguous bytes; the transposed put
 // writes 32 consecutive dwords per instruction (bank-conflict free); one fetch can feed both
 // the row-major and the transposed image of the same tile.  Rows >= limit are zero.
-template <typename T> struct Tile2 { Frag<T> a, b; };
+template <typename T> struct Tile2 { Frag<T> a, b; bool oka, okb; };
 
 template <typename T> MTMP_DEV Tile2<T> tile_fetch(const T* src, int ld, int row0, int limit, int tid) {
     const int rp = row0 + (tid & 31) * 2;
     const int cg = (tid >> 5) * 8;
-    Tile2<T> t;                                    // clamped (valid) addresses + masks: no branch per load
-    t.a = frag_keep(frag_load<T>(src + (size_t)min(rp, limit - 1) * ld + cg), rp < limit);
-    t.b = frag_keep(frag_load<T>(src + (size_t)min(rp + 1, limit - 1) * ld + cg), rp + 1 < limit);
+    Tile2<T> t;            // unconditional loads from clamped rows; masked at PUT time so that the loads
+    t.a = frag_load<T>(src + (size_t)min(rp, limit - 1) * ld + cg);        // stay in flight under the MFMAs
+    t.b = frag_load<T>(src + (size_t)min(rp + 1, limit - 1) * ld + cg);
+    t.oka = rp < limit;
+    t.okb = rp + 1 < limit;
     return t;
 }
 template <typename T> MTMP_DEV void put_rows(T* dst, const Tile2<T>& t, int tid) {
     T* d = dst + (tid & 31) * 2 * LDT + (tid >> 5) * 8;
-    frag_store<T>(d, t.a);
-    frag_store<T>(d + LDT, t.b);
+    frag_store<T>(d, frag_keep(t.a, t.oka));
+    frag_store<T>(d + LDT, frag_keep(t.b, t.okb));
 }
 template <typename T> MTMP_DEV void store_pair(T* p, T a, T b);
 template <> MTMP_DEV void store_pair<bf16>(bf16* p, bf16 a, bf16 b) {
@@ -66,8 +68,9 @@ template <> MTMP_DEV void store_pair<float>(float* p, float a, float b) {
 }
 template <typename T> MTMP_DEV void put_transposed(T* dst, const Tile2<T>& t, int tid) {
     T* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
+    const Frag<T> a = frag_keep(t.a, t.oka), b = frag_keep(t.b, t.okb);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) store_pair<T>(d + e * LDT, t.a.v[e], t.b.v[e]);
+    for (int e = 0; e < 8; ++e) store_pair<T>(d + e * LDT, a.v[e], b.v[e]);
 }
 
 // 32x32 tile: acc += A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)

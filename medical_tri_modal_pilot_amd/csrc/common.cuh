@@ -143,6 +143,15 @@ MTMP_DEV float wave_sum(float v) {
     return v;
 }
 MTMP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// erf, Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7), branch free: the libm erff expands into
+// a multi-way branch per element inside GEMM epilogues.
+MTMP_DEV float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float y = 1.0f - poly * __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    return copysignf(y, x);
+}
 
 // Counter-based dropout mask: element `idx` of a call seeded with `seed` is kept iff
 // fmix32(idx * golden ^ seed) >= p * 2^32.  Stateless, so the backward regenerates the

@@ -40,20 +40,29 @@ template <typename T> struct GemmArgs {
     int rows_per_scale;
 };
 
-// 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread); rows >= limit give zeros.
+// 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread).  The loads are
+// unconditional from a CLAMPED (always valid) address and carry no use until tile_commit, so they
+// stay in flight under the MFMAs of the current tile; rows >= limit / columns >= kmax (K tail of a
+// 64-wide chunk) are zeroed by a mask at commit time (a `cond ? load : 0` at the fetch site makes
+// hipcc branch around -- and wait for -- every single load).
+template <typename T> struct TileRegs { Frag<T> f[4]; unsigned ok; };
+
 template <typename T>
-MTMP_DEV void tile_fetch(Frag<T> (&reg)[4], const T* src, int ld, int row0, int limit, int k0, int tid, int kmax) {
-    const int kc = k0 + (tid & 7) * 8;             // columns >= kmax (K tail of a 64-wide chunk) read as zero
-    const int kcc = min(kc, kmax - 8);             // clamped (valid) address + mask: no branch per load
+MTMP_DEV void tile_fetch(TileRegs<T>& t, const T* src, int ld, int row0, int limit, int k0, int tid, int kmax) {
+    const int kc = k0 + (tid & 7) * 8;
+    const int kcc = min(kc, kmax - 8);
+    t.ok = 0;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int row = row0 + (tid >> 3) + 32 * ps;
-        reg[ps] = frag_keep(frag_load<T>(src + (size_t)min(row, limit - 1) * ld + kcc), row < limit && kc < kmax);
+        t.f[ps] = frag_load<T>(src + (size_t)min(row, limit - 1) * ld + kcc);
+        t.ok |= (row < limit && kc < kmax) ? (1u << ps) : 0u;
     }
 }
-template <typename T> MTMP_DEV void tile_commit(T* dst, const Frag<T> (&reg)[4], int tid) {
+template <typename T> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, int tid) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, reg[ps]);
+    for (int ps = 0; ps < 4; ++ps)
+        frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, frag_keep(t.f[ps], (t.ok >> ps) & 1u));
 }
 
 // acc[nt]: rows = output features n0 + 32nt + acc_row(t, half), column = this lane's token row.
@@ -75,7 +84,7 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, in
             for (int i = 0; i < 4; ++i) {
                 v[i] = acc[nt][4 * g + i] + bv[i];
                 if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
-                if (p.act == 2) v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752f));
+                if (p.act == 2) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752f));
                 if (p.drop_p > 0.f)
                     v[i] = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)(col + i), thr) ? v[i] * keep_scale : 0.f;
             }
@@ -144,7 +153,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     }
     // ---- Y tiles: for each 128-column block, 4 k-chunks of 64 (kc unrolled: af[] stays in registers)
     const int nblk = (p.N + BN - 1) / BN;
-    Frag<T> wreg[4];
+    TileRegs<T> wreg;
     tile_fetch<T>(wreg, p.w, 256, 0, p.N, 0, tid, 256);
     for (int nb = 0; nb < nblk; ++nb) {
         const int n0 = nb * BN;
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (w / ntn) * BM, n0 = (w % ntn) * BN;
     const int nk = (p.K + BK - 1) / BK;
-    Frag<T> areg[4], wreg[4];
+    TileRegs<T> areg, wreg;
     tile_fetch<T>(areg, p.a, p.lda, m0, p.M, 0, tid, p.K);
     tile_fetch<T>(wreg, p.w, p.K, n0, p.N, 0, tid, p.K);
     f32x16 acc[4] = {{0}, {0}, {0}, {0}};
@@ -220,15 +229,23 @@ template <> MTMP_DEV void store_quad<float>(float* p, float a, float b, float c,
     *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
 }
 
-// 64 tokens x 128 cols -> registers: thread (q = tid&15: tokens 4q..4q+3, cg = tid>>4: cols 8cg..8cg+7)
+// 64 tokens x 128 cols -> registers: thread (q = tid&15: tokens 4q..4q+3, cg = tid>>4: cols 8cg..8cg+7);
+// unconditional loads from clamped rows, tokens >= m_end zeroed at commit time (see tile_fetch).
+template <typename T> struct TnRegs { Frag<T> f[4]; unsigned ok; };
 template <typename T>
-MTMP_DEV void tn_fetch(Frag<T> (&reg)[4], const T* src, int ld, int m0, int m_end, int c0, int tid) {
+MTMP_DEV void tn_fetch(TnRegs<T>& t, const T* src, int ld, int m0, int m_end, int c0, int tid) {
     const int q = (tid & 15) * 4, cg = (tid >> 4) * 8;
+    t.ok = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + q + i;                  // clamped address + mask (no branch per load)
-        reg[i] = frag_keep(frag_load<T>(src + (size_t)min(m, max(m_end - 1, 0)) * ld + c0 + cg), m < m_end);
+        const int m = m0 + q + i;
+        t.f[i] = frag_load<T>(src + (size_t)min(m, max(m_end - 1, 0)) * ld + c0 + cg);
+        t.ok |= (m < m_end) ? (1u << i) : 0u;
     }
+}
+template <typename T> MTMP_DEV void tn_mask(TnRegs<T>& t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.f[i] = frag_keep(t.f[i], (t.ok >> i) & 1u);
 }
 // registers (4 tokens x 8 cols) -> LDS [col][token]: a 4x8 in-register transpose.  For bf16 it is
 // spelled with v_perm_b32 on the packed dwords (element-wise bf16 vector shuffles make hipcc
@@ -270,17 +287,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
     f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // column sums of dY (bias gradient)
-    Frag<T> yreg[4], xreg[4];
+    TnRegs<T> yreg, xreg;
     tn_fetch<T>(yreg, p.dy, p.ldy, m_lo, m_end, n0, tid);
     tn_fetch<T>(xreg, p.x, p.ldx, m_lo, m_end, k0, tid);
     for (int m0 = m_lo; m0 < m_end; m0 += TK) {
         __syncthreads();
-        tn_commit<T>(sY, yreg, tid);
-        tn_commit<T>(sX, xreg, tid);
+        tn_mask<T>(yreg);
+        tn_mask<T>(xreg);
+        tn_commit<T>(sY, yreg.f, tid);
+        tn_commit<T>(sX, xreg.f, tid);
         if (k0 == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                csum[e] += to_f32(yreg[0].v[e]) + to_f32(yreg[1].v[e]) + to_f32(yreg[2].v[e]) + to_f32(yreg[3].v[e]);
+                csum[e] += to_f32(yreg.f[0].v[e]) + to_f32(yreg.f[1].v[e]) + to_f32(yreg.f[2].v[e]) + to_f32(yreg.f[3].v[e]);
         }
         __syncthreads();
         if (m0 + TK < m_end) {

@@ -19,61 +19,94 @@ constexpr int WS = 7, L = 49, LP = 64, DH = 32, LDV = LP + 8;
 constexpr float LOG2E = 1.4426950408889634f;
 
 // ------------------------------------------------------------------------------------------
-template <typename T>
+// A wave is split into 64/G groups of G lanes; a group normalises one row, a lane owns NCH chunks of
+// 8 consecutive channels (16-byte loads/stores).  C = 96 -> 4 rows per wave, 192 -> 2, >= 384 -> 1.
+template <typename T, int G, int NCH>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const T* x, const float* w, const float* b, T* y, long long rows,
                                                       int C, float eps, int merge, int H, int W) {
-    constexpr int MAXP = 12;                       // pairs per lane: C <= 1536
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int npairs = C >> 1;
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & (G - 1), grp = lane / G;
+    const int chunks = C >> 3;
     const int Cs = merge ? (C >> 2) : C;           // channels of one source pixel
-    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    for (long long rb = (long long)blockIdx.x * 4 + wave; rb * RPW < rows; rb += (long long)gridDim.x * 4) {
+        const long long row = rb * RPW + grp;
+        const bool valid = row < rows;
+        const long long rc = valid ? row : rows - 1;
         const T* src[4];
         if (merge) {
             const int Ho = H >> 1, Wo = W >> 1;
-            const long long img = row / (Ho * Wo);
-            const int rem = (int)(row - img * Ho * Wo), i = rem / Wo, j = rem - i * Wo;
+            const long long img = rc / (Ho * Wo);
+            const int rem = (int)(rc - img * Ho * Wo), i = rem / Wo, j = rem - i * Wo;
             const T* base = x + ((img * H + 2 * i) * W + 2 * j) * (long long)Cs;
-            src[0] = base;                         // x[0::2, 0::2]
-            src[1] = base + (long long)W * Cs;     // x[1::2, 0::2]
-            src[2] = base + Cs;                    // x[0::2, 1::2]
+            src[0] = base;                           // x[0::2, 0::2]
+            src[1] = base + (long long)W * Cs;       // x[1::2, 0::2]
+            src[2] = base + Cs;                      // x[0::2, 1::2]
             src[3] = base + (long long)W * Cs + Cs;  // x[1::2, 1::2]
         } else {
-            src[0] = src[1] = src[2] = src[3] = x + row * C;
+            src[0] = src[1] = src[2] = src[3] = x + rc * C;
         }
-        float v[2 * MAXP];
+        float v[NCH][8];
         float s1 = 0.f;
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int pi = lane + 64 * k;
-            v[2 * k] = v[2 * k + 1] = 0.f;
-            if (pi < npairs) {
-                const int e = 2 * pi;
-                const T* p = merge ? (src[e / Cs] + (e % Cs)) : (src[0] + e);
-                v[2 * k] = to_f32(p[0]);
-                v[2 * k + 1] = to_f32(p[1]);
-                s1 += v[2 * k] + v[2 * k + 1];
-            }
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = gl + k * G;
+            const bool on = ch < chunks;
+            const int e = 8 * (on ? ch : 0);
+            const Frag<T> f = frag_load<T>(merge ? (src[e / Cs] + (e % Cs)) : (src[0] + e));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[k][i] = on ? to_f32(f.v[i]) : 0.f; s1 += v[k][i]; }
         }
-        const float mean = wave_sum(s1) / (float)C;
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 / (float)C;
         float s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k)
-            if (lane + 64 * k < npairs) {
-                const float d0 = v[2 * k] - mean, d1 = v[2 * k + 1] - mean;
-                s2 += d0 * d0 + d1 * d1;
-            }
-        const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
-        T* out = y + row * C;
+        for (int k = 0; k < NCH; ++k)
+            if (gl + k * G < chunks) {
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) {
-            const int pi = lane + 64 * k;
-            if (pi < npairs) {
-                const int e = 2 * pi;
-                out[e] = from_f32<T>(fmaf((v[2 * k] - mean) * rstd, w[e], b[e]));
-                out[e + 1] = from_f32<T>(fmaf((v[2 * k + 1] - mean) * rstd, w[e + 1], b[e + 1]));
+                for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; s2 += d * d; }
+            }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rstd = rsqrtf(s2 / (float)C + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = gl + k * G;
+            if (valid && ch < chunks) {
+                const int e = 8 * ch;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + e), w1 = *reinterpret_cast<const f32x4*>(w + e + 4);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + e), b1 = *reinterpret_cast<const f32x4*>(b + e + 4);
+                Frag<T> o;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o.v[i] = from_f32<T>(fmaf((v[k][i] - mean) * rstd, w0[i], b0[i]));
+                    o.v[i + 4] = from_f32<T>(fmaf((v[k][i + 4] - mean) * rstd, w1[i], b1[i]));
+                }
+                frag_store<T>(y + row * C + e, o);
             }
         }
     }
+}
+
+template <typename T>
+int launch_ln_rows(const void* x, const float* w, const float* b, void* y, long long rows, int C, float eps, int merge, int H,
+                   int W, hipStream_t st) {
+    const int chunks = C / 8;
+    int G = 16;
+    while (G < chunks && G < 64) G <<= 1;
+    const int nch = (chunks + G - 1) / G;
+    const long long nrb = (rows + (64 / G) - 1) / (64 / G);
+    const int nb = (int)((nrb + 3) / 4 < 4096 ? (nrb + 3) / 4 : 4096);
+#define MTMP_LN_CASE(g, n)                                                                                          \
+    if (G == g && nch == n) {                                                                                       \
+        hipLaunchKernelGGL((ln_rows_kernel<T, g, n>), dim3(nb), dim3(256), 0, st, (const T*)x, w, b, (T*)y, rows, C, eps, \
+                           merge, H, W);                                                                            \
+        return MTMP_OK;                                                                                             \
+    }
+    MTMP_LN_CASE(16, 1) MTMP_LN_CASE(32, 1) MTMP_LN_CASE(64, 1) MTMP_LN_CASE(64, 2) MTMP_LN_CASE(64, 3)
+#undef MTMP_LN_CASE
+    mtmp_set_error("mtmp_layernorm_rows: unsupported C=%d", C);
+    return MTMP_ERR_ARG;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -201,13 +234,14 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* 
 extern "C" int mtmp_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* y, long long rows,
                                    int C, float eps, int merge, int H, int W, void* stream) {
     MTMP_CHECK_ARG(x && w && b && y && rows > 0, "mtmp_layernorm_rows: bad pointer / rows");
-    MTMP_CHECK_ARG(C > 0 && C % 2 == 0 && C <= 1536 && (!merge || (C % 8 == 0 && H % 2 == 0 && W % 2 == 0)),
+    MTMP_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 1536 && (!merge || (C % 32 == 0 && H % 2 == 0 && W % 2 == 0)),
                    "mtmp_layernorm_rows: bad shape C=%d merge=%d H=%d W=%d", C, merge, H, W);
-    const int nb = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) hipLaunchKernelGGL(ln_rows_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, w, b, (float*)y, rows, C, eps, merge, H, W);
-    else if (dtype == 1) hipLaunchKernelGGL(ln_rows_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)x, w, b, (bf16*)y, rows, C, eps, merge, H, W);
+    int rc;
+    if (dtype == 0) rc = launch_ln_rows<float>(x, w, b, y, rows, C, eps, merge, H, W, st);
+    else if (dtype == 1) rc = launch_ln_rows<bf16>(x, w, b, y, rows, C, eps, merge, H, W, st);
     else { mtmp_set_error("mtmp_layernorm_rows: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    if (rc) return rc;
     MTMP_CHECK_LAUNCH("mtmp_layernorm_rows");
     return MTMP_OK;
 }
