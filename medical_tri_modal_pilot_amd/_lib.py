@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_uint, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmtmp_hip.so")
+LIB_PATH = os.environ.get("MTMP_LIB", os.path.join(_HERE, "libmtmp_hip.so"))   # MTMP_LIB: diagnostic builds only
 
 F32, BF16 = 0, 1
 

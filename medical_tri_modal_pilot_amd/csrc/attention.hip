@@ -21,6 +21,23 @@
 #include "common.cuh"
 #include <math.h>
 
+// Diagnostic build only (make stamp): s_memtime stamps around the phases of the forward loop.
+#ifdef MTMP_STAMP
+__device__ unsigned long long g_stamp[8];
+#define STAMP(var)                                                                                   \
+    {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    }
+#define STAMP_DECL unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa = 0, sb = 0, sc = 0, sd = 0;
+#define STAMP_ACC  { sa += ts1 - ts0; sb += ts2 - ts1; sc += ts3 - ts2; sd += ts4 - ts3; }
+#else
+#define STAMP(var)
+#define STAMP_DECL
+#define STAMP_ACC
+#endif
+
 namespace {
 
 constexpr int DH = 64;       // head dim: d_model 256 / 4 heads (tri_mbt_vsltcls.py:29-30)
@@ -38,39 +55,73 @@ template <typename T> struct AttnArgs {
 
 // ---- LDS staging of a 64-row x 64-col tile by 256 threads, split into FETCH (global ->
 // registers, issued one tile ahead so the loads fly under the MFMAs of the current tile) and
-// PUT (registers -> LDS, after the barrier).  Thread -> (row pair rp = 2*(tid&31), 8-column
-// group cg = 8*(tid>>5)): a wave-load reads 32 rows x 32 contiguous bytes; the transposed put
-// writes 32 consecutive dwords per instruction (bank-conflict free); one fetch can feed both
-// the row-major and the transposed image of the same tile.  Rows >= limit are zero.
+// PUT (registers -> LDS, after the barrier).  Rows >= limit are zero (masked at PUT time, so
+// the loads carry no use while in flight).
+//
+// A tile is needed in two roles: as ROW operand (fragment = 8 consecutive columns of one row:
+// ds_read_b128 from a row-major image, stride LDT) and as TRANSPOSED operand (fragment = 8
+// consecutive ROWS of one column: V for P.V, K for dQ, Q / dO for dK / dV).
+//   bf16: both images are row-major; the transposed fragments come from the hardware
+//         transposing read ds_read_b64_tr_b16 (two per fragment) on an image with a 192-byte row
+//         stride (conflict free for that read).  Global loads are fully coalesced: 8 lanes read
+//         one 128-byte row, a wave-load covers 8 whole rows.
+//   fp32 (parity build): there is no 32-bit transposing read; the transposed image is written
+//         [col][row] with 8-byte LDS stores from a (row pair, column group) thread mapping.
 template <typename T> struct Tile2 { Frag<T> a, b; bool oka, okb; };
+constexpr int LDR = 96;      // row stride (elements) of the bf16 image that feeds ds_read_b64_tr_b16
 
+template <typename T> constexpr int tr_elems() { return sizeof(T) == 2 ? KT * LDR : DH * LDT; }
+
+template <typename T> MTMP_DEV void tile_map(int tid, int& ra, int& rb, int& col) {
+    if (sizeof(T) == 2) { ra = tid >> 3; rb = ra + 32; col = (tid & 7) * 8; }
+    else                { ra = (tid & 31) * 2; rb = ra + 1; col = (tid >> 5) * 8; }
+}
 template <typename T> MTMP_DEV Tile2<T> tile_fetch(const T* src, int ld, int row0, int limit, int tid) {
-    const int rp = row0 + (tid & 31) * 2;
-    const int cg = (tid >> 5) * 8;
-    Tile2<T> t;            // unconditional loads from clamped rows; masked at PUT time so that the loads
-    t.a = frag_load<T>(src + (size_t)min(rp, limit - 1) * ld + cg);        // stay in flight under the MFMAs
-    t.b = frag_load<T>(src + (size_t)min(rp + 1, limit - 1) * ld + cg);
-    t.oka = rp < limit;
-    t.okb = rp + 1 < limit;
+    int ra, rb, col;
+    tile_map<T>(tid, ra, rb, col);
+    Tile2<T> t;
+    t.a = frag_load<T>(src + (size_t)min(row0 + ra, limit - 1) * ld + col);
+    t.b = frag_load<T>(src + (size_t)min(row0 + rb, limit - 1) * ld + col);
+    t.oka = row0 + ra < limit;
+    t.okb = row0 + rb < limit;
     return t;
 }
 template <typename T> MTMP_DEV void put_rows(T* dst, const Tile2<T>& t, int tid) {
-    T* d = dst + (tid & 31) * 2 * LDT + (tid >> 5) * 8;
-    frag_store<T>(d, frag_keep(t.a, t.oka));
-    frag_store<T>(d + LDT, frag_keep(t.b, t.okb));
+    int ra, rb, col;
+    tile_map<T>(tid, ra, rb, col);
+    frag_store<T>(dst + ra * LDT + col, frag_keep(t.a, t.oka));
+    frag_store<T>(dst + rb * LDT + col, frag_keep(t.b, t.okb));
 }
-template <typename T> MTMP_DEV void store_pair(T* p, T a, T b);
-template <> MTMP_DEV void store_pair<bf16>(bf16* p, bf16 a, bf16 b) {
-    *reinterpret_cast<bf16x2*>(p) = bf16x2{a, b};
+// image for the TRANSPOSED role
+MTMP_DEV void put_tr(bf16* dst, const Tile2<bf16>& t, int tid) {
+    int ra, rb, col;
+    tile_map<bf16>(tid, ra, rb, col);
+    frag_store<bf16>(dst + ra * LDR + col, frag_keep(t.a, t.oka));
+    frag_store<bf16>(dst + rb * LDR + col, frag_keep(t.b, t.okb));
 }
-template <> MTMP_DEV void store_pair<float>(float* p, float a, float b) {
-    *reinterpret_cast<f32x2*>(p) = f32x2{a, b};
-}
-template <typename T> MTMP_DEV void put_transposed(T* dst, const Tile2<T>& t, int tid) {
-    T* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
-    const Frag<T> a = frag_keep(t.a, t.oka), b = frag_keep(t.b, t.okb);
+MTMP_DEV void put_tr(float* dst, const Tile2<float>& t, int tid) {
+    float* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
+    const Frag<float> a = frag_keep(t.a, t.oka), b = frag_keep(t.b, t.okb);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) store_pair<T>(d + e * LDT, a.v[e], b.v[e]);
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(d + e * LDT) = f32x2{a.v[e], b.v[e]};
+}
+// fragment of the transposed role: element j = tile[row0 + 8*half + j][col0 + r]   (r = lane & 31)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+MTMP_DEV Frag<bf16> frag_tr(const bf16* img, int row0, int col0, int lane) {
+    // ds_read_b64_tr_b16: within a group of 16 lanes, lane 4q+p supplies the address of row q,
+    // columns 4p..4p+3 of a 4 x 16 block; lane i receives column i of the 4 rows.
+    const int G = lane >> 4, i = lane & 15;
+    const bf16* a = img + (row0 + 8 * (G >> 1) + (i >> 2)) * LDR + col0 + 16 * (G & 1) + 4 * (i & 3);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * LDR));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    return f;
+}
+MTMP_DEV Frag<float> frag_tr(const float* img, int row0, int col0, int lane) {
+    return frag_load<float>(img + (col0 + (lane & 31)) * LDT + row0 + 8 * (lane >> 5));
 }
 
 // 32x32 tile: acc += A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
@@ -86,7 +137,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
-    T* sVt = sK + KT * LDT;                   // [DH][LDT]   dh x keys
+    T* sVt = sK + KT * LDT;                   // V image for the transposed role (frag_tr)
     const int nqt = (p.N + 127) >> 7;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
@@ -108,12 +159,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
     const int ntiles = (kvl + KT - 1) / KT;
     Tile2<T> kreg = tile_fetch<T>(Kb, p.ld_qkv, 0, kvl, tid);
     Tile2<T> vreg = tile_fetch<T>(Vb, p.ld_qkv, 0, kvl, tid);
+    STAMP_DECL
     for (int it = 0; it < ntiles; ++it) {
         const int k0 = it * KT;
+        STAMP(ts0)
         __syncthreads();
         put_rows<T>(sK, kreg, tid);
-        put_transposed<T>(sVt, vreg, tid);
+        put_tr(sVt, vreg, tid);
         __syncthreads();
+        STAMP(ts1)
         if (it + 1 < ntiles) {                 // next tile's loads fly under this tile's MFMAs
             kreg = tile_fetch<T>(Kb, p.ld_qkv, k0 + KT, kvl, tid);
             vreg = tile_fetch<T>(Vb, p.ld_qkv, k0 + KT, kvl, tid);
@@ -130,6 +184,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
                 for (int t = 0; t < 16; ++t)
                     if (k0 + 32 * kb + acc_row_swz(t, half) >= kvl) st[kb][t] = -INFINITY;
         }
+        STAMP(ts2)
         float mx = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(st[0][t], st[1][t]));
@@ -146,16 +201,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
                 l += pv;
                 st[kb][t] = pv;
             }
+        STAMP(ts3)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> pf = frag_from_acc<T>(st[kb], s);
-                const T* vrow = sVt + r * LDT + 32 * kb + 16 * s + 8 * half;
-                mma<T>(o0, frag_load<T>(vrow), pf);
-                mma<T>(o1, frag_load<T>(vrow + 32 * LDT), pf);
+                mma<T>(o0, frag_tr(sVt, 32 * kb + 16 * s, 0, lane), pf);
+                mma<T>(o1, frag_tr(sVt, 32 * kb + 16 * s, 32, lane), pf);
             }
+        STAMP(ts4)
+        STAMP_ACC
     }
+#ifdef MTMP_STAMP
+    if (lane == 0) {
+        atomicAdd(&g_stamp[0], sa); atomicAdd(&g_stamp[1], sb); atomicAdd(&g_stamp[2], sc); atomicAdd(&g_stamp[3], sd);
+        atomicAdd(&g_stamp[4], (unsigned long long)ntiles);
+    }
+#endif
     l += __shfl_xor(l, 32, 64);
     if (qrow < p.N) {
         const float inv = 1.0f / l;
@@ -213,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]
     T* sV = sK + KT * LDT;                    // [KT][LDT]
-    T* sKt = sV + KT * LDT;                   // [DH][LDT]  dh x keys
+    T* sKt = sV + KT * LDT;                   // K image for the transposed role (frag_tr)
     const int nqt = (p.N + 127) >> 7;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
@@ -244,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
         const int k0 = it * KT;
         __syncthreads();
         put_rows<T>(sK, kreg, tid);
-        put_transposed<T>(sKt, kreg, tid);
+        put_tr(sKt, kreg, tid);
         put_rows<T>(sV, vreg, tid);
         __syncthreads();
         if (it + 1 < ntiles) {
@@ -265,9 +328,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> dsf = frag_from_acc<T>(st, s);
-                const T* krow = sKt + r * LDT + 32 * kb + 16 * s + 8 * half;
-                mma<T>(dq0, frag_load<T>(krow), dsf);
-                mma<T>(dq1, frag_load<T>(krow + 32 * LDT), dsf);
+                mma<T>(dq0, frag_tr(sKt, 32 * kb + 16 * s, 0, lane), dsf);
+                mma<T>(dq1, frag_tr(sKt, 32 * kb + 16 * s, 32, lane), dsf);
             }
         }
     }
@@ -292,9 +354,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sQ = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]  q x dh
     T* sdO = sQ + KT * LDT;                   // [KT][LDT]
-    T* sQt = sdO + KT * LDT;                  // [DH][LDT]  dh x q
-    T* sdOt = sQt + DH * LDT;                 // [DH][LDT]
-    float* sL = reinterpret_cast<float*>(sdOt + DH * LDT);   // [KT] lse (log2 units), +inf past N
+    T* sQt = sdO + KT * LDT;                  // Q image for the transposed role (frag_tr)
+    T* sdOt = sQt + tr_elems<T>();             // dO image for the transposed role
+    float* sL = reinterpret_cast<float*>(sdOt + tr_elems<T>());   // [KT] lse (log2 units), +inf past N
     float* sD = sL + KT;                                     // [KT] delta
     const int nkt = (p.N + 127) >> 7;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
@@ -330,9 +392,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
             const int q0 = it * KT;
             __syncthreads();
             put_rows<T>(sQ, qreg, tid);
-            put_transposed<T>(sQt, qreg, tid);
+            put_tr(sQt, qreg, tid);
             put_rows<T>(sdO, oreg, tid);
-            put_transposed<T>(sdOt, oreg, tid);
+            put_tr(sdOt, oreg, tid);
             if (tid < KT) { sL[tid] = lreg; sD[tid] = dreg; }
             __syncthreads();
             if (it + 1 < nq) {
@@ -362,11 +424,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
                     for (int s = 0; s < 2; ++s) {
                         const Frag<T> pf = frag_from_acc<T>(st, s);
                         const Frag<T> dsf = frag_from_acc<T>(ds, s);
-                        const int off = r * LDT + 32 * qb + 16 * s + 8 * half;
-                        mma<T>(dv0, pf, frag_load<T>(sdOt + off));
-                        mma<T>(dv1, pf, frag_load<T>(sdOt + off + 32 * LDT));
-                        mma<T>(dk0, dsf, frag_load<T>(sQt + off));
-                        mma<T>(dk1, dsf, frag_load<T>(sQt + off + 32 * LDT));
+                        const int q16 = 32 * qb + 16 * s;
+                        mma<T>(dv0, pf, frag_tr(sdOt, q16, 0, lane));
+                        mma<T>(dv1, pf, frag_tr(sdOt, q16, 32, lane));
+                        mma<T>(dk0, dsf, frag_tr(sQt, q16, 0, lane));
+                        mma<T>(dk1, dsf, frag_tr(sQt, q16, 32, lane));
                     }
                 }
             }
@@ -388,9 +450,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
     }
 }
 
-template <typename T> size_t fwd_smem() { return (size_t)(KT + DH) * LDT * sizeof(T); }
-template <typename T> size_t dq_smem() { return (size_t)(2 * KT + DH) * LDT * sizeof(T); }
-template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT + 2 * DH) * LDT * sizeof(T) + 2 * KT * sizeof(float); }
+template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T); }
+template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T); }
+template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float); }
 
 template <typename K> int set_smem(K kern, size_t bytes) {
     if (bytes > 48 * 1024) {
@@ -473,3 +535,12 @@ extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void
     mtmp_set_error("mtmp_attn_bwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
+
+#ifdef MTMP_STAMP
+// diagnostic build: read and clear the accumulated phase cycles {puts+barriers, S, softmax, PV, tiles}
+extern "C" int mtmp_debug_stamps(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess;
+}
+#endif
