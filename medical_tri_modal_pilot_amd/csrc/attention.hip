@@ -89,15 +89,25 @@ template <typename T> MTMP_DEV Tile2<T> tile_fetch(const T* src, int ld, int row
 template <typename T> MTMP_DEV void put_rows(T* dst, const Tile2<T>& t, int tid) {
     int ra, rb, col;
     tile_map<T>(tid, ra, rb, col);
-    frag_store<T>(dst + ra * LDT + col, frag_keep(t.a, t.oka));
-    frag_store<T>(dst + rb * LDT + col, frag_keep(t.b, t.okb));
+    if (wave_all(t.oka && t.okb)) {
+        frag_store<T>(dst + ra * LDT + col, t.a);
+        frag_store<T>(dst + rb * LDT + col, t.b);
+    } else {
+        frag_store<T>(dst + ra * LDT + col, frag_keep(t.a, t.oka));
+        frag_store<T>(dst + rb * LDT + col, frag_keep(t.b, t.okb));
+    }
 }
 // image for the TRANSPOSED role
 MTMP_DEV void put_tr(bf16* dst, const Tile2<bf16>& t, int tid) {
     int ra, rb, col;
     tile_map<bf16>(tid, ra, rb, col);
-    frag_store<bf16>(dst + ra * LDR + col, frag_keep(t.a, t.oka));
-    frag_store<bf16>(dst + rb * LDR + col, frag_keep(t.b, t.okb));
+    if (wave_all(t.oka && t.okb)) {
+        frag_store<bf16>(dst + ra * LDR + col, t.a);
+        frag_store<bf16>(dst + rb * LDR + col, t.b);
+    } else {
+        frag_store<bf16>(dst + ra * LDR + col, frag_keep(t.a, t.oka));
+        frag_store<bf16>(dst + rb * LDR + col, frag_keep(t.b, t.okb));
+    }
 }
 MTMP_DEV void put_tr(float* dst, const Tile2<float>& t, int tid) {
     float* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
@@ -128,8 +138,9 @@ MTMP_DEV Frag<float> frag_tr(const float* img, int row0, int col0, int lane) {
 template <typename T>
 MTMP_DEV void tile_qk(f32x16& acc, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
     const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
+    acc = mma0<T>(frag_load<T>(arow), bf[0]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) mma<T>(acc, frag_load<T>(arow + 16 * c), bf[c]);
+    for (int c = 1; c < 4; ++c) mma<T>(acc, frag_load<T>(arow + 16 * c), bf[c]);
 }
 
 // =============================== forward ====================================
@@ -168,14 +179,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
         put_tr(sVt, vreg, tid);
         __syncthreads();
         STAMP(ts1)
+#ifndef MTMP_ABLATE_FETCH                      // (ablation builds: tools/ablate_attn.sh -- never shipped)
         if (it + 1 < ntiles) {                 // next tile's loads fly under this tile's MFMAs
             kreg = tile_fetch<T>(Kb, p.ld_qkv, k0 + KT, kvl, tid);
             vreg = tile_fetch<T>(Vb, p.ld_qkv, k0 + KT, kvl, tid);
         }
-        f32x16 st[2] = {{0}, {0}};
+#endif
+        f32x16 st[2];
         if (!uniform) {
             tile_qk<T>(st[0], sK, r, half, qf);
             tile_qk<T>(st[1], sK + 32 * LDT, r, half, qf);
+        } else {
+            st[0] = f32x16{0};
+            st[1] = f32x16{0};
         }
         if (k0 + KT > kvl) {
 #pragma unroll
@@ -185,19 +201,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
                     if (k0 + 32 * kb + acc_row_swz(t, half) >= kvl) st[kb][t] = -INFINITY;
         }
         STAMP(ts2)
-        float mx = -INFINITY;
+        float mx = st[0][0];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) mx = fmaxf(mx, fmaxf(st[0][t], st[1][t]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx * c2);
-        const float alpha = fast_exp2(m - m_new);
-        l *= alpha; o0 *= alpha; o1 *= alpha;
-        m = m_new;
+        for (int t = 1; t < 16; t += 2) mx = max3(mx, st[0][t], st[0][t + 1 < 16 ? t + 1 : t]);
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) mx = max3(mx, st[1][t], st[1][t + 1]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+        // Deferred rescale (exact): O, l and m move only when some row's maximum grew; while it has
+        // not, p = exp2(s - m) <= 1 still holds.  Wave-uniform branch, rare after the first tiles.
+        if (!wave_all(mx <= m)) {
+            const float m_new = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - m_new);
+            l *= alpha; o0 *= alpha; o1 *= alpha;
+            m = m_new;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
+#ifdef MTMP_ABLATE_EXP
+                const float pv = fmaf(st[kb][t], c2, -m);
+#else
                 const float pv = fast_exp2(fmaf(st[kb][t], c2, -m));
+#endif
                 l += pv;
                 st[kb][t] = pv;
             }

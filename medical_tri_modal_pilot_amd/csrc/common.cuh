@@ -85,6 +85,27 @@ MTMP_DEV Frag<float> frag_keep(const Frag<float>& f, bool ok) {
     return r;
 }
 
+// All lanes of the wave agree that nothing needs masking -> skip the ANDs (interior tiles).
+MTMP_DEV bool wave_all(bool ok) { return __builtin_amdgcn_ballot_w64(!ok) == 0; }
+
+// acc = A*B (no accumulator input: the MFMA takes the inline constant 0 as C, no zero-fill moves)
+template <typename T> MTMP_DEV f32x16 mma0(const Frag<T>& a, const Frag<T>& b);
+template <> MTMP_DEV f32x16 mma0<bf16>(const Frag<bf16>& a, const Frag<bf16>& b) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, f32x16{0}, 0, 0, 0);
+}
+template <> MTMP_DEV f32x16 mma0<float>(const Frag<float>& a, const Frag<float>& b) {
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0], b.v[0], f32x16{0}, 0, 0, 0);
+#pragma unroll
+    for (int u = 1; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u], b.v[u], acc, 0, 0, 0);
+    return acc;
+}
+// max of three as ONE v_max3_f32 (fmaxf() on MFMA outputs costs an extra canonicalising v_max each)
+MTMP_DEV float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <typename T> MTMP_DEV void mma(f32x16& acc, const Frag<T>& a, const Frag<T>& b);
 template <> MTMP_DEV void mma<bf16>(f32x16& acc, const Frag<bf16>& a, const Frag<bf16>& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);

@@ -65,10 +65,21 @@ template <typename T> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, in
         frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, frag_keep(t.f[ps], (t.ok >> ps) & 1u));
 }
 
-// acc[nt]: rows = output features n0 + 32nt + acc_row(t, half), column = this lane's token row.
+// Epilogue of a 128 (tokens) x 128 (features) block, in two phases so that HBM sees whole rows:
+//  1. every wave applies bias / activation / dropout to its accumulators (acc[nt]: rows = features
+//     n0 + 32nt + acc_row(t, half), column = this lane's token) and parks them, as T, in an LDS
+//     staging tile [128 tokens][LDO];
+//  2. all 256 threads walk the tile row-wise -- 16 lanes x 16 bytes = one 256-byte row segment per
+//     pass -- apply gate / row scale / residual from equally coalesced loads and store.
+// (Storing straight from the accumulator layout writes 8-byte pieces at a row stride: partial-line
+//  writes that made the K = 256, write-heavy projections run at half their HBM bound.)
+constexpr int LDO = BN + 8;
+template <typename T> constexpr size_t stage_bytes() { return (size_t)BM * LDO * sizeof(T); }
+
 template <typename T, bool RELU>
-MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, int n0, int half) {
-    if (row >= p.M) return;
+MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int row = m0 + 32 * wave + r;
     const unsigned thr = dropout_threshold(p.drop_p);
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
 #pragma unroll
@@ -76,7 +87,7 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, in
         if (n0 + 32 * nt >= p.N) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int col = n0 + 32 * nt + 8 * g + 4 * half;
+            const int cl = 32 * nt + 8 * g + 4 * half, col = n0 + cl;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
             float v[4];
@@ -88,22 +99,40 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, int row, in
                 if (p.drop_p > 0.f)
                     v[i] = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)(col + i), thr) ? v[i] * keep_scale : 0.f;
             }
-            if (p.gate) {
-                const f32x4 gv = load4<T>(p.gate + (size_t)row * p.N + col);
+            store4<T>(sOut + (32 * wave + r) * LDO + cl, v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    const int c8 = (tid & 15) * 8, gcol = n0 + c8;
+    if (gcol < p.N) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = gv[i] > 0.f ? v[i] * p.gate_scale : 0.f;
-            }
-            if (p.row_scale) {
-                const float rsv = p.row_scale[row / p.rows_per_scale];
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rl = (tid >> 4) + 16 * ps, grow = m0 + rl;
+            if (grow >= p.M) break;
+            Frag<T> o = frag_load<T>(sOut + rl * LDO + c8);
+            if (p.gate || p.row_scale || p.res) {
+                float v[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] *= rsv;
-            }
-            if (p.res) {
-                const f32x4 rv = load4<T>(p.res + (size_t)row * p.ldr + col);
+                for (int i = 0; i < 8; ++i) v[i] = to_f32(o.v[i]);
+                if (p.gate) {
+                    const Frag<T> gv = frag_load<T>(p.gate + (size_t)grow * p.N + gcol);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = round_as<T>(v[i]) + rv[i];
+                    for (int i = 0; i < 8; ++i) v[i] = to_f32(gv.v[i]) > 0.f ? v[i] * p.gate_scale : 0.f;
+                }
+                if (p.row_scale) {
+                    const float rsv = p.row_scale[grow / p.rows_per_scale];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] *= rsv;
+                }
+                if (p.res) {
+                    const Frag<T> rv = frag_load<T>(p.res + (size_t)grow * p.ldr + gcol);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = round_as<T>(v[i]) + to_f32(rv.v[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o.v[i] = from_f32<T>(v[i]);
             }
-            store4<T>(p.y + (size_t)row * p.ldy + col, v[0], v[1], v[2], v[3]);
+            frag_store<T>(p.y + (size_t)grow * p.ldy + gcol, o);
         }
     }
 }
@@ -114,6 +143,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sW = reinterpret_cast<T*>(smem_raw);                      // [BN][LDW]
     float* sG = reinterpret_cast<float*>(sW + BN * LDW);         // gamma[256], beta[256]
+    T* sOut = reinterpret_cast<T*>(sG + 512);                    // epilogue staging tile [BM][LDO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int row = blockIdx.x * BM + wave * 32 + r;
     sG[tid] = p.gamma[tid];
@@ -171,7 +201,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
                 for (int nt = 0; nt < 4; ++nt)
                     mma<T>(acc[nt], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half), af[4 * kc + c]);
         }
-        epilogue<T, RELU>(acc, p, row, n0, half);
+        epilogue<T, RELU>(acc, p, sOut, blockIdx.x * BM, n0, tid);
     }
 }
 
@@ -207,7 +237,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
                 mma<T>(acc[nt], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half), a);
         }
     }
-    epilogue<T, RELU>(acc, p, m0 + 32 * wave + r, n0, half);
+    __syncthreads();                          // every wave is done with sA / sW: reuse them as the staging tile
+    epilogue<T, RELU>(acc, p, sA, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -365,7 +396,14 @@ int tn_splits(int M, int N, int K) {
 
 template <typename T>
 int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
-    const size_t sm = (size_t)BN * LDW * sizeof(T) + 512 * sizeof(float);
+    const size_t sm = (size_t)BN * LDW * sizeof(T) + 512 * sizeof(float) + stage_bytes<T>();
+    if (sm > 48 * 1024) {
+        const void* f = relu ? (const void*)ln_gemm_kernel<T, true> : (const void*)ln_gemm_kernel<T, false>;
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+            mtmp_set_error("mtmp_ln_gemm: cannot raise dynamic LDS to %zu", sm);
+            return MTMP_ERR_LAUNCH;
+        }
+    }
     dim3 grid((a.M + BM - 1) / BM);
     if (relu) hipLaunchKernelGGL((ln_gemm_kernel<T, true>), grid, dim3(256), sm, st, a);
     else      hipLaunchKernelGGL((ln_gemm_kernel<T, false>), grid, dim3(256), sm, st, a);
@@ -374,7 +412,8 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
 }
 template <typename T>
 int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
-    const size_t sm = (size_t)(BM + BN) * LDW * sizeof(T);
+    size_t sm = (size_t)(BM + BN) * LDW * sizeof(T);
+    if (sm < stage_bytes<T>()) sm = stage_bytes<T>();
     if (sm > 48 * 1024) {
         const void* f = relu ? (const void*)gemm_nt_kernel<T, true> : (const void*)gemm_nt_kernel<T, false>;
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
@@ -418,7 +457,7 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
                             const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
                             float eps, int relu, float drop_p, unsigned seed, void* stream) {
     MTMP_CHECK_ARG(x && gamma && beta && w && y, "mtmp_ln_gemm: null pointer");
-    MTMP_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && ldx >= 256 && ldx % 8 == 0 && ldy >= N && ldy % 4 == 0,
+    MTMP_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && ldx >= 256 && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0,
                    "mtmp_ln_gemm: bad shape M=%d N=%d ldx=%d ldy=%d (K is fixed at 256)", M, N, ldx, ldy);
     MTMP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (double)M * N < 4294967296.0, "mtmp_ln_gemm: bad dropout %f", drop_p);
     hipStream_t st = (hipStream_t)stream;
@@ -444,7 +483,7 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
                             void* stream) {
     MTMP_CHECK_ARG(a && w && y, "mtmp_gemm_nt: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
-                       ldy % 4 == 0 && (!res || (ldr >= N && ldr % 4 == 0)),
+                       ldy % 8 == 0 && (!res || (ldr >= N && ldr % 8 == 0)),
                    "mtmp_gemm_nt: bad shape M=%d N=%d K=%d lda=%d ldy=%d ldr=%d", M, N, K, lda, ldy, ldr);
     MTMP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (double)M * N < 4294967296.0, "mtmp_gemm_nt: bad dropout %f", drop_p);
     MTMP_CHECK_ARG(act >= 0 && act <= 2 && (!row_scale || rows_per_scale > 0), "mtmp_gemm_nt: bad act %d / row_scale", act);
