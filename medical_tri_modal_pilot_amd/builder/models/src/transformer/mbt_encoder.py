@@ -56,6 +56,17 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             TransformerEncoderLayer(d_model=d_model, num_heads=n_head, d_ff=d_ff, dropout_p=dropout)
             for _ in range(n_modality)]) for _ in range(n_layers))
 
+    def _side_streams(self, dev):
+        """Two extra HIP streams: the image (54-token) and text (133-token) streams of a layer cannot fill
+        256 CUs on their own, so they run beside the 1005-token vital-sign stream."""
+        if not getattr(self, "overlap_streams", True) or dev.type != "cuda":
+            return None
+        key = (dev.type, dev.index)
+        if getattr(self, "_streams_key", None) != key:
+            self._streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            self._streams_key = key
+        return self._streams
+
     # ---- integer artefacts (bit-exact with the reference) ---------------------------------
     def key_lengths(self, varying_lengths, device) -> List[Optional[torch.Tensor]]:
         """Valid tokens per stream INCLUDING the CLS token, before the bottleneck prefix
@@ -113,7 +124,7 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             fused.append(frow)
             seeds.append(srow)
         cfg = dict(n_layers=len(fl), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused,
-                   missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=None)
+                   missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev))
         out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(streams[0], streams[1], streams[2], self.bottlenecks,
                                                              *params, cfg)
         nb = self.bottlenecks_n

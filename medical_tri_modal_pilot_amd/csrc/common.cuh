@@ -175,13 +175,19 @@ MTMP_DEV float erf_as(float x) {
 }
 
 // Counter-based dropout mask: element `idx` of a call seeded with `seed` is kept iff
-// fmix32(idx * golden ^ seed) >= p * 2^32.  Stateless, so the backward regenerates the
+// a 16-bit field of fmix32(group * golden ^ seed) >= p * 2^16.  Stateless, so the backward regenerates the
 // same mask from (seed, idx) instead of storing it.
-MTMP_DEV unsigned dropout_threshold(float p) { return p <= 0.f ? 0u : (unsigned)((double)p * 4294967296.0); }
-MTMP_DEV bool dropout_keep(unsigned seed, unsigned idx, unsigned thr) {
-    unsigned x = (idx * 0x9E3779B1u) ^ seed;
+MTMP_DEV unsigned dropout_threshold(float p) { return p <= 0.f ? 0u : (unsigned)((double)p * 65536.0 + 0.5); }
+// keep-decisions for the 4 consecutive elements 4g..4g+3 of a call seeded with `seed` (bit i = keep
+// element 4g+i): ONE murmur finaliser per group + one extra mixing round; each decision compares a
+// 16-bit field with thr = p * 2^16 (the per-element hash of the first version cost more VALU than the
+// MFMAs of the projection it sat behind).
+MTMP_DEV unsigned dropout_keep4(unsigned seed, unsigned g, unsigned thr) {
+    unsigned x = (g * 0x9E3779B1u) ^ seed;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    return x >= thr;
+    unsigned y = x * 0x27D4EB2Fu; y ^= y >> 15;
+    return ((x & 0xFFFFu) >= thr ? 1u : 0u) | ((x >> 16) >= thr ? 2u : 0u) | ((y & 0xFFFFu) >= thr ? 4u : 0u) |
+           ((y >> 16) >= thr ? 8u : 0u);
 }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8)

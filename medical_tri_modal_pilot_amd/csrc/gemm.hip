@@ -91,13 +91,13 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
             float v[4];
+            const unsigned keep = p.drop_p > 0.f ? dropout_keep4(p.seed, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i] = acc[nt][4 * g + i] + bv[i];
                 if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
                 if (p.act == 2) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752f));
-                if (p.drop_p > 0.f)
-                    v[i] = dropout_keep(p.seed, (unsigned)row * (unsigned)p.N + (unsigned)(col + i), thr) ? v[i] * keep_scale : 0.f;
+                if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
             }
             store4<T>(sOut + (32 * wave + r) * LDO + cl, v[0], v[1], v[2], v[3]);
         }
@@ -531,8 +531,9 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* gi, T* go, si
     const float sc = 1.0f / (1.0f - p);
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         f32x4 v = load4<T>(gi + 4 * i);
+        const unsigned keep = dropout_keep4(seed, (unsigned)i, thr);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = dropout_keep(seed, (unsigned)(4 * i + k), thr) ? v[k] * sc : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = (keep >> k) & 1u ? v[k] * sc : 0.f;
         store4<T>(go + 4 * i, v[0], v[1], v[2], v[3]);
     }
 }
