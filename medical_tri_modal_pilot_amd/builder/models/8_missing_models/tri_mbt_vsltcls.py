@@ -118,7 +118,20 @@ class TRI_MBT_VSLTCLS(nn.Module):
             skip.append("rmse_layer.")
         if self.args.mbt_only_vslt == 1:
             skip += [f"fusion_transformer.layer_stacks.{L - 1}.1.", f"fusion_transformer.layer_stacks.{L - 1}.2."]
-        return [(n, p) for n, p in self.named_parameters() if not n.startswith(tuple(skip))]
+        named = [(n, p) for n, p in self.named_parameters() if not n.startswith(tuple(skip))]
+        # Lay every encoder layer out in ops.PARAMS order -- (gamma,beta), (Wq,Wk,Wv), (bq,bk,bv), ... adjacent --
+        # so that FlatParams gives the backward kernels contiguous gradient destinations (ops.GradSink).
+        order = {}
+        rank = [0, 1, 2, 5, 3, 6, 4, 7, 8, 9, 10, 11, 12, 13]     # param_list index -> position in the flat layout
+        for li, layers in enumerate(self.fusion_transformer.layer_stacks):
+            for m, layer in enumerate(layers):
+                for k, q in enumerate(layer.param_list()):
+                    order[id(q)] = (li, m, rank[k])
+        first = min((i for i, (_, q) in enumerate(named) if id(q) in order), default=len(named))
+        head = [x for x in named[:first] if id(x[1]) not in order]
+        body = sorted((x for x in named if id(x[1]) in order), key=lambda x: order[id(x[1])])
+        tail = [x for x in named[first:] if id(x[1]) not in order]
+        return head + body + tail
 
     def forward(self, x, h, m, d, x_m, age, gen, input_lengths, txts, txt_lengths, img, missing, f_indices, img_time,
                 txt_time, flow_type, reports_tokens, reports_lengths):

@@ -94,6 +94,18 @@ class TransformerEncoderLayer(nn.Module):
         out = ops.EncoderLayerFn.apply(inputs, kv_len, *self.param_list(), self._fused_weights(inputs.dtype), p, seeds)
         return out, None
 
+    def grad_sink(self):
+        """ops.GradSink when these parameters live in an optim.FlatParams buffer (FusedAdamW), else None."""
+        P = self.param_list()
+        flat = getattr(P[0], "_mtmp_flat", None)
+        if flat is None or any(getattr(p, "_mtmp_flat", None) is not flat for p in P):
+            return None
+        key = (id(flat), flat.grad.data_ptr())
+        if getattr(self, "_sink_key", None) != key:
+            self._sink = ops.GradSink(flat, [flat.index_of[id(p)] for p in P])
+            self._sink_key = key
+        return self._sink
+
     def dropout_args(self):
         p = self.dropout_p if self.training else 0.0
         return p, ((next_dropout_seed(), next_dropout_seed()) if p > 0 else (0, 0))

@@ -123,7 +123,8 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
                 srow.append(sd)
             fused.append(frow)
             seeds.append(srow)
-        cfg = dict(n_layers=len(fl), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused,
+        sinks = [[layer.grad_sink() for layer in layers] for layers in fl] if torch.is_grad_enabled() else None
+        cfg = dict(n_layers=len(fl), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
                    missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev))
         out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(streams[0], streams[1], streams[2], self.bottlenecks,
                                                              *params, cfg)

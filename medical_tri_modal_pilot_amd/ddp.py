@@ -48,13 +48,17 @@ class GradReducer:
         self.launched = [False] * len(self.buckets)
         self.works = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
+        flat.ready_cb = self._ready          # gradients written straight into the flat buffer (ops.GradSink)
+
+    def _ready(self, i: int):
+        b = self.bucket_of[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0 and self.overlap:
+            self._launch(b)
 
     def _make_hook(self, i: int):
         def hook(_param):
-            b = self.bucket_of[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0 and self.overlap:
-                self._launch(b)
+            self._ready(i)
         return hook
 
     def _launch(self, b: int):

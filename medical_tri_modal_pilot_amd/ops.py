@@ -104,13 +104,17 @@ def swin_window_attn(qkv, table, heads, shift):
     return out
 
 
-def gemm_tn(dy2d, x2d, want_bias=True):
-    """(dW[N,K], db[N] | None) in fp32: dW = dy^T x, db = column sums of dy (split over the M tokens)."""
+def gemm_tn(dy2d, x2d, want_bias=True, out=None):
+    """(dW[N,K], db[N] | None) in fp32: dW = dy^T x, db = column sums of dy (split over the M tokens).
+    out=(dw, db): write into these fp32 buffers (slices of the flat gradient) instead of allocating."""
     _gpu(dy2d, x2d)
     M, N = dy2d.shape
     K = x2d.shape[1]
-    dw = torch.empty(N, K, dtype=torch.float32, device=dy2d.device)
-    db = torch.empty(N, dtype=torch.float32, device=dy2d.device) if want_bias else None
+    if out is not None:
+        dw, db = out
+    else:
+        dw = torch.empty(N, K, dtype=torch.float32, device=dy2d.device)
+        db = torch.empty(N, dtype=torch.float32, device=dy2d.device) if want_bias else None
     ws = torch.empty(_lib.lib().mtmp_gemm_tn_ws_floats(M, N, K), dtype=torch.float32, device=dy2d.device)
     call("mtmp_gemm_tn", _dt(dy2d), _p(dy2d), _p(x2d), _p(dw), _p(db), _p(ws), M, N, K, dy2d.stride(0),
          x2d.stride(0), _stream())
@@ -143,12 +147,13 @@ def attn_bwd(qkv, o, d_o, lse, kv_len):
     return dqkv
 
 
-def ln_bwd(z2d, stats, gamma, dy2d, d_res2d=None):
-    """-> (dz[M,256], dgamma[256], dbeta[256]) of the custom LayerNorm (+ residual gradient)."""
+def ln_bwd(z2d, stats, gamma, dy2d, d_res2d=None, gb_out=None):
+    """-> (dz[M,256], dgamma[256], dbeta[256]) of the custom LayerNorm (+ residual gradient).
+    gb_out: fp32[512] destination for (dgamma | dbeta) (a slice of the flat gradient)."""
     _gpu(z2d, dy2d)
     M = z2d.shape[0]
     dz = torch.empty(M, D_MODEL, dtype=z2d.dtype, device=z2d.device)
-    gb = torch.empty(2 * D_MODEL, dtype=torch.float32, device=z2d.device)
+    gb = gb_out if gb_out is not None else torch.empty(2 * D_MODEL, dtype=torch.float32, device=z2d.device)
     ws = torch.empty(_lib.lib().mtmp_ln_bwd_ws_floats(M), dtype=torch.float32, device=z2d.device)
     call("mtmp_ln_bwd", _dt(z2d), _p(z2d), z2d.stride(0), _p(stats), _p(gamma), _p(dy2d), _p(d_res2d),
          0 if d_res2d is None else d_res2d.stride(0), _p(dz), _p(gb), _p(ws), M, LN_EPS, _stream())
@@ -248,26 +253,58 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     return out.view(B, N, D), saved
 
 
-def layer_backward(saved, d_out):
+class GradSink:
+    """Destinations inside optim.FlatParams' flat gradient for the 14 parameter gradients of one encoder
+    layer.  When the layer's parameters were laid out by FlatParams in ops.PARAMS order with
+    (gamma,beta), (Wq,Wk,Wv), (bq,bk,bv) adjacent, the backward kernels write dW / db / dgamma / dbeta
+    straight into the flat buffer (each parameter is used once per forward, so a freshly zeroed
+    slice can simply be overwritten) -- no per-parameter accumulate kernels, no extra copies."""
+
+    def __init__(self, flat, idx):
+        self.flat, self.idx = flat, idx              # idx: positions of the 14 parameters in flat.params
+        g, off, n = flat.grad, flat.offsets, [flat.params[i].numel() for i in idx]
+        o = [off[i] for i in idx]
+        D = D_MODEL
+        ok = (o[1] == o[0] + D and o[4] == o[2] + D * D and o[6] == o[4] + D * D and o[5] == o[3] + D and
+              o[7] == o[5] + D and o[9] == o[8] + D)
+        self.ok = ok
+        if ok:
+            self.gb1 = g[o[0]:o[0] + 2 * D]
+            self.wqkv, self.bqkv = g[o[2]:o[2] + 3 * D * D].view(3 * D, D), g[o[3]:o[3] + 3 * D]
+            self.gb2 = g[o[8]:o[8] + 2 * D]
+            self.w1, self.c1 = g[o[10]:o[10] + n[10]].view(4 * D, D), g[o[11]:o[11] + 4 * D]
+            self.w2, self.c2 = g[o[12]:o[12] + n[12]].view(D, 4 * D), g[o[13]:o[13] + D]
+
+    def usable(self):
+        """Direct writes only into slices not yet written since the last zero_grad()."""
+        return self.ok and self.flat.claim(self.idx)
+
+
+def layer_backward(saved, d_out, sink=None):
     """d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
-    in PARAMS order; weights as 2-D [out,in]))."""
+    in PARAMS order; weights as 2-D [out,in])) -- or (dz, None) when the gradients went straight into
+    the flat gradient buffer through `sink`."""
     z, kv_len, g1, g2, wqkv, w1c, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds = saved
     B, N, D = z.shape
     M = B * N
     d_out = d_out.view(M, D)
     # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
     dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
-    dw2, dc2 = gemm_tn(dy2, h)                              # [256,1024], [256]
+    direct = sink is not None and sink.usable()
+    dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None)       # [256,1024], [256]
     # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue
     dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
-    dw1, dc1 = gemm_tn(dh, xn2)                             # [1024,256], [1024]
+    dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None)      # [1024,256], [1024]
     dxn2 = dh @ w1c                                         # [M,256]   (plain BLAS)
-    dr1, dg2, db2 = ln_bwd(r1.view(M, D), st2, g2, dxn2, d_res2d=d_out)
+    dr1, dg2, db2 = ln_bwd(r1.view(M, D), st2, g2, dxn2, d_res2d=d_out, gb_out=sink.gb2 if direct else None)
     # ---- attention: r1 = z + o  ->  d_o = dr1
     dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
-    dwqkv, dbqkv = gemm_tn(dqkv, xn1)                       # [768,256], [768]
+    dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None)   # [768,256], [768]
     dxn1 = dqkv @ wqkv                                      # [M,256]   (plain BLAS)
-    dz, dg1, db1 = ln_bwd(z.view(M, D), st1, g1, dxn1, d_res2d=dr1)
+    dz, dg1, db1 = ln_bwd(z.view(M, D), st1, g1, dxn1, d_res2d=dr1, gb_out=sink.gb1 if direct else None)
+    if direct:
+        sink.flat.mark_ready(sink.idx)
+        return dz.view(B, N, D), None
     grads = (dg1, db1, dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
              dg2, db2, dw1, dc1, dw2, dc2)
     return dz.view(B, N, D), grads
@@ -417,16 +454,18 @@ class FusionStackFn(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record(cur)
             for m in ms:
+                sink = cfg["sinks"][li][m] if cfg.get("sinks") else None
                 if streams is not None and m > 0:
                     s = streams[m - 1]
                     s.wait_event(ev)
                     with torch.cuda.stream(s):
-                        nxt[m], g = layer_backward(saved[li][m], dz[m])
+                        nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
                 else:
-                    nxt[m], g = layer_backward(saved[li][m], dz[m])
+                    nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
                 base = (li * 3 + m) * PARAMS_PER_LAYER
-                for k in range(PARAMS_PER_LAYER):
-                    pgrads[base + k] = g[k].view(pshapes[base + k])
+                if g is not None:
+                    for k in range(PARAMS_PER_LAYER):
+                        pgrads[base + k] = g[k].view(pshapes[base + k])
             if streams is not None and len(ms) > 1:
                 for s in streams:
                     cur.wait_stream(s)

@@ -35,11 +35,15 @@ class FlatParams:
         self.numel = off
         self.data = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.index_of = {id(p): i for i, p in enumerate(self.params)}
+        self.written = set()          # parameter indices whose gradient slice was written directly since zero_grad
+        self.ready_cb = None          # ddp.GradReducer: called with an index when a slice was written directly
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.data[o:o + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
+                p._mtmp_flat = self
         self.attach_grads()
 
     def attach_grads(self):
@@ -51,7 +55,24 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
+        self.written.clear()
         self.attach_grads()
+
+    # ---- direct writes by the backward kernels (ops.GradSink) ----
+    def claim(self, idx) -> bool:
+        """True if none of these gradient slices was written since the last zero_grad() and every p.grad is
+        still the flat view (then a kernel may overwrite them); False -> caller returns gradients normally."""
+        for i in idx:
+            p = self.params[i]
+            if i in self.written or p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[i]:
+                return False
+        self.written.update(idx)
+        return True
+
+    def mark_ready(self, idx):
+        if self.ready_cb is not None:
+            for i in idx:
+                self.ready_cb(i)
 
     def slice_of(self, i: int) -> Tuple[int, int]:
         return self.offsets[i], self.offsets[i] + self.params[i].numel()

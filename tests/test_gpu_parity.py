@@ -414,6 +414,10 @@ def _run_steps(dtype, multi, tag, fused):
                            txt_lengths=bt["txt_lengths"].clone(), flow_type="train", **kw)
     for h in hooks:
         h.remove()
+    hot = set(n for n, _ in model.hot_parameters())
+    for n, p in model.named_parameters():     # gradients written straight into the flat buffer bypass the hooks
+        if n not in grads and n in hot and p.grad is not None:
+            grads[n] = p.grad.detach().clone()
     lr_after = opt.param_groups[0]["lr"]
     params1 = {n: p.detach().clone() for n, p in model.named_parameters()}
     _, loss2 = get_trainer(iteration=2, input_lengths=bt["input_lengths"].clone(),
