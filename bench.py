@@ -35,13 +35,13 @@ B_PER_GPU, TIE_LEN, LAYERS = 64, 1000, 6
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def make_args(dtype: str, dropout: float):
+def make_args(dtype: str, dropout: float, hip_graph: int = 1):
     from medical_tri_modal_pilot_amd.control.config import parse_args
     return parse_args(["--input-types", "vslt_img_txt", "--model", "tri_mbt_vsltcls", "--modality-inclusion",
                        "train-missing_test-missing", "--lr-init", "1e-5", "--output-type", "intubation",
                        "--batch-size", str(B_PER_GPU), "--transformer-num-layers", str(LAYERS), "--vslt-type", "TIE",
                        "--model-types", "detection", "--imgtxt-time", "1", "--mbt-only-vslt", "1", "--multiimages", "0",
-                       "--dropout", str(dropout), "--compute-dtype", dtype])
+                       "--dropout", str(dropout), "--compute-dtype", dtype, "--hip-graph", str(hip_graph)])
 
 
 def cpu_baseline(sample_b: int = 8, timed: int = 2):
@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-graph", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--probe-steps", type=int, default=5, help="eager steps after the timed region that time "
+                    "the roofline kernel with HIP events (only when the timed region replays a hipGraph)")
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,7 +88,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # MTMP_FORCE_DDP=1: run the RCCL reducer even with one rank (exercises the N>1 code path on a 1-GPU box)
+    ddp = world > 1 or bool(os.environ.get("MTMP_FORCE_DDP"))
+    if ddp and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    if ddp:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import filler
@@ -96,15 +103,15 @@ def main():
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     from medical_tri_modal_pilot_amd.ddp import GradReducer, broadcast_module_state
 
-    args = make_args(a.dtype, a.dropout)
+    args = make_args(a.dtype, a.dropout, a.hip_graph)
     args.device = dev
     torch.manual_seed(412)
     model = get_model(args)(args).to(dev)
-    if world > 1:
+    if ddp:
         broadcast_module_state(model, 0)
     model.train()
     opt = FusedAdamW(model.hot_parameters(), lr=args.lr_init, weight_decay=args.weight_decay)
-    if world > 1:
+    if ddp:
         opt.reducer = GradReducer(opt.flat)
         opt.grad_scale = 1.0 / world
     sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=args.t_0 * 100, cycle_mult=args.t_mult,
@@ -147,7 +154,21 @@ def main():
 
     ops.attn_fwd = timed_attn_fwd
 
+    # host-side enqueue time: from step start until the trainer blocks in loss.item()
+    enq = {"t0": 0.0, "sum": 0.0, "n": 0}
+    raw_item = torch.Tensor.item
+
+    def timed_item(self):
+        if record["on"] and enq["t0"] > 0:
+            enq["sum"] += time.perf_counter() - enq["t0"]
+            enq["n"] += 1
+            enq["t0"] = 0.0
+        return raw_item(self)
+
+    torch.Tensor.item = timed_item
+
     def step(it):
+        enq["t0"] = time.perf_counter()
         return get_trainer(iteration=it, input_lengths=in_len_host, txt_lengths=d["txt_lengths"], **kw)[1]
 
     for i in range(a.warmup):
@@ -165,6 +186,20 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     record["on"] = False
+    host_ms = 1e3 * enq["sum"] / max(1, enq["n"])
+    gs = getattr(model, "_mtmp_graph_step", None)
+    graphed = gs is not None and gs.replays >= a.steps
+    if graphed and rank == 0:
+        # events cannot time one kernel inside a replayed graph: time the same kernel on the same workload in
+        # eager steps right after the timed region (its rocprofv3 average covers both kinds of launch)
+        events.clear()
+        args.hip_graph = 0
+        record["on"] = True
+        for i in range(a.probe_steps):
+            step(a.warmup + a.steps + i + 1)
+        torch.cuda.synchronize()
+        record["on"] = False
+        args.hip_graph = a.hip_graph
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -180,7 +215,8 @@ def main():
         out = {
             "metric": "tri-modal training samples/s (fwd+bwd+AdamW step, per-GPU batch 64)",
             "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
             "config": {"workload": "BASELINE configs[1]: vslt_img_txt tri_mbt_vsltcls, 6 layers, d_model 256, "
                                    "batch 64/GPU, TIE-len 1000 (N_v=1005), 224x224 CXR, 128-tok text, "
@@ -189,12 +225,13 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel<bf16> (vslt stream, N=1005)" if a.dtype == "bf16"
                          else "attn_fwd_kernel<float>", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
-                         "launches_timed": len(events), "avg_launch_ms": k_ms, "flops_per_launch": flops},
+                         "launches_timed": len(events), "avg_launch_ms": k_ms, "flops_per_launch": flops,
+                         "timed_in": "eager probe steps after the graph-replay region" if graphed else "timed steps"},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

@@ -53,10 +53,12 @@ int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const 
  * or the first FFN conv + ReLU (module.py:74-77).  gamma/beta/bias fp32; w in `dtype`.
  * Optional outputs: xn[M,256] = LN(x) (dtype), stats[M,2] = (mean, 1/(std+eps)).
  * drop_p > 0 applies nn.Dropout (module.py:77-79 drop1) to the activated output with the
- * counter-based mask keep(seed, row*N+col); the backward regenerates it (mtmp_dropout_bwd). */
+ * counter-based mask keep(seed ^ *seed_dev, row*N+col); the backward regenerates it (mtmp_dropout_bwd).
+ * seed_dev (may be NULL) is a device word the host advances every step, so that a captured hipGraph
+ * (whose scalar arguments are frozen) still draws fresh masks on every replay. */
 int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, const void* w, const float* bias,
                  void* y, void* xn, float* stats, int M, int N, int ldx, int ldy, float eps, int relu, float drop_p,
-                 unsigned seed, void* stream);
+                 unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* y[M,N] = drop(act(a[M,K] w[N,K]^T + bias)) (+ res[M,N]); K % 64 == 0, N % 32 == 0.
  * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32).  With gate[M,N] != NULL the
@@ -66,8 +68,8 @@ int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta
  * row_scale[M / rows_per_scale] (may be NULL) multiplies row blocks before the residual add
  * (row-mode StochasticDepth of the Swin blocks). */
 int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N,
-                 int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed, const void* gate,
-                 float gate_scale, const float* row_scale, int rows_per_scale, void* stream);
+                 int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed, const unsigned* seed_dev,
+                 const void* gate, float gate_scale, const float* row_scale, int rows_per_scale, void* stream);
 
 /* Weight / bias gradient of the Linear and k=1 Conv1d layers (attention.py:60-62, module.py:74-78):
  * dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db[N] (fp32, may be NULL) = column sums of dy.
@@ -79,7 +81,8 @@ int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw, float* db,
 
 /* g_out[i] = keep(seed,i) ? g_in[i]/(1-p) : 0 over n contiguous elements: backward of the epilogue
  * dropout above (n = M*N of that call, n % 4 == 0). */
-int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long long n, unsigned seed, float p, void* stream);
+int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long long n, unsigned seed, const unsigned* seed_dev,
+                     float p, void* stream);
 
 /* Backward of the custom LayerNorm (module.py:138-144), plus the residual-branch gradient:
  * dz[M,256] = LNbwd(dy[M,256]; z, stats, gamma) (+ d_res); dgamma_dbeta float[512] overwritten.

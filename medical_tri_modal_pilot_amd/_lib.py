@@ -19,8 +19,8 @@ SIGNATURES = {
     "mtmp_last_error": (c_char_p, []),
     "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
-    "mtmp_ln_gemm": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_float, c_uint, c_void_p]),
-    "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_float, c_void_p, c_int,
+    "mtmp_ln_gemm": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_float, c_uint, c_void_p, c_void_p]),
+    "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_void_p, c_float, c_void_p, c_int,
                              c_void_p]),
     "mtmp_layernorm_rows": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p]),
     "mtmp_swin_window_attn": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
@@ -34,7 +34,7 @@ SIGNATURES = {
     "mtmp_tie_embed_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
     "mtmp_swin_stem_fwd": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "mtmp_adamw_step": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 5 + [c_int, c_float, c_void_p]),
-    "mtmp_dropout_bwd": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_uint, c_float, c_void_p]),
+    "mtmp_dropout_bwd": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_uint, c_void_p, c_float, c_void_p]),
 }
 
 _lib = None

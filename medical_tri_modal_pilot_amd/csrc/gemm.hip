@@ -32,7 +32,9 @@ template <typename T> struct GemmArgs {
     int M, N, K, lda, ldy, ldr;
     float eps;
     float drop_p;        // nn.Dropout probability applied after act (0 = off), module.py:77-79
-    unsigned seed;       // per-call seed of the counter-based mask (common.cuh: dropout_keep)
+    unsigned seed;       // per-call seed of the counter-based mask (common.cuh: dropout_keep4)
+    const unsigned* seed_dev;   // optional device word XOR-ed into seed (advanced by the host/graph every step,
+                                // so a replayed hipGraph does not repeat its masks)
     const T* gate;       // optional [M,N]: y = gate > 0 ? y * gate_scale : 0  (ReLU/dropout backward)
     float gate_scale;
     int act;             // 0 none, 1 ReLU, 2 exact GELU (Swin MLP, swin_transformer.py:439)
@@ -82,6 +84,7 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
     const int row = m0 + 32 * wave + r;
     const unsigned thr = dropout_threshold(p.drop_p);
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
+    const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         if (n0 + 32 * nt >= p.N) continue;
@@ -91,7 +94,7 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
             float v[4];
-            const unsigned keep = p.drop_p > 0.f ? dropout_keep4(p.seed, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
+            const unsigned keep = p.drop_p > 0.f ? dropout_keep4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 v[i] = acc[nt][4 * g + i] + bv[i];
@@ -455,7 +458,7 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
 // (relu=0, N=768) and module.py:138-144 + module.py:74-77 (relu=1, N=1024).
 extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, const void* w,
                             const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
-                            float eps, int relu, float drop_p, unsigned seed, void* stream) {
+                            float eps, int relu, float drop_p, unsigned seed, const unsigned* seed_dev, void* stream) {
     MTMP_CHECK_ARG(x && gamma && beta && w && y, "mtmp_ln_gemm: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && ldx >= 256 && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0,
                    "mtmp_ln_gemm: bad shape M=%d N=%d ldx=%d ldy=%d (K is fixed at 256)", M, N, ldx, ldy);
@@ -463,12 +466,12 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> a{(const float*)x, (const float*)w, bias, nullptr, (float*)y, gamma, beta, (float*)xn, stats,
-                          M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f, 0, nullptr, 1};
+                          M, N, 256, ldx, ldy, 0, eps, drop_p, seed, seed_dev, nullptr, 1.f, 0, nullptr, 1};
         return launch_ln_gemm<float>(a, relu, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, gamma, beta, (bf16*)xn, stats,
-                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, nullptr, 1.f, 0, nullptr, 1};
+                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, seed_dev, nullptr, 1.f, 0, nullptr, 1};
         return launch_ln_gemm<bf16>(a, relu, st);
     }
     mtmp_set_error("mtmp_ln_gemm: unknown dtype %d", dtype);
@@ -479,8 +482,8 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
 // (Conv1d(1024,256,1) + drop2 + residual) and is the generic NT projection of the path.
 extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
                             int M, int N, int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed,
-                            const void* gate, float gate_scale, const float* row_scale, int rows_per_scale,
-                            void* stream) {
+                            const unsigned* seed_dev, const void* gate, float gate_scale, const float* row_scale,
+                            int rows_per_scale, void* stream) {
     MTMP_CHECK_ARG(a && w && y, "mtmp_gemm_nt: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
                        ldy % 8 == 0 && (!res || (ldr >= N && ldr % 8 == 0)),
@@ -490,13 +493,13 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> g{(const float*)a, (const float*)w, bias, (const float*)res, (float*)y, nullptr, nullptr,
-                          nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const float*)gate, gate_scale, act, row_scale,
+                          nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, seed_dev, (const float*)gate, gate_scale, act, row_scale,
                           rows_per_scale};
         return launch_gemm_nt<float>(g, 0, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, bias, (const bf16*)res, (bf16*)y, nullptr, nullptr, nullptr,
-                         nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, (const bf16*)gate, gate_scale, act, row_scale,
+                         nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, seed_dev, (const bf16*)gate, gate_scale, act, row_scale,
                          rows_per_scale};
         return launch_gemm_nt<bf16>(g, 0, st);
     }
@@ -526,7 +529,9 @@ extern "C" int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw,
 namespace {
 // g_out[i] = keep(seed, i) ? g_in[i] / (1-p) : 0 -- backward of the epilogue dropout (same mask).
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* gi, T* go, size_t n4, unsigned seed, float p) {
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* gi, T* go, size_t n4, unsigned seed0, const unsigned* seed_dev,
+                                                          float p) {
+    const unsigned seed = seed0 ^ (seed_dev ? *seed_dev : 0u);
     const unsigned thr = dropout_threshold(p);
     const float sc = 1.0f / (1.0f - p);
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -541,15 +546,15 @@ __global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* gi, T* go, si
 
 // Backward of the dropout applied in the mtmp_gemm_nt / mtmp_ln_gemm epilogue with the same
 // (seed, p) on a contiguous [M,N] tensor of n = M*N elements (n % 4 == 0); in place allowed.
-extern "C" int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long long n, unsigned seed, float p,
-                                void* stream) {
+extern "C" int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long long n, unsigned seed,
+                                const unsigned* seed_dev, float p, void* stream) {
     MTMP_CHECK_ARG(g_in && g_out && n > 0 && n % 4 == 0 && n < 4294967296LL && p >= 0.f && p < 1.f,
                    "mtmp_dropout_bwd: bad argument n=%lld p=%f", n, p);
     const size_t n4 = (size_t)n / 4;
     const int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)g_in, (float*)g_out, n4, seed, p);
-    else if (dtype == 1) hipLaunchKernelGGL(dropout_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)g_in, (bf16*)g_out, n4, seed, p);
+    if (dtype == 0) hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)g_in, (float*)g_out, n4, seed, seed_dev, p);
+    else if (dtype == 1) hipLaunchKernelGGL(dropout_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, (const bf16*)g_in, (bf16*)g_out, n4, seed, seed_dev, p);
     else { mtmp_set_error("mtmp_dropout_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_dropout_bwd");
     return MTMP_OK;

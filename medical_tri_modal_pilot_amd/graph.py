@@ -1,0 +1,102 @@
+"""hipGraph replay of the training step's device work (zero_grad + forward + BCE + backward).
+
+Why: at config 2 the step launches ~750 kernels; one MI355X finishes them in less time than one
+CPU core needs to enqueue them through Python (bench.py: host_enqueue_ms_per_step), so the eager
+step is host-bound.  The step's launch sequence is static for a given input shape -- ragged
+batches only change *kv_len tensors*, which the kernels read from HBM -- so it is captured once per
+shape and replayed with one hipGraphLaunch.
+
+What is inside the graph: the advance of the dropout step word (ops.set_seed_word), the gradient
+memset, the forward (HIP kernels on three streams, fork/join captured), the loss, the backward
+(direct gradient writes into optim.FlatParams.grad).  What stays outside: host->device copies of
+the batch into the static input buffers, missing_to_num (CPU, trainer.py:53-77), the gradient
+all-reduce (ddp.GradReducer, world > 1), AdamW (one launch; lr / bias corrections are host
+scalars that change every step), the scheduler, and loss.item().
+
+Anything that would make a replay differ from an eager step is keyed or refused:
+  * one graph per input signature (names, shapes, dtypes); at most ``max_graphs`` live (LRU);
+  * the first ``warmup`` calls of a signature run eagerly (lazy initialisation must not be captured);
+  * a failed capture disables graphs for this object and the step runs eagerly (never silently wrong:
+    capture either succeeds completely or the eager path is used).
+"""
+import warnings
+from collections import OrderedDict
+from typing import Callable, Dict
+
+import torch
+
+from . import ops
+
+_GOLDEN = 0x9E3779B1          # odd increment of the step word
+
+
+class GraphedTrainStep:
+    def __init__(self, device: torch.device, max_graphs: int = 8, warmup: int = 1):
+        if device.type != "cuda":
+            raise RuntimeError("hipGraph capture needs a GPU device")
+        self.device = device
+        self.max_graphs, self.warmup = max_graphs, warmup
+        self.entries: "OrderedDict[tuple, dict]" = OrderedDict()
+        self.disabled = False
+        self.seed_word = torch.full((1,), torch.initial_seed() & 0x7FFFFFFF, dtype=torch.int64, device=device)
+        ops.set_seed_word(self.seed_word)
+        self.pool = None
+        self.captures = 0
+        self.replays = 0
+
+    @staticmethod
+    def signature(inputs: Dict[str, torch.Tensor]) -> tuple:
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in inputs.items())
+
+    def invalidate(self):
+        """Drop every captured graph (call after load_state_dict / any change of module structure or flags)."""
+        self.entries.clear()
+
+    def _capture(self, ent: dict, inputs: Dict[str, torch.Tensor], fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
+                 params):
+        static = {k: v.detach().clone() for k, v in inputs.items()}
+        if params:
+            torch._C._increment_version(params)      # compute-dtype weight casts must be re-done INSIDE the graph
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(g, pool=self.pool):
+            self.seed_word.add_(_GOLDEN)
+            loss = fn(static)
+        if self.pool is None:
+            self.pool = g.pool()
+        ent.update(graph=g, static=static, loss=loss)
+        self.captures += 1
+
+    def run(self, inputs: Dict[str, torch.Tensor], fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
+            params=None) -> torch.Tensor:
+        """fn(inputs) -> scalar loss tensor; must do zero_grad + forward + backward with no host sync.
+        Returns the loss tensor of this step (a static buffer when replayed)."""
+        if self.disabled:
+            return fn(inputs)
+        key = self.signature(inputs)
+        ent = self.entries.get(key)
+        if ent is None:
+            ent = self.entries[key] = {"seen": 0}
+            while len(self.entries) > self.max_graphs:
+                self.entries.popitem(last=False)
+        self.entries.move_to_end(key)
+        if "graph" not in ent:
+            if ent["seen"] < self.warmup:
+                ent["seen"] += 1
+                self.seed_word.add_(_GOLDEN)
+                return fn(inputs)
+            try:
+                self._capture(ent, inputs, fn, params)
+            except Exception as e:                      # noqa: BLE001 -- any capture failure -> eager
+                self.disabled = True
+                self.entries.clear()
+                torch.cuda.synchronize(self.device)
+                warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+                              "continuing with eager launches")
+                return fn(inputs)
+        else:
+            for k, v in inputs.items():
+                ent["static"][k].copy_(v, non_blocking=True)
+        ent["graph"].replay()
+        self.replays += 1
+        return ent["loss"]

@@ -46,6 +46,19 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Device-resident step word of the dropout masks.  The scalar `seed` arguments below are frozen into a captured
+# hipGraph; the kernels XOR them with the low 32 bits of this int64 word, which graph.GraphedTrainStep advances
+# inside the graph, so every replay draws fresh masks.  None (eager mode) = NULL pointer = plain scalar seeds.
+_seed_word: Optional[torch.Tensor] = None
+
+
+def set_seed_word(t: Optional[torch.Tensor]):
+    global _seed_word
+    if t is not None and (t.dtype != torch.int64 or t.numel() != 1 or not t.is_cuda):
+        raise ValueError("seed word must be a one-element int64 CUDA tensor")
+    _seed_word = t
+
+
 # ----------------------------------------------------------------------------- raw kernels
 def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, want_xn=True):
     """y = act(LN(x) w^T + bias); returns (y[M,n_out], xn[M,256] | None, stats[M,2])."""
@@ -55,7 +68,7 @@ def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, wa
     xn = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=x2d.device) if want_xn else None
     stats = torch.empty(M, 2, dtype=torch.float32, device=x2d.device)
     call("mtmp_ln_gemm", _dt(x2d), _p(x2d), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), _p(xn), _p(stats),
-         M, n_out, x2d.stride(0), n_out, LN_EPS, int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _stream())
+         M, n_out, x2d.stride(0), n_out, LN_EPS, int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _stream())
     return y, xn, stats
 
 
@@ -70,7 +83,7 @@ def gemm_nt(a2d, w, bias=None, res2d=None, act=None, drop_p=0.0, seed=0, gate=No
     N = w.shape[0]
     y = torch.empty(M, N, dtype=a2d.dtype, device=a2d.device)
     call("mtmp_gemm_nt", _dt(a2d), _p(a2d), _p(w), _p(bias), _p(res2d), _p(y), M, N, K, a2d.stride(0), N,
-         0 if res2d is None else res2d.stride(0), ACT[act], float(drop_p), int(seed) & 0xFFFFFFFF, _p(gate),
+         0 if res2d is None else res2d.stride(0), ACT[act], float(drop_p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _p(gate),
          float(gate_scale), _p(row_scale), int(rows_per_scale), _stream())
     return y
 
@@ -162,7 +175,8 @@ def ln_bwd(z2d, stats, gamma, dy2d, d_res2d=None, gb_out=None):
 
 def dropout_bwd(g, seed, p):
     out = torch.empty_like(g)
-    call("mtmp_dropout_bwd", _dt(g), _p(g), _p(out), g.numel(), int(seed) & 0xFFFFFFFF, float(p), _stream())
+    call("mtmp_dropout_bwd", _dt(g), _p(g), _p(out), g.numel(), int(seed) & 0xFFFFFFFF, _p(_seed_word),
+         float(p), _stream())
     return out
 
 
@@ -337,6 +351,15 @@ class EncoderLayerFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------- fusion stack engine
 _EXCHANGE_W = torch.tensor([[1 / 3, 1 / 3, 1 / 3], [0.5, 0.5, 0.0], [0.5, 0.0, 0.5], [1.0, 0.0, 0.0]])
 NB = 4   # bottleneck tokens
+_exchange_w_dev = {}
+
+
+def _exchange_w(dev):
+    """Device copy of the exchange table, made once (a pageable H2D copy cannot be captured in a hipGraph)."""
+    k = (dev.type, dev.index)
+    if k not in _exchange_w_dev:
+        _exchange_w_dev[k] = _EXCHANGE_W.to(dev)
+    return _exchange_w_dev[k]
 
 
 class FusionStackFn(torch.autograd.Function):
@@ -368,7 +391,7 @@ class FusionStackFn(torch.autograd.Function):
             buf[:, NB:] = x
             buf[:, :NB] = bott.to(dt)
             z.append(buf)
-        wsel = _EXCHANGE_W.to(dev)[cfg["missing"]]                      # [B,3] exchange weights per sample
+        wsel = _exchange_w(dev)[cfg["missing"]]                     # [B,3] exchange weights per sample
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
         saved, active = [], []
