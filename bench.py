@@ -110,6 +110,8 @@ def main():
     if ddp:
         broadcast_module_state(model, 0)
     model.train()
+    if os.environ.get("MTMP_NO_OVERLAP"):            # experiment switch: all three modality streams on one HIP stream
+        model.fusion_transformer.overlap_streams = False
     opt = FusedAdamW(model.hot_parameters(), lr=args.lr_init, weight_decay=args.weight_decay)
     if ddp:
         opt.reducer = GradReducer(opt.flat)

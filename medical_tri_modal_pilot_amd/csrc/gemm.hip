@@ -141,23 +141,101 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
 }
 
 // ---------------------------------------------------------------------------
+// A-stationary row-panel kernel (K = 256).  A workgroup owns 128 token rows (32 per wave, held as 16
+// normalised MFMA fragments in registers for the whole kernel) and walks over its share of the output
+// features in PANELS of NP features: the [NP][256] weight panel is the only thing that goes through LDS.
+//
+// The loop is written for memory latency, which is what bounded the first version (its s_waitcnt vmcnt(0)
+// at the top of every k-chunk also waited for the previous tile's output STORES -- gfx9 counts loads and
+// stores in one in-order counter):
+//   * two LDS panel buffers, one barrier per panel;
+//   * the global loads of panel j+2 are issued BEFORE the stores of panel j, and are only waited for after
+//     the MFMAs of panel j+1, so a wait for loads never covers younger stores;
+//   * every load and store is unconditional: rows >= M read (and therefore recompute and rewrite) row M-1,
+//     which keeps the in-flight counts static so that hipcc emits exact vmcnt(N) waits;
+//   * the epilogue parks 32 tokens x 32 features per wave in a wave-private LDS tile (no barrier) and
+//     writes 64-byte row pieces, 16 rows per store instruction.
+// gridDim.y splits the panels of one row block over several workgroups when M alone cannot fill 256 CUs
+// (image / text streams: 29 and 69 row blocks); split 0 writes xn / stats.
+template <typename T> struct Panel {
+    static constexpr int NP = sizeof(T) == 2 ? 64 : 32;          // features per panel (32 KiB of weights)
+    static constexpr int G = NP / 32;                            // 32-feature MFMA groups per panel
+    static constexpr int LDP = 256 + 16 / (int)sizeof(T);        // panel row + 16 B pad (conflict-free ds_read_b128)
+    static constexpr int CPR = 256 * (int)sizeof(T) / 16;        // 16-byte chunks per weight row
+    static constexpr int LOADS = NP * CPR / 256;                 // 16-byte loads per thread per panel (= 8)
+    static constexpr int FS = 32 + 16 / (int)sizeof(T);          // staging row: 32 features + 16 B pad
+    static constexpr int LPT = 32 * (int)sizeof(T) / 16;         // lanes per token row in the store phase
+    static constexpr int PASSES = 32 * LPT / 64;                 // store instructions per 32 x 32 tile
+    static constexpr size_t panel_bytes = (size_t)NP * LDP * sizeof(T);
+    static constexpr size_t stage_bytes_wave = (size_t)32 * FS * sizeof(T);
+    static constexpr size_t lds_bytes = 2 * panel_bytes + 4 * stage_bytes_wave;
+};
+struct PanelRegs { u32x4_t q[8]; };
+
+template <typename T> MTMP_DEV void panel_fetch(PanelRegs& w, const T* wsrc, int n0, int N, int tid) {
+    using P = Panel<T>;
+#pragma unroll
+    for (int i = 0; i < P::LOADS; ++i) {
+        const int id = i * 256 + tid, row = id / P::CPR, ch = id % P::CPR;
+        w.q[i] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(wsrc + (size_t)min(n0 + row, N - 1) * 256) + 16 * ch);
+    }
+}
+template <typename T> MTMP_DEV void panel_commit(T* dst, const PanelRegs& w, int tid) {
+    using P = Panel<T>;
+#pragma unroll
+    for (int i = 0; i < P::LOADS; ++i) {
+        const int id = i * 256 + tid, row = id / P::CPR, ch = id % P::CPR;
+        *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst + row * P::LDP) + 16 * ch) = w.q[i];
+    }
+}
+// bias of one panel in accumulator order (lane half h: features 32g + 8*i4 + 4h .. +3); a null bias reads zeros
+// from a constant so that the load count per iteration stays static
+template <typename T>
+MTMP_DEV void bias_fetch(f32x4 (&b)[Panel<T>::G][4], const float* bias, const T* w, int n0, int half) {
+    // (a select between the bias and a __device__ constant would turn these into FLAT loads, whose
+    //  out-of-order counters force s_waitcnt 0 everywhere; with no bias, the first N*4 bytes of W are read
+    //  and masked to zero instead -- both are kernel-argument, i.e. global, pointers)
+    const float* src = bias ? bias : reinterpret_cast<const float*>(w);
+    const unsigned m = bias ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int g = 0; g < Panel<T>::G; ++g)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + n0 + 32 * g + 8 * i4 + 4 * half);
+            b[g][i4] = __builtin_bit_cast(f32x4, v & u32x4_t{m, m, m, m});
+        }
+}
+// LDS traffic of ONE wave to its private staging tile needs no barrier (a wave's LDS instructions execute in
+// order); this only stops the compiler from moving memory operations across the hand-over point.
+MTMP_DEV void wave_lds_handover() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <typename T, bool RELU>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(GemmArgs<T> p) {
+    using P = Panel<T>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sW = reinterpret_cast<T*>(smem_raw);                      // [BN][LDW]
-    float* sG = reinterpret_cast<float*>(sW + BN * LDW);         // gamma[256], beta[256]
-    T* sOut = reinterpret_cast<T*>(sG + 512);                    // epilogue staging tile [BM][LDO]
+    T* sP = reinterpret_cast<T*>(smem_raw);                                       // [2][NP][LDP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
-    const int row = blockIdx.x * BM + wave * 32 + r;
-    sG[tid] = p.gamma[tid];
-    sG[256 + tid] = p.beta[tid];
+    T* sS = reinterpret_cast<T*>(smem_raw + 2 * P::panel_bytes) + wave * 32 * P::FS;   // wave-private [32][FS]
+    float* sG = reinterpret_cast<float*>(smem_raw + 2 * P::panel_bytes);          // gamma|beta, prologue only (aliases sS)
+    const int npanels = p.N / P::NP;
+    const int per = (npanels + gridDim.y - 1) / gridDim.y;
+    const int j0 = blockIdx.y * per, j1 = min(npanels, j0 + per);
+    if (j0 >= j1) return;
+    const int m_wave = blockIdx.x * BM + wave * 32;
+    const int row = min(m_wave + r, p.M - 1);
+    PanelRegs wreg;
+    panel_fetch<T>(wreg, p.w, j0 * P::NP, p.N, tid);
+    if (p.gamma) {
+        sG[tid] = p.gamma[tid];
+        sG[256 + tid] = p.beta[tid];
+    }
     // ---- LayerNorm prologue, in registers: lane (r, half) holds k = 16c + 8*half + j of row r
     Frag<T> af[16];
     float s1 = 0.f;
-    const T* arow = p.a + (size_t)min(row, p.M - 1) * p.lda + 8 * half;
+    const T* arow = p.a + (size_t)row * p.lda + 8 * half;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        af[c] = frag_keep(frag_load<T>(arow + 16 * c), row < p.M);
+        af[c] = frag_load<T>(arow + 16 * c);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
     }
@@ -172,39 +250,72 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     const float sigma = sqrtf(s2 * (1.0f / 255.0f));             // torch.std: Bessel-corrected
     const float rs = 1.0f / (sigma + p.eps);
     __syncthreads();                                             // sG ready
+    if (p.gamma) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int k = 16 * c + 8 * half;
+        for (int c = 0; c < 16; ++c) {
+            const int k = 16 * c + 8 * half;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
-        if (p.xn && row < p.M) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
-    }
-    if (p.stats && half == 0 && row < p.M) {
-        p.stats[2 * (size_t)row] = mean;
-        p.stats[2 * (size_t)row + 1] = rs;
-    }
-    // ---- Y tiles: for each 128-column block, 4 k-chunks of 64 (kc unrolled: af[] stays in registers)
-    const int nblk = (p.N + BN - 1) / BN;
-    TileRegs<T> wreg;
-    tile_fetch<T>(wreg, p.w, 256, 0, p.N, 0, tid, 256);
-    for (int nb = 0; nb < nblk; ++nb) {
-        const int n0 = nb * BN;
-        f32x16 acc[4] = {{0}, {0}, {0}, {0}};
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            __syncthreads();
-            tile_commit<T>(sW, wreg, tid);
-            __syncthreads();
-            if (kc < 3) tile_fetch<T>(wreg, p.w, 256, n0, p.N, (kc + 1) * BK, tid, 256);
-            else if (nb + 1 < nblk) tile_fetch<T>(wreg, p.w, 256, n0 + BN, p.N, 0, tid, 256);
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    mma<T>(acc[nt], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half), af[4 * kc + c]);
+            for (int j = 0; j < 8; ++j)
+                af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
+            if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
         }
-        epilogue<T, RELU>(acc, p, sOut, blockIdx.x * BM, n0, tid);
+        if (p.stats && half == 0 && blockIdx.y == 0) {
+            p.stats[2 * (size_t)row] = mean;
+            p.stats[2 * (size_t)row + 1] = rs;
+        }
+    }
+    panel_commit<T>(sP, wreg, tid);
+    f32x4 binit[P::G][4];
+    bias_fetch<T>(binit, p.bias, p.w, j0 * P::NP, half);
+    panel_fetch<T>(wreg, p.w, min(j0 + 1, j1 - 1) * P::NP, p.N, tid);
+    __syncthreads();                                             // panel j0 visible; sG dead (sS may be written)
+    const unsigned thr = dropout_threshold(p.drop_p);
+    const float keep_scale = 1.0f / (1.0f - p.drop_p);
+    const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
+    const int tok = lane / P::LPT, ch = lane % P::LPT;           // store phase: this lane's token (+ 64/LPT per pass), 16 B chunk
+    for (int j = j0; j < j1; ++j) {
+        const int n0 = j * P::NP;
+        T* cur = sP + ((j - j0) & 1) * P::NP * P::LDP;
+        T* nxt = sP + (((j - j0) & 1) ^ 1) * P::NP * P::LDP;
+        f32x16 acc[P::G];                                        // accumulators start from the bias
+#pragma unroll
+        for (int g = 0; g < P::G; ++g)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[g][t] = binit[g][t >> 2][t & 3];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int g = 0; g < P::G; ++g)
+                mma<T>(acc[g], frag_load<T>(cur + (32 * g + r) * P::LDP + 16 * c + 8 * half), af[c]);
+        panel_commit<T>(nxt, wreg, tid);                         // panel j+1 (or a harmless repeat of the last one)
+        bias_fetch<T>(binit, p.bias, p.w, min(j + 1, j1 - 1) * P::NP, half);
+        panel_fetch<T>(wreg, p.w, min(j + 2, j1 - 1) * P::NP, p.N, tid);
+#pragma unroll
+        for (int g = 0; g < P::G; ++g) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int col = n0 + 32 * g + 8 * i4 + 4 * half;
+                const unsigned keep = p.drop_p > 0.f ? dropout_keep4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[g][4 * i4 + i];
+                    if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
+                    if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
+                }
+                store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+            }
+            wave_lds_handover();
+#pragma unroll
+            for (int ps = 0; ps < P::PASSES; ++ps) {
+                const int t = tok + ps * (64 / P::LPT);
+                const u32x4_t d = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + t * P::FS) + 16 * ch);
+                T* dst = p.y + (size_t)min(m_wave + t, p.M - 1) * p.ldy + n0 + 32 * g;
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst) + 16 * ch) = d;
+            }
+            wave_lds_handover();
+        }
+        __syncthreads();                                         // nxt visible to all waves, cur free for the next commit
     }
 }
 
@@ -399,7 +510,11 @@ int tn_splits(int M, int N, int K) {
 
 template <typename T>
 int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
-    const size_t sm = (size_t)BN * LDW * sizeof(T) + 512 * sizeof(float) + stage_bytes<T>();
+    const size_t sm = Panel<T>::lds_bytes;
+    if (a.N % Panel<T>::NP != 0) {
+        mtmp_set_error("mtmp_ln_gemm: N=%d must be a multiple of %d for this dtype", a.N, Panel<T>::NP);
+        return MTMP_ERR_ARG;
+    }
     if (sm > 48 * 1024) {
         const void* f = relu ? (const void*)ln_gemm_kernel<T, true> : (const void*)ln_gemm_kernel<T, false>;
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
@@ -407,7 +522,12 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
             return MTMP_ERR_LAUNCH;
         }
     }
-    dim3 grid((a.M + BM - 1) / BM);
+    // one workgroup per 128 rows walks all panels when the row blocks alone fill the chip (2 per CU);
+    // otherwise the panels of a row block are split over gridDim.y workgroups
+    const int mtiles = (a.M + BM - 1) / BM, npanels = a.N / Panel<T>::NP;
+    int nsplit = 512 / mtiles;
+    nsplit = nsplit < 1 ? 1 : (nsplit > npanels ? npanels : nsplit);
+    dim3 grid(mtiles, nsplit);
     if (relu) hipLaunchKernelGGL((ln_gemm_kernel<T, true>), grid, dim3(256), sm, st, a);
     else      hipLaunchKernelGGL((ln_gemm_kernel<T, false>), grid, dim3(256), sm, st, a);
     MTMP_CHECK_LAUNCH("mtmp_ln_gemm");

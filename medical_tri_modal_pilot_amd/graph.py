@@ -40,6 +40,9 @@ class GraphedTrainStep:
         self.disabled = False
         self.seed_word = torch.full((1,), torch.initial_seed() & 0x7FFFFFFF, dtype=torch.int64, device=device)
         ops.set_seed_word(self.seed_word)
+        # Warm-up steps and the capture run on ONE dedicated stream: autograd's AccumulateGrad nodes remember the
+        # stream they were created on, and a node left on the (non-capturing) default stream breaks the capture.
+        self.stream = torch.cuda.Stream(device=device)
         self.pool = None
         self.captures = 0
         self.replays = 0
@@ -59,13 +62,24 @@ class GraphedTrainStep:
             torch._C._increment_version(params)      # compute-dtype weight casts must be re-done INSIDE the graph
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(g, pool=self.pool):
+        with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
             self.seed_word.add_(_GOLDEN)
             loss = fn(static)
         if self.pool is None:
             self.pool = g.pool()
         ent.update(graph=g, static=static, loss=loss)
         self.captures += 1
+
+    def _eager_on_side_stream(self, inputs, fn):
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self.seed_word.add_(_GOLDEN)
+            loss = fn(inputs)
+        cur.wait_stream(self.stream)
+        for v in inputs.values():
+            v.record_stream(self.stream)
+        return loss
 
     def run(self, inputs: Dict[str, torch.Tensor], fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
             params=None) -> torch.Tensor:
@@ -83,8 +97,7 @@ class GraphedTrainStep:
         if "graph" not in ent:
             if ent["seen"] < self.warmup:
                 ent["seen"] += 1
-                self.seed_word.add_(_GOLDEN)
-                return fn(inputs)
+                return self._eager_on_side_stream(inputs, fn)
             try:
                 self._capture(ent, inputs, fn, params)
             except Exception as e:                      # noqa: BLE001 -- any capture failure -> eager

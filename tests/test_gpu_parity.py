@@ -537,7 +537,9 @@ def test_graph_length_buckets_match_trimmed_eager(ops):
     err = max(abs(a - b) for a, b in zip(le, lg))
     REPORT["graph_bucketed_vs_trimmed[fp32].loss"] = {"rel_err": err, "tol": 1e-5}
     assert err < 1e-5
-    check("graph_bucketed_vs_trimmed[fp32].params", pg, pe, 1e-5)
+    # AdamW normalises every element's update to ~lr, so rounding-level gradient differences on noise-sized
+    # gradients (mathematically-zero ones included) move parameters by up to 2*lr per step: 5 steps at lr <= 5e-4
+    check("graph_bucketed_vs_trimmed[fp32].params", pg, pe, 5e-3)
 
 
 def test_graph_replay_draws_fresh_dropout_masks(ops):
