@@ -22,6 +22,19 @@
 // fp32 master), gamma/beta/bias always fp32.
 #include "common.cuh"
 
+// Diagnostic build only (make stamp): s_memtime stamps around the phases of the gemm_tn token loop.
+#ifdef MTMP_STAMP
+__device__ unsigned long long g_stamp_tn[8];
+#define TSTAMP(var)                                                                                  \
+    {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    }
+#else
+#define TSTAMP(var)
+#endif
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, LDW = BK + 8;
@@ -44,9 +57,11 @@ template <typename T> struct GemmArgs {
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread).  The loads are
 // unconditional from a CLAMPED (always valid) address and carry no use until tile_commit, so they
-// stay in flight under the MFMAs of the current tile; rows >= limit / columns >= kmax (K tail of a
-// 64-wide chunk) are zeroed by a mask at commit time (a `cond ? load : 0` at the fetch site makes
-// hipcc branch around -- and wait for -- every single load).
+// stay in flight under the MFMAs of the current tile; columns >= kmax (K tail of a 64-wide chunk) are
+// zeroed by a mask at commit time (a `cond ? load : 0` at the fetch site makes hipcc branch around --
+// and wait for -- every single load).  Rows >= limit REPLICATE row limit-1: a replicated token row
+// recomputes, and rewrites, exactly the output of row M-1, so the epilogue needs no row predicates;
+// replicated weight rows produce columns >= N, which are never stored.
 template <typename T> struct TileRegs { Frag<T> f[4]; unsigned ok; };
 
 template <typename T>
@@ -58,7 +73,7 @@ MTMP_DEV void tile_fetch(TileRegs<T>& t, const T* src, int ld, int row0, int lim
     for (int ps = 0; ps < 4; ++ps) {
         const int row = row0 + (tid >> 3) + 32 * ps;
         t.f[ps] = frag_load<T>(src + (size_t)min(row, limit - 1) * ld + kcc);
-        t.ok |= (row < limit && kc < kmax) ? (1u << ps) : 0u;
+        t.ok |= (kc < kmax) ? (1u << ps) : 0u;
     }
 }
 template <typename T> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, int tid) {
@@ -81,10 +96,24 @@ template <typename T> constexpr size_t stage_bytes() { return (size_t)BM * LDO *
 template <typename T, bool RELU>
 MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
-    const int row = m0 + 32 * wave + r;
+    const int row = min(m0 + 32 * wave + r, p.M - 1);
     const unsigned thr = dropout_threshold(p.drop_p);
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
     const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
+    // phase-2 operands first: eight independent 16-byte loads per thread stay in flight under phase 1
+    // (loading them one by one inside the store loop cost one full memory latency per pass)
+    const int c8 = (tid & 15) * 8, gcol = n0 + c8, gcolc = min(gcol, p.N - 8);
+    Frag<T> gv[8], rv[8];
+    if (p.gate) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+            gv[ps] = frag_load<T>(p.gate + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.N + gcolc);
+    }
+    if (p.res) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+            rv[ps] = frag_load<T>(p.res + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.ldr + gcolc);
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         if (n0 + 32 * nt >= p.N) continue;
@@ -106,21 +135,18 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
         }
     }
     __syncthreads();
-    const int c8 = (tid & 15) * 8, gcol = n0 + c8;
     if (gcol < p.N) {
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
-            const int rl = (tid >> 4) + 16 * ps, grow = m0 + rl;
-            if (grow >= p.M) break;
+            const int rl = (tid >> 4) + 16 * ps, grow = min(m0 + rl, p.M - 1);
             Frag<T> o = frag_load<T>(sOut + rl * LDO + c8);
             if (p.gate || p.row_scale || p.res) {
                 float v[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) v[i] = to_f32(o.v[i]);
                 if (p.gate) {
-                    const Frag<T> gv = frag_load<T>(p.gate + (size_t)grow * p.N + gcol);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = to_f32(gv.v[i]) > 0.f ? v[i] * p.gate_scale : 0.f;
+                    for (int i = 0; i < 8; ++i) v[i] = to_f32(gv[ps].v[i]) > 0.f ? v[i] * p.gate_scale : 0.f;
                 }
                 if (p.row_scale) {
                     const float rsv = p.row_scale[grow / p.rows_per_scale];
@@ -128,9 +154,8 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
                     for (int i = 0; i < 8; ++i) v[i] *= rsv;
                 }
                 if (p.res) {
-                    const Frag<T> rv = frag_load<T>(p.res + (size_t)grow * p.ldr + gcol);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = round_as<T>(v[i]) + to_f32(rv.v[i]);
+                    for (int i = 0; i < 8; ++i) v[i] = round_as<T>(v[i]) + to_f32(rv[ps].v[i]);
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o.v[i] = from_f32<T>(v[i]);
@@ -424,7 +449,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
     T* sX = sY + 128 * LDX;                   // [128 k][LDX tokens]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int tn = p.N / 128, tk = p.K / 128;
-    int w = blockIdx.x;
+    int w = xcd_remap(blockIdx.x, gridDim.x);         // the tn*tk tiles of one M split share an XCD: re-reads of its dY / X rows hit that L2
     const int split = w / (tn * tk);
     w -= split * tn * tk;
     const int n0 = (w / tk) * 128, k0 = (w % tk) * 128;
@@ -435,8 +460,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
     TnRegs<T> yreg, xreg;
     tn_fetch<T>(yreg, p.dy, p.ldy, m_lo, m_end, n0, tid);
     tn_fetch<T>(xreg, p.x, p.ldx, m_lo, m_end, k0, tid);
+#ifdef MTMP_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa = 0, sb = 0, sc = 0, sd = 0, nst = 0;
+#endif
     for (int m0 = m_lo; m0 < m_end; m0 += TK) {
+        TSTAMP(ts0)
         __syncthreads();
+        TSTAMP(ts1)
         tn_mask<T>(yreg);
         tn_mask<T>(xreg);
         tn_commit<T>(sY, yreg.f, tid);
@@ -446,7 +476,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
             for (int e = 0; e < 8; ++e)
                 csum[e] += to_f32(yreg.f[0].v[e]) + to_f32(yreg.f[1].v[e]) + to_f32(yreg.f[2].v[e]) + to_f32(yreg.f[3].v[e]);
         }
+        TSTAMP(ts2)
         __syncthreads();
+        TSTAMP(ts3)
         if (m0 + TK < m_end) {
             tn_fetch<T>(yreg, p.dy, p.ldy, m0 + TK, m_end, n0, tid);
             tn_fetch<T>(xreg, p.x, p.ldx, m0 + TK, m_end, k0, tid);
@@ -460,7 +492,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
             mma<T>(acc[0][0], a0, b0); mma<T>(acc[0][1], a0, b1);
             mma<T>(acc[1][0], a1, b0); mma<T>(acc[1][1], a1, b1);
         }
+        TSTAMP(ts4)
+#ifdef MTMP_STAMP
+        sa += ts1 - ts0; sb += ts2 - ts1; sc += ts3 - ts2; sd += ts4 - ts3; ++nst;
+#endif
     }
+#ifdef MTMP_STAMP
+    if (lane == 0) {
+        atomicAdd(&g_stamp_tn[0], sa); atomicAdd(&g_stamp_tn[1], sb); atomicAdd(&g_stamp_tn[2], sc);
+        atomicAdd(&g_stamp_tn[3], sd); atomicAdd(&g_stamp_tn[4], nst);
+    }
+#endif
     // partial slab row: [N*K] products then [N] column sums
     float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
 #pragma unroll
@@ -679,3 +721,12 @@ extern "C" int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long l
     MTMP_CHECK_LAUNCH("mtmp_dropout_bwd");
     return MTMP_OK;
 }
+
+#ifdef MTMP_STAMP
+// diagnostic build: read and clear {barrier 1, load wait + transpose + LDS write, barrier 2, fetch issue + MFMA, steps}
+extern "C" int mtmp_debug_stamps_tn(unsigned long long* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_tn), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_tn), z, sizeof(z)) != hipSuccess;
+}
+#endif
