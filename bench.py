@@ -71,8 +71,8 @@ def cpu_baseline(sample_b: int = 8, timed: int = 2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -128,6 +128,20 @@ int mtmp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
                     long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float grad_scale, void* stream);
 
+/* Bottleneck exchange between the modality streams (mbt_encoder.py:764-779), in place on the stream
+ * buffers z_m [B, n_m, 256] whose rows 0..3 are the four bottleneck tokens (n_m = 4 + 1 + tokens):
+ * rows 0..3 of all three become the per-sample weighted mean over the present modalities
+ * (missing[b] 0: vslt+img+txt, 1: vslt+img, 2: vslt+txt, 3: vslt) -- with resbottle != 0 averaged with
+ * prev [B,4,256] fp32 (mbt_encoder.py:741-742,778-779).  keep (may be NULL) receives the fp32 result.
+ * _bwd transforms the gradient buffers dz_m the same way in place: rows 0..3 hold the consumers'
+ * gradients on entry and each stream's own bottleneck-output gradient on exit; d_prev_in (may be NULL) /
+ * d_prev_out carry the residual path between consecutive exchanges. */
+int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, void* z_t, int B, int n_v, int n_i, int n_t,
+                                 const long long* missing, int resbottle, const float* prev, float* keep, void* stream);
+int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, int B, int n_v, int n_i, int n_t,
+                                 const long long* missing, int resbottle, const float* d_prev_in, float* d_prev_out,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

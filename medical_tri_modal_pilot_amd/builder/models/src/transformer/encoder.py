@@ -63,6 +63,20 @@ class TransformerEncoderLayer(nn.Module):
               a.query_proj.linear.bias, a.key_proj.linear.bias, a.value_proj.linear.bias, f.w_1.weight, f.w_2.weight]
         key = (dtype,) + tuple((p._version, p.data_ptr()) for p in ps)
         if key != self._fused_key:
+            # parameters living in an optim.FlatParams buffer: views of the fp32 master / the bf16 shadow that the
+            # AdamW kernel keeps current -- no cast kernels in the step (only W2^T is materialised)
+            flat = getattr(ps[0], "_mtmp_flat", None)
+            if flat is not None and all(getattr(q, "_mtmp_flat", None) is flat for q in ps):
+                ix = [flat.index_of[id(q)] for q in ps]
+                wqkv, bqkv = flat.span(ix[0:3], dtype), flat.span(ix[3:6], torch.float32)
+                w1, w2 = flat.span(ix[6:7], dtype), flat.span(ix[7:8], dtype)
+                if all(t is not None for t in (wqkv, bqkv, w1, w2)):
+                    with torch.no_grad():
+                        w2 = w2.view(ps[7].shape[0], -1)
+                        self._fused = (wqkv.view(3 * ps[0].shape[0], -1), bqkv, w1.view(ps[6].shape[0], -1), w2,
+                                       w2.t().contiguous())
+                    self._fused_key = key
+                    return self._fused
             with torch.no_grad():
                 w2 = ps[7].reshape(ps[7].shape[0], -1).to(dtype).contiguous()
                 self._fused = (torch.cat([ps[0], ps[1], ps[2]], 0).to(dtype).contiguous(),

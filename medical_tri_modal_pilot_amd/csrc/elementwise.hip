@@ -294,3 +294,108 @@ extern "C" int mtmp_adamw_step(float* param, const float* grad, float* exp_avg, 
     MTMP_CHECK_LAUNCH("mtmp_adamw_step");
     return MTMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Bottleneck exchange between the three modality streams (K9, mbt_encoder.py:764-779).  Every stream
+// buffer is [B, 4 + N_m, 256] with the four bottleneck tokens in rows 0..3; the exchanged tokens are
+// the per-sample weighted mean over the modalities that are present (missing_num 0: all three, 1: vslt +
+// image, 2: vslt + text, 3: vslt only; weights below), optionally averaged with the previous layer's
+// (--residual-bottlenecks 1), and are written back into rows 0..3 of all three buffers in place.
+// One thread per (sample, token, feature); products and sums in the order of the torch expression
+// (bo * w).sum(1), un-fused, so fp32 results are bit-identical to it.
+namespace {
+
+__device__ const float kExchangeW[4][3] = {{1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f}, {0.5f, 0.5f, 0.0f}, {0.5f, 0.0f, 0.5f}, {1.0f, 0.0f, 0.0f}};
+
+template <typename T> struct ExchangeArgs {
+    T* z[3];
+    long long bstride[3];     // elements between consecutive samples of stream m ((4 + N_m) * 256)
+    const long long* missing; // [B] pattern ids 0..3
+    const float* prev;        // [B,4,256] fp32 previous exchange result (resbottle) or null
+    float* keep;              // [B,4,256] fp32 copy of the new tokens (next layer's prev / backward) or null
+    const float* d_prev_in;   // backward: gradient flowing into this exchange's output through the next residual, or null
+    float* d_prev_out;        // backward: gradient for the previous exchange's output (resbottle), or null
+    int resbottle;
+};
+
+template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel(ExchangeArgs<T> p) {
+    const int b = blockIdx.x >> 2, r = blockIdx.x & 3, f = threadIdx.x;
+    const long long pat = p.missing[b];
+    const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
+    float v = __fmul_rn(to_f32(p.z[0][b * p.bstride[0] + o]), kExchangeW[pat][0]);
+    v = __fadd_rn(v, __fmul_rn(to_f32(p.z[1][b * p.bstride[1] + o]), kExchangeW[pat][1]));
+    v = __fadd_rn(v, __fmul_rn(to_f32(p.z[2][b * p.bstride[2] + o]), kExchangeW[pat][2]));
+    if (p.resbottle) v = __fmul_rn(__fadd_rn(v, p.prev[ko]), 0.5f);
+    if (p.keep) p.keep[ko] = v;
+    const T t = from_f32<T>(v);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) p.z[m][b * p.bstride[m] + o] = t;
+}
+
+// z[m] hold dL/d(input of the next layer): rows 0..3 are the gradients w.r.t. the exchanged tokens as seen by
+// each consumer.  d_new = sum_m rows (+ d_prev_in); resbottle: half goes to the previous exchange (d_prev_out);
+// rows 0..3 of z[m] become d_new * w[m] = gradient w.r.t. stream m's own bottleneck outputs.
+template <typename T> __global__ __launch_bounds__(256) void exchange_bwd_kernel(ExchangeArgs<T> p) {
+    const int b = blockIdx.x >> 2, r = blockIdx.x & 3, f = threadIdx.x;
+    const long long pat = p.missing[b];
+    const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
+    float d = to_f32(p.z[0][b * p.bstride[0] + o]);
+    d = __fadd_rn(d, to_f32(p.z[1][b * p.bstride[1] + o]));
+    d = __fadd_rn(d, to_f32(p.z[2][b * p.bstride[2] + o]));
+    if (p.d_prev_in) d = __fadd_rn(d, p.d_prev_in[ko]);
+    if (p.resbottle) {
+        d = __fmul_rn(d, 0.5f);
+        p.d_prev_out[ko] = d;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) p.z[m][b * p.bstride[m] + o] = from_f32<T>(__fmul_rn(d, kExchangeW[pat][m]));
+}
+
+}  // namespace
+
+// In-place bottleneck exchange over the three stream buffers z_m [B, n_m, 256] (n_m = 4 + tokens, rows 0..3 =
+// bottleneck tokens).  missing: int64[B] in 0..3.  resbottle != 0: new = (mean + prev) / 2 with prev [B,4,256]
+// fp32.  keep (optional) receives the fp32 result.  Replaces mbt_encoder.py:764-779.
+extern "C" int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, void* z_t, int B, int n_v, int n_i, int n_t,
+                                            const long long* missing, int resbottle, const float* prev, float* keep,
+                                            void* stream) {
+    MTMP_CHECK_ARG(z_v && z_i && z_t && missing && B > 0 && n_v >= 4 && n_i >= 4 && n_t >= 4 && (!resbottle || prev),
+                   "mtmp_bottleneck_exchange_fwd: bad argument (B=%d rows %d/%d/%d)", B, n_v, n_i, n_t);
+    if (dtype == 0) {
+        ExchangeArgs<float> a{{(float*)z_v, (float*)z_i, (float*)z_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
+                              missing, prev, keep, nullptr, nullptr, resbottle};
+        hipLaunchKernelGGL(exchange_fwd_kernel<float>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == 1) {
+        ExchangeArgs<bf16> a{{(bf16*)z_v, (bf16*)z_i, (bf16*)z_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
+                             missing, prev, keep, nullptr, nullptr, resbottle};
+        hipLaunchKernelGGL(exchange_fwd_kernel<bf16>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        mtmp_set_error("mtmp_bottleneck_exchange_fwd: unknown dtype %d", dtype);
+        return MTMP_ERR_ARG;
+    }
+    MTMP_CHECK_LAUNCH("mtmp_bottleneck_exchange_fwd");
+    return MTMP_OK;
+}
+
+// Backward of the exchange, in place on the gradient buffers dz_m [B, n_m, 256] (rows 0..3): see
+// exchange_bwd_kernel.  d_prev_in / d_prev_out: [B,4,256] fp32, used with resbottle (d_prev_in may be null).
+extern "C" int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, int B, int n_v, int n_i, int n_t,
+                                            const long long* missing, int resbottle, const float* d_prev_in,
+                                            float* d_prev_out, void* stream) {
+    MTMP_CHECK_ARG(dz_v && dz_i && dz_t && missing && B > 0 && n_v >= 4 && n_i >= 4 && n_t >= 4 && (!resbottle || d_prev_out),
+                   "mtmp_bottleneck_exchange_bwd: bad argument (B=%d rows %d/%d/%d)", B, n_v, n_i, n_t);
+    if (dtype == 0) {
+        ExchangeArgs<float> a{{(float*)dz_v, (float*)dz_i, (float*)dz_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
+                              missing, nullptr, nullptr, d_prev_in, d_prev_out, resbottle};
+        hipLaunchKernelGGL(exchange_bwd_kernel<float>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == 1) {
+        ExchangeArgs<bf16> a{{(bf16*)dz_v, (bf16*)dz_i, (bf16*)dz_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
+                             missing, nullptr, nullptr, d_prev_in, d_prev_out, resbottle};
+        hipLaunchKernelGGL(exchange_bwd_kernel<bf16>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        mtmp_set_error("mtmp_bottleneck_exchange_bwd: unknown dtype %d", dtype);
+        return MTMP_ERR_ARG;
+    }
+    MTMP_CHECK_LAUNCH("mtmp_bottleneck_exchange_bwd");
+    return MTMP_OK;
+}

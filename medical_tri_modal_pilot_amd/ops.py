@@ -196,6 +196,21 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, 
          float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
 
 
+def bottleneck_exchange_fwd(z, missing, resbottle=False, prev=None, keep=None):
+    """In place on z = [z_v, z_i, z_t] ([B, n_m, 256] contiguous): rows 0..3 <- exchanged bottleneck tokens."""
+    _gpu(*z)
+    B = z[0].shape[0]
+    call("mtmp_bottleneck_exchange_fwd", _dt(z[0]), _p(z[0]), _p(z[1]), _p(z[2]), B, z[0].shape[1], z[1].shape[1],
+         z[2].shape[1], _p(missing), int(bool(resbottle)), _p(prev), _p(keep), _stream())
+
+
+def bottleneck_exchange_bwd(dz, missing, resbottle=False, d_prev_in=None, d_prev_out=None):
+    _gpu(*dz)
+    B = dz[0].shape[0]
+    call("mtmp_bottleneck_exchange_bwd", _dt(dz[0]), _p(dz[0]), _p(dz[1]), _p(dz[2]), B, dz[0].shape[1], dz[1].shape[1],
+         dz[2].shape[1], _p(missing), int(bool(resbottle)), _p(d_prev_in), _p(d_prev_out), _stream())
+
+
 def _mm_f32(a, b):
     """Plain library GEMM with an fp32 result (weight gradients are kept in fp32)."""
     if a.dtype == torch.float32:
@@ -391,11 +406,11 @@ class FusionStackFn(torch.autograd.Function):
             buf[:, NB:] = x
             buf[:, :NB] = bott.to(dt)
             z.append(buf)
-        wsel = _exchange_w(dev)[cfg["missing"]]                     # [B,3] exchange weights per sample
+        wsel = _exchange_w(dev)
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
         saved, active = [], []
-        prev_bott = bott.expand(B, -1, -1).float()
+        prev_bott = bott.expand(B, -1, -1).float().contiguous() if cfg["resbottle"] else None
         for li in range(L):
             last = cfg["vsltonly"] == 1 and li == L - 1
             ms = [0] if last else [0, 1, 2]
@@ -423,15 +438,10 @@ class FusionStackFn(torch.autograd.Function):
             if last:
                 z = outs
                 break
-            # bottleneck exchange (:764-779) on the [B,4,256] prefixes, written back in place
-            bo = torch.stack([outs[m][:, :NB].float() for m in range(3)], 1)        # [B,3,4,256]
-            newb = (bo * wsel[:, :, None, None]).sum(1)
-            if cfg["resbottle"]:
-                newb = (newb + prev_bott) * 0.5
-            prev_bott = newb
-            nb_dt = newb.to(dt)
-            for m in range(3):
-                outs[m][:, :NB] = nb_dt
+            # bottleneck exchange (:764-779) on the [B,4,256] prefixes, written back in place (one kernel)
+            keep = torch.empty(B, NB, D_MODEL, dtype=torch.float32, device=dev) if cfg["resbottle"] else None
+            bottleneck_exchange_fwd(outs, cfg["missing"], cfg["resbottle"], prev_bott if cfg["resbottle"] else None, keep)
+            prev_bott = keep
             z = outs
         ctx.saved, ctx.active, ctx.cfg, ctx.wsel = saved, active, cfg, wsel
         ctx.shapes = (B, Ns, [p.shape for p in params])
@@ -462,16 +472,11 @@ class FusionStackFn(torch.autograd.Function):
         for li in range(n_run - 1, -1, -1):
             ms = active[li]
             if not (cfg["vsltonly"] == 1 and li == L - 1):
-                # this layer's outputs went through an exchange before feeding layer li+1:
-                # d_newb = sum over consumers' bottleneck rows; distribute by the exchange weights
-                d_newb = sum(dz[m][:, :NB].float() for m in range(3) if dz[m] is not None)
-                if d_prev_bott is not None:
-                    d_newb = d_newb + d_prev_bott
-                if cfg["resbottle"]:
-                    d_prev_bott = d_newb * 0.5
-                    d_newb = d_newb * 0.5
-                for m in range(3):
-                    dz[m][:, :NB] = (d_newb * wsel[:, m, None, None]).to(dt)
+                # this layer's outputs went through an exchange before feeding layer li+1: rows 0..3 of the three
+                # gradient buffers are summed and redistributed by the exchange weights, in place (one kernel)
+                d_out_prev = torch.empty(B, NB, D_MODEL, dtype=torch.float32, device=dev) if cfg["resbottle"] else None
+                bottleneck_exchange_bwd(dz, cfg["missing"], cfg["resbottle"], d_prev_bott, d_out_prev)
+                d_prev_bott = d_out_prev
             nxt = [None, None, None]
             if streams is not None and len(ms) > 1:
                 ev = torch.cuda.Event()

@@ -77,6 +77,49 @@ class FlatParams:
     def slice_of(self, i: int) -> Tuple[int, int]:
         return self.offsets[i], self.offsets[i] + self.params[i].numel()
 
+    # ---- bf16 shadow copy, kept current by the AdamW kernel itself -------------------------------
+    def enable_shadow(self):
+        """Allocate the bf16 copy of the whole buffer that the MFMA kernels read.  FusedAdamW refreshes it inside
+        the optimizer kernel, so a training step launches no weight-cast kernels; span() hands out views."""
+        self.shadow = self.data.to(torch.bfloat16)
+        self.shadow_versions = [p._version for p in self.params]
+
+    def span(self, idxs, dtype):
+        """A 1-D view over the adjacent parameters ``idxs`` in ``dtype`` (fp32: the master buffer; bf16: the
+        shadow), or None if they are not adjacent / the shadow is missing or stale for one of them (parameter
+        modified by anything but FusedAdamW, e.g. load_state_dict) -- the caller then casts the usual way."""
+        lo = self.offsets[idxs[0]]
+        end = lo
+        for i in idxs:
+            if self.offsets[i] != end:
+                return None
+            end += self.params[i].numel()
+            if end % ALIGN and i != idxs[-1]:
+                return None
+        if dtype == torch.float32:
+            for i in idxs:
+                if self.params[i].data_ptr() != self.data.data_ptr() + 4 * self.offsets[i]:
+                    return None
+            return self.data[lo:end]
+        shadow = getattr(self, "shadow", None)
+        if dtype != torch.bfloat16 or shadow is None:
+            return None
+        for i in idxs:
+            if self.params[i]._version != self.shadow_versions[i]:
+                return None
+        return shadow[lo:end]
+
+
+def compute_weight(p: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """``p`` in the compute dtype: a view of the flat master / shadow buffer when there is a current one,
+    otherwise a cast."""
+    flat = getattr(p, "_mtmp_flat", None)
+    if flat is not None:
+        v = flat.span([flat.index_of[id(p)]], dtype)
+        if v is not None:
+            return v.view(p.shape)
+    return p.detach().to(dtype)
+
 
 class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the sqrt)
@@ -91,6 +134,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(self.flat.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        self.flat.enable_shadow()
         self.step_count = 0
         self.reducer = None            # ddp.GradReducer, attached by the training script
         self.grad_scale = 1.0
@@ -106,9 +150,14 @@ class FusedAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         self.flat.attach_grads()
         self.step_count += 1
-        ops.adamw_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, None, g["lr"], g["betas"][0],
-                       g["betas"][1], g["eps"], g["weight_decay"], self.step_count, self.grad_scale)
-        # the kernel wrote through raw pointers: bump the version counters so that cached
-        # compute-dtype weight copies (encoder.py:_fused_weights) are rebuilt on next use
+        fresh = all(p._version == v for p, v in zip(self.flat.params, self.flat.shadow_versions))
+        ops.adamw_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.flat.shadow, g["lr"],
+                       g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count, self.grad_scale)
+        # the kernel wrote through raw pointers: bump the version counters so that cached compute-dtype weight
+        # copies are rebuilt on next use; the bf16 shadow was refreshed by the same kernel, so it stays current
+        # (unless somebody else had modified a parameter since the last refresh: then re-cast everything once)
         torch._C._increment_version(self.flat.params)
+        if not fresh:
+            self.flat.shadow.copy_(self.flat.data)
+        self.flat.shadow_versions = [p._version for p in self.flat.params]
         return None
