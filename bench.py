@@ -214,6 +214,14 @@ def main():
         k_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, len(events))
         flops = 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # HBM traffic of the same kernel from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3
+        # runs of this script -- counters cannot be read from inside it); committed under profiles/ with its method
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if a.dtype == "bf16" and os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/roofline_traffic.json ({tj.get('round')})"
         out = {
             "metric": "tri-modal training samples/s (fwd+bwd+AdamW step, per-GPU batch 64)",
             "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
@@ -226,7 +234,8 @@ def main():
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel<bf16> (vslt stream, N=1005)" if a.dtype == "bf16"
                          else "attn_fwd_kernel<float>", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "launches_timed": len(events), "avg_launch_ms": k_ms, "flops_per_launch": flops,
                          "timed_in": "eager probe steps after the graph-replay region" if graphed else "timed steps"},
         }
