@@ -467,10 +467,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
         TSTAMP(ts0)
         __syncthreads();
         TSTAMP(ts1)
+#ifndef MTMP_TN_NOCOMMIT                                  // (ablation builds: tools/ablate_tn.sh -- never shipped)
         tn_mask<T>(yreg);
         tn_mask<T>(xreg);
         tn_commit<T>(sY, yreg.f, tid);
         tn_commit<T>(sX, xreg.f, tid);
+#endif
         if (k0 == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -479,10 +481,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
         TSTAMP(ts2)
         __syncthreads();
         TSTAMP(ts3)
+#ifndef MTMP_TN_NOFETCH
         if (m0 + TK < m_end) {
             tn_fetch<T>(yreg, p.dy, p.ldy, m0 + TK, m_end, n0, tid);
             tn_fetch<T>(xreg, p.x, p.ldx, m0 + TK, m_end, k0, tid);
         }
+#endif
+#ifndef MTMP_TN_NOMMA
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const Frag<T> a0 = frag_load<T>(sY + (wn + r) * LDX + 16 * c + 8 * half);
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
             mma<T>(acc[0][0], a0, b0); mma<T>(acc[0][1], a0, b1);
             mma<T>(acc[1][0], a1, b0); mma<T>(acc[1][1], a1, b1);
         }
+#endif
         TSTAMP(ts4)
 #ifdef MTMP_STAMP
         sa += ts1 - ts0; sb += ts2 - ts1; sc += ts3 - ts2; sd += ts4 - ts3; ++nst;
@@ -524,6 +530,137 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// bf16 build of dW = dY^T X: same tiling and slab protocol as gemm_tn_kernel, but the 64-token tiles are
+// kept in LDS in their NATURAL [token][col] layout (plain 16-byte copies, no register transposes) and the
+// MFMA fragments -- 8 consecutive TOKENS of one column -- come from the transposing LDS read
+// ds_read_b64_tr_b16.  Two LDS stages (one barrier per 64 tokens) and two register stages: the global loads
+// of step s+3 are issued while step s is multiplied, so a step's loads have two full steps to arrive.
+// (Ablations of the first version, profiles/: the in-register transposes + masks + two barriers per step cost
+//  as much as the memory traffic, and loads were only in flight during the short MFMA phase.)
+constexpr int TT = 64;            // tokens per stage
+constexpr int LDG = 128 + 32;     // LDS row stride, elements: 320 B = 16 banks mod 64 -> conflict-free ds_read_b64_tr_b16
+struct TrRegs { u32x4_t q[4]; unsigned ok; };
+
+// 64 tokens x 128 cols -> 4 x 16 B per thread: thread (rg = tid >> 4, ch = tid & 15) holds rows 16i + rg, cols 8ch..8ch+7
+MTMP_DEV void tr_fetch(TrRegs& t, const bf16* src, int ld, int m0, int m_end, int c0, int tid) {
+    const int rg = tid >> 4, ch = tid & 15;
+    t.ok = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * i + rg;
+        t.q[i] = *reinterpret_cast<const u32x4_t*>(src + (size_t)min(m, m_end - 1) * ld + c0 + 8 * ch);
+        t.ok |= (m < m_end) ? (1u << i) : 0u;
+    }
+}
+MTMP_DEV void tr_commit(bf16* dst, TrRegs& t, int tid) {
+    const int rg = tid >> 4, ch = tid & 15;
+    if (!wave_all(t.ok == 15u)) {              // token tail of the split: rows past m_end contribute zero
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned m = (t.ok >> i) & 1u ? 0xFFFFFFFFu : 0u;
+            t.q[i] &= u32x4_t{m, m, m, m};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4_t*>(dst + (16 * i + rg) * LDG + 8 * ch) = t.q[i];
+}
+// fragment of the transposed role on a [token][LDG] image: element j = img[row0 + 8*half + j][col0 + r]
+MTMP_DEV Frag<bf16> frag_tr_g(const bf16* img, int row0, int col0, int lane) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int G = lane >> 4, i = lane & 15;
+    const bf16* a = img + (row0 + 8 * (G >> 1) + (i >> 2)) * LDG + col0 + 16 * (G & 1) + 4 * (i & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * LDG));
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    return f;
+}
+MTMP_DEV void tr_csum(float (&csum)[8], const TrRegs& y) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, y.q[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += (float)v[e];
+    }
+}
+MTMP_DEV void tr_mma(f32x16 (&acc)[2][2], const bf16* sY, const bf16* sX, int wn, int wk, int lane) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const Frag<bf16> a0 = frag_tr_g(sY, 16 * c, wn, lane), a1 = frag_tr_g(sY, 16 * c, wn + 32, lane);
+        const Frag<bf16> b0 = frag_tr_g(sX, 16 * c, wk, lane), b1 = frag_tr_g(sX, 16 * c, wk + 32, lane);
+        mma<bf16>(acc[0][0], a0, b0); mma<bf16>(acc[0][1], a0, b1);
+        mma<bf16>(acc[1][0], a1, b0); mma<bf16>(acc[1][1], a1, b1);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs<bf16> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* sm = reinterpret_cast<bf16*>(smem_raw);          // [2 stages][dY | X][TT][LDG]
+    constexpr int MAT = TT * LDG, STAGE = 2 * MAT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int tn = p.N / 128, tk = p.K / 128;
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = w / (tn * tk);
+    w -= split * tn * tk;
+    const int n0 = (w / tk) * 128, k0 = (w % tk) * 128;
+    const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int nsteps = m_end > m_lo ? (m_end - m_lo + TT - 1) / TT : 0;
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool bias_blk = (k0 == 0);
+    TrRegs y0, x0, y1, x1;
+    // steps past the end fetch clamped rows with ok = 0: their tiles are all zero
+    tr_fetch(y0, p.dy, p.ldy, m_lo, m_end, n0, tid);           tr_fetch(x0, p.x, p.ldx, m_lo, m_end, k0, tid);
+    tr_fetch(y1, p.dy, p.ldy, m_lo + TT, m_end, n0, tid);      tr_fetch(x1, p.x, p.ldx, m_lo + TT, m_end, k0, tid);
+    if (nsteps > 0) {
+        tr_commit(sm, y0, tid); tr_commit(sm + MAT, x0, tid);
+        if (bias_blk) tr_csum(csum, y0);
+        tr_fetch(y0, p.dy, p.ldy, m_lo + 2 * TT, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, m_lo + 2 * TT, m_end, k0, tid);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+        // even step: multiply stage 0, stage 1 <- registers y1/x1 (step s+1), refill them with step s+3
+        tr_mma(acc, sm, sm + MAT, wn, wk, lane);
+        tr_commit(sm + STAGE, y1, tid); tr_commit(sm + STAGE + MAT, x1, tid);
+        if (bias_blk) tr_csum(csum, y1);
+        tr_fetch(y1, p.dy, p.ldy, m_lo + (s + 3) * TT, m_end, n0, tid); tr_fetch(x1, p.x, p.ldx, m_lo + (s + 3) * TT, m_end, k0, tid);
+        __syncthreads();
+        if (s + 1 >= nsteps) break;
+        // odd step: multiply stage 1, stage 0 <- y0/x0 (step s+2), refill with step s+4
+        tr_mma(acc, sm + STAGE, sm + STAGE + MAT, wn, wk, lane);
+        tr_commit(sm, y0, tid); tr_commit(sm + MAT, x0, tid);
+        if (bias_blk) tr_csum(csum, y0);
+        tr_fetch(y0, p.dy, p.ldy, m_lo + (s + 4) * TT, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, m_lo + (s + 4) * TT, m_end, k0, tid);
+        __syncthreads();
+    }
+    float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + wk + 32 * j + r] = acc[i][j][t];
+    if (bias_blk) {
+        // thread (rg, ch) holds partial sums of columns 8ch..8ch+7 over its rows: 16 row groups -> LDS -> one sum
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem_raw);   // [16][128]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + 8 * (tid & 15) + e] = csum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += red[g * 128 + tid];
+            out[(size_t)p.N * p.K + n0 + tid] = s;
+        }
+    }
+}
+
 // out[c] = sum_s slab[s][c]; a block owns 64 columns, 4 row-lanes reduce through LDS
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, int splits, size_t cols, float* dw, float* db,
                                                         size_t nk) {
@@ -542,9 +679,9 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, int s
     }
 }
 
-int tn_splits(int M, int N, int K) {
+int tn_splits(int M, int N, int K, int target_wgs) {
     const int tiles = (N / 128) * (K / 128);
-    int s = 640 / tiles;                                   // ~2.5 workgroups per CU in total
+    int s = target_wgs / tiles;
     const int max_s = (M + 4 * TK - 1) / (4 * TK);         // at least 4 token steps per split
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
@@ -595,17 +732,19 @@ int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
                    hipStream_t st) {
-    const int splits = tn_splits(M, N, K);
+    constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernel, 2 workgroups per CU
+    const int splits = tn_splits(M, N, K, TR ? 512 : 640);
     int rps = (M + splits - 1) / splits;
     rps = (rps + TK - 1) / TK * TK;
     TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
-    const size_t sm = (size_t)256 * LDX * sizeof(T);
-    if (sm > 48 * 1024 &&
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+    const size_t sm = TR ? (size_t)4 * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
+    const void* fn = TR ? (const void*)gemm_tn_tr_kernel : (const void*)gemm_tn_kernel<T>;
+    if (sm > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
         mtmp_set_error("mtmp_gemm_tn: cannot raise dynamic LDS to %zu", sm);
         return MTMP_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(splits * (N / 128) * (K / 128)), dim3(256), sm, st, a);
+    if constexpr (TR) hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(splits * (N / 128) * (K / 128)), dim3(256), sm, st, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(splits * (N / 128) * (K / 128)), dim3(256), sm, st, a);
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn");
     const size_t nk = (size_t)N * K, cols = nk + N;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, ws, splits, cols, dw, db, nk);
@@ -670,7 +809,7 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
 }
 
 extern "C" long long mtmp_gemm_tn_ws_floats(int M, int N, int K) {
-    return (long long)tn_splits(M, N, K) * ((long long)N * K + N);
+    return (long long)tn_splits(M, N, K, 640) * ((long long)N * K + N);   // upper bound over both dtypes' split counts
 }
 
 // dW[N,K] (fp32) = dY[M,N]^T X[M,K];  db[N] (fp32, optional) = column sums of dY.  N, K multiples of
