@@ -75,28 +75,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* z, int ldz, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const f32x4 gm = ld4f(gamma + 4 * lane);
     float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float mu = stats[2 * (size_t)row], rs = stats[2 * (size_t)row + 1];
-        const float sigma = 1.0f / rs - eps;
-        const f32x4 zv = load4<T>(z + (size_t)row * ldz + 4 * lane);
-        const f32x4 dv = load4<T>(dy + (size_t)row * D + 4 * lane);
-        float xh[4], g[4], sg = 0.f, sgx = 0.f;
+    // A wave owns RPW consecutive rows per trip and issues all of their loads before the first use: one row per
+    // trip left a single 512-byte load in flight per wave, i.e. one memory latency per row (58 us for 64 k rows).
+    constexpr int RPW = 4;
+    const T* res = d_res ? d_res : dy;                     // no residual: read dy again (L1 hit) and scale by 0
+    const int ldres = d_res ? ldr : D;
+    const float rscale = d_res ? 1.0f : 0.0f;
+    for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < M; row0 += gridDim.x * 4 * RPW) {
+        f32x4 zv[RPW], dv[RPW], rv[RPW];
+        float mu[RPW], rs[RPW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xh[i] = (zv[i] - mu) * rs;
-            g[i] = dv[i] * gm[i];
-            sg += g[i];
-            sgx += g[i] * xh[i];
-            acc[0][i] += dv[i] * xh[i];
-            acc[1][i] += dv[i];
+        for (int k = 0; k < RPW; ++k) {
+            const size_t row = (size_t)min(row0 + k, M - 1);
+            zv[k] = load4<T>(z + row * ldz + 4 * lane);
+            dv[k] = load4<T>(dy + row * D + 4 * lane);
+            rv[k] = load4<T>(res + row * ldres + 4 * lane);
+            mu[k] = stats[2 * row];
+            rs[k] = stats[2 * row + 1];
         }
-        wave_sum2(sg, sgx);
-        const float mg = sg * (1.0f / D);
-        const float kx = sgx / ((float)(D - 1) * sigma);
-        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-        if (d_res) rv = load4<T>(d_res + (size_t)row * ldr + 4 * lane);
-        store4<T>(dz + (size_t)row * D + 4 * lane, (g[0] - mg) * rs - xh[0] * kx + rv[0], (g[1] - mg) * rs - xh[1] * kx + rv[1],
-                  (g[2] - mg) * rs - xh[2] * kx + rv[2], (g[3] - mg) * rs - xh[3] * kx + rv[3]);
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const float live = row0 + k < M ? 1.0f : 0.0f;   // rows past M (clamped loads) add nothing and rewrite row M-1 identically
+            const float sigma = 1.0f / rs[k] - eps;
+            float xh[4], g[4], sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[i] = (zv[k][i] - mu[k]) * rs[k];
+                g[i] = dv[k][i] * gm[i];
+                sg += g[i];
+                sgx += g[i] * xh[i];
+                acc[0][i] += live * dv[k][i] * xh[i];
+                acc[1][i] += live * dv[k][i];
+            }
+            wave_sum2(sg, sgx);
+            const float mg = sg * (1.0f / D);
+            const float kx = sgx / ((float)(D - 1) * sigma);
+            store4<T>(dz + (size_t)min(row0 + k, M - 1) * D + 4 * lane,
+                      (g[0] - mg) * rs[k] - xh[0] * kx + rscale * rv[k][0], (g[1] - mg) * rs[k] - xh[1] * kx + rscale * rv[k][1],
+                      (g[2] - mg) * rs[k] - xh[2] * kx + rscale * rv[k][2], (g[3] - mg) * rs[k] - xh[3] * kx + rscale * rv[k][3]);
+        }
     }
     flush_partials<2>(acc, slab + (size_t)blockIdx.x * 2 * D, lds, lane, wave);
 }
@@ -221,7 +238,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
     }
 }
 
-int grid_for_rows(int rows) { return max(1, min((rows + 3) / 4, 512)); }
+int grid_for_rows(int rows) { return max(1, min((rows + 15) / 16, 2048)); }   // 4 waves x 4 rows per trip; <= 8 workgroups per CU
 
 }  // namespace
 

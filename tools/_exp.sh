@@ -1,6 +1,4 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-run() { tag=$1; shift; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/p_$tag -o $tag -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 3 "$@" > gpurun_out/p_$tag.log 2>&1; python tools/trace_summary.py gpurun_out/p_$tag/${tag}_kernel_trace.csv --top 40 > gpurun_out/sum_$tag.txt 2>&1; rm -rf gpurun_out/p_$tag; }
-run eager --hip-graph 0
+python -m pytest tests -m gpu -x -q -k "ln_bwd or training_step or encoder_layer" 2>&1 | tail -3
+python tools/bench_kernels.py --only stream 2>&1 | grep ln_bwd
 python bench.py --no-cpu-baseline --hip-graph 0 2>&1 | tail -1 | cut -c1-200
 python bench.py --no-cpu-baseline --hip-graph 1 2>&1 | tail -1 | cut -c1-200
