@@ -19,6 +19,7 @@ Anything that would make a replay differ from an eager step is keyed or refused:
   * a failed capture disables graphs for this object and the step runs eagerly (never silently wrong:
     capture either succeeds completely or the eager path is used).
 """
+import os
 import warnings
 from collections import OrderedDict
 from typing import Callable, Dict
@@ -28,6 +29,7 @@ import torch
 from . import ops
 
 _GOLDEN = 0x9E3779B1          # odd increment of the step word
+_SYNC_AFTER_REPLAY = os.environ.get("MTMP_GRAPH_NO_SYNC", "") == ""      # (diagnostics only: MTMP_GRAPH_NO_SYNC=1)
 
 
 class GraphedTrainStep:
@@ -67,7 +69,7 @@ class GraphedTrainStep:
             loss = fn(static)
         if self.pool is None:
             self.pool = g.pool()
-        ent.update(graph=g, static=static, loss=loss)
+        ent.update(graph=g, static=static, loss=loss, fresh=True)
         self.captures += 1
 
     def _eager_on_side_stream(self, inputs, fn):
@@ -107,9 +109,22 @@ class GraphedTrainStep:
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
                               "continuing with eager launches")
                 return fn(inputs)
-        else:
-            for k, v in inputs.items():
-                ent["static"][k].copy_(v, non_blocking=True)
-        ent["graph"].replay()
+        cur = torch.cuda.current_stream(self.device)
+        fresh = ent.pop("fresh", False)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):           # replay on the capture stream, joined to the caller's by events
+            if not fresh:
+                for k, v in inputs.items():
+                    ent["static"][k].copy_(v, non_blocking=True)
+                    v.record_stream(self.stream)
+            ent["graph"].replay()
+        cur.wait_stream(self.stream)
+        # Host-wait for the replay before anything else is enqueued.  Measured on ROCm 7.2 / torch 2.10 (bench.py with
+        # MTMP_NO_OVERLAP=1 MTMP_GRAPH_NO_SYNC=1 --warmup 10): with the replay launched on the default stream, work
+        # enqueued on that stream right after hipGraphLaunch (the AdamW kernel) could overtake the graph's tail -- the
+        # loss went NaN within ~15 steps, while a wait after the replay keeps it bit-identical to the eager steps.
+        # The trainer reads loss.item() right after the step anyway, so this wait costs nothing extra.
+        if _SYNC_AFTER_REPLAY:
+            self.stream.synchronize()
         self.replays += 1
         return ent["loss"]
