@@ -51,6 +51,7 @@ int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const 
 /* y[M,N] = act(LN(x[M,256]) w[N,256]^T + bias): custom LayerNorm (module.py:138-144: unbiased
  * std, eps added to std) fused into the Q/K/V projections (attention.py:60-62,68-70; w = [Wq;Wk;Wv])
  * or the first FFN conv + ReLU (module.py:74-77).  gamma/beta/bias fp32; w in `dtype`.
+ * N % 64 == 0 (bf16) / N % 32 == 0 (fp32): features are walked in whole weight panels.
  * Optional outputs: xn[M,256] = LN(x) (dtype), stats[M,2] = (mean, 1/(std+eps)).
  * drop_p > 0 applies nn.Dropout (module.py:77-79 drop1) to the activated output with the
  * counter-based mask keep(seed ^ *seed_dev, row*N+col); the backward regenerates it (mtmp_dropout_bwd).
@@ -60,7 +61,7 @@ int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta
                  void* y, void* xn, float* stats, int M, int N, int ldx, int ldy, float eps, int relu, float drop_p,
                  unsigned seed, const unsigned* seed_dev, void* stream);
 
-/* y[M,N] = drop(act(a[M,K] w[N,K]^T + bias)) (+ res[M,N]); K % 64 == 0, N % 32 == 0.
+/* y[M,N] = drop(act(a[M,K] w[N,K]^T + bias)) (+ res[M,N]); K % 8 == 0, N % 32 == 0; res must not alias y.
  * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32).  With gate[M,N] != NULL the
  * result is gated: y = gate > 0 ? y * gate_scale : 0 -- the backward of ReLU (+ drop1) applied to
  * dH = dY W2 in the same pass (gate = the stored post-dropout activations). */

@@ -606,3 +606,54 @@ def test_graph_replay_draws_fresh_dropout_masks(ops):
     assert gs.captures == 1 and gs.replays == 3
     assert not torch.equal(zero[0], zero[1]) and not torch.equal(zero[1], zero[2])
     ops.set_seed_word(None)
+
+
+# ------------------------------------------------------------------ next rows: eval metrics, checkpoints
+def test_evaluator_metrics_on_gpu(ops):
+    """Evaluator (metrics.py:26-108 of the reference, minus torchmetrics/.cuda()) on device tensors vs scikit-learn."""
+    from types import SimpleNamespace
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from medical_tri_modal_pilot_amd.builder.utils.metrics import Evaluator
+    ev = Evaluator(SimpleNamespace(output_dim=1, batch_size=64, model_types="detection", loss_types="bce",
+                                   auxiliary_loss_type="None"))
+    g = torch.Generator().manual_seed(3)
+    ys, ps = [], []
+    for _ in range(40):
+        y = (torch.rand(64, generator=g) < 0.25).float()
+        p = (torch.sigmoid(torch.randn(64, generator=g) + 1.2 * y) * 50).round() / 50      # ties
+        ev.add_batch(y.to(DEV), p.to(DEV))
+        ys.append(y)
+        ps.append(p)
+    auc, apr, f1 = ev.performance_metric()
+    yy, pp = torch.cat(ys).numpy(), torch.cat(ps).numpy()
+    assert auc == round(roc_auc_score(yy, pp), 4) and apr == round(average_precision_score(yy, pp), 4)
+    assert 0.0 <= f1 <= 1.0
+
+
+def test_resume_from_reference_optimizer_state(ops):
+    """A torch.optim.AdamW(model.parameters()) checkpoint (Logger.save layout) resumes on the fused optimizer: the
+    next update equals torch's next update."""
+    from medical_tri_modal_pilot_amd.builder.utils import checkpoint as C
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+
+    def tiny():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8)).to(DEV)
+
+    x = torch.randn(12, 16, device=DEV)
+    ref = tiny()
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=1e-2)
+    for _ in range(3):
+        ropt.zero_grad()
+        ref(x).square().sum().backward()
+        ropt.step()
+    ckpt = C.make_checkpoint(ref, ropt, 3, 1, 0.5)
+    model = tiny()
+    fopt = FusedAdamW(list(model.named_parameters()), lr=1.0)
+    C.load_checkpoint(ckpt, model, fopt)
+    for m, o in ((ref, ropt), (model, fopt)):
+        o.zero_grad()
+        m(x).square().sum().backward()
+        o.step()
+    for a, b in zip(model.parameters(), ref.parameters()):
+        check("resume.param", a, b, 1e-6)
