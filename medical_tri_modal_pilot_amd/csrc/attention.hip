@@ -233,6 +233,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> pf = frag_from_acc<T>(st[kb], s);
+                // (requesting these eight V^T fragments before the softmax math was tried: +24 VGPRs cost a wave of
+                //  occupancy and the forward got 3 % slower -- it is VALU-bound, not LDS-latency-bound like the backward)
                 mma<T>(o0, frag_tr(sVt, 32 * kb + 16 * s, 0, lane), pf);
                 mma<T>(o1, frag_tr(sVt, 32 * kb + 16 * s, 32, lane), pf);
             }
@@ -342,6 +344,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // transposed K fragments of the dQ product requested before the score math (see the dK/dV kernel)
+            Frag<T> trf[2][2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                trf[s][0] = frag_tr(sKt, 32 * kb + 16 * s, 0, lane);
+                trf[s][1] = frag_tr(sKt, 32 * kb + 16 * s, 32, lane);
+            }
             f32x16 st = {0}, dp = {0};
             tile_qk<T>(st, sK + 32 * kb * LDT, r, half, qf);
             tile_qk<T>(dp, sV + 32 * kb * LDT, r, half, dof);
@@ -354,8 +363,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> dsf = frag_from_acc<T>(st, s);
-                mma<T>(dq0, frag_tr(sKt, 32 * kb + 16 * s, 0, lane), dsf);
-                mma<T>(dq1, frag_tr(sKt, 32 * kb + 16 * s, 32, lane), dsf);
+                mma<T>(dq0, trf[s][0], dsf);
+                mma<T>(dq1, trf[s][1], dsf);
             }
         }
     }
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
             put_tr(sdOt, oreg, tid);
             if (tid < KT) { sL[tid] = lreg; sD[tid] = dreg; }
             __syncthreads();
+#ifndef MTMP_DKDV_NOFETCH                      // (ablation builds: tools/ablate_dkdv.sh -- never shipped)
             if (it + 1 < nq) {
                 qreg = tile_fetch<T>(Qb, p.ld_qkv, q0 + KT, p.N, tid);
                 oreg = tile_fetch<T>(dOb, p.ld_do, q0 + KT, p.N, tid);
@@ -431,30 +441,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
                     dreg = (q0 + KT + tid < p.N) ? Db[q0 + KT + tid] : 0.f;
                 }
             }
+#endif
             if (kw0 < kvl) {                   // wave-uniform
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
+                    // Everything this query block reads from LDS is requested up front: the 8 transposed fragments of
+                    // the dV / dK products and the lse / delta of its 16 + 16 query rows as four 16-byte reads each.
+                    // (Ablations, tools/ablate_dkdv.sh: 64 scalar ds_read_b32 of lse/delta per tile cost 94 us of a
+                    //  439 us backward, and transposed reads issued right in front of their MFMA another ~140 us of
+                    //  exposed LDS latency; exp2 and the global loads cost nothing.)
+                    Frag<T> trf[2][4];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int q16 = 32 * qb + 16 * s;
+                        trf[s][0] = frag_tr(sdOt, q16, 0, lane);
+                        trf[s][1] = frag_tr(sdOt, q16, 32, lane);
+                        trf[s][2] = frag_tr(sQt, q16, 0, lane);
+                        trf[s][3] = frag_tr(sQt, q16, 32, lane);
+                    }
+                    float lq[16], dq_[16];         // row t of the accumulators = query 32qb + 16(t>>3) + 8half + (t&7)
+#pragma unroll
+                    for (int h8 = 0; h8 < 2; ++h8)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 32 * qb + 16 * h8 + 8 * half + 4 * v);
+                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 32 * qb + 16 * h8 + 8 * half + 4 * v);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { lq[8 * h8 + 4 * v + i] = l4[i]; dq_[8 * h8 + 4 * v + i] = d4[i]; }
+                        }
                     f32x16 st = {0}, dp = {0};
                     if (!uniform) tile_qk<T>(st, sQ + 32 * qb * LDT, r, half, kf);
                     tile_qk<T>(dp, sdO + 32 * qb * LDT, r, half, vf);
                     f32x16 ds;
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        const int qi = 32 * qb + acc_row_swz(t, half);
                         // uniform case: st == 0 and the forward stored lse = log2(N), so pv = 1/N
-                        const float pv = key_ok ? fast_exp2(fmaf(st[t], c2, -sL[qi])) : 0.f;
+                        const float pv = key_ok ? fast_exp2(fmaf(st[t], c2, -lq[t])) : 0.f;
                         st[t] = pv;
-                        ds[t] = uniform ? 0.f : pv * (dp[t] - sD[qi]);
+                        ds[t] = uniform ? 0.f : pv * (dp[t] - dq_[t]);
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const Frag<T> pf = frag_from_acc<T>(st, s);
                         const Frag<T> dsf = frag_from_acc<T>(ds, s);
-                        const int q16 = 32 * qb + 16 * s;
-                        mma<T>(dv0, pf, frag_tr(sdOt, q16, 0, lane));
-                        mma<T>(dv1, pf, frag_tr(sdOt, q16, 32, lane));
-                        mma<T>(dk0, dsf, frag_tr(sQt, q16, 0, lane));
-                        mma<T>(dk1, dsf, frag_tr(sQt, q16, 32, lane));
+                        mma<T>(dv0, pf, trf[s][0]);
+                        mma<T>(dv1, pf, trf[s][1]);
+                        mma<T>(dk0, dsf, trf[s][2]);
+                        mma<T>(dk1, dsf, trf[s][3]);
                     }
                 }
             }
