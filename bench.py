@@ -35,7 +35,7 @@ B_PER_GPU, TIE_LEN, LAYERS = 64, 1000, 6
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def make_args(dtype: str, dropout: float, hip_graph: int = 0):
+def make_args(dtype: str, dropout: float, hip_graph: int = 1):
     from medical_tri_modal_pilot_amd.control.config import parse_args
     return parse_args(["--input-types", "vslt_img_txt", "--model", "tri_mbt_vsltcls", "--modality-inclusion",
                        "train-missing_test-missing", "--lr-init", "1e-5", "--output-type", "intubation",
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hip-graph", type=int, default=0, choices=[0, 1])
+    ap.add_argument("--hip-graph", type=int, default=1, choices=[0, 1])
     ap.add_argument("--probe-steps", type=int, default=5, help="eager steps after the timed region that time "
                     "the roofline kernel with HIP events (only when the timed region replays a hipGraph)")
     a = ap.parse_args()

@@ -26,18 +26,19 @@ from medical_tri_modal_pilot_amd import ops
 WS = 7
 PAD_LOGIT = -30000.0
 
-_cast_cache = {}
-
-
 def _w(p: torch.Tensor, dtype) -> torch.Tensor:
-    """Frozen-encoder weights in the compute dtype, converted once per (tensor, version)."""
+    """Frozen-encoder weights in the compute dtype, converted once per (tensor, version).  The copy lives ON the
+    parameter object (a module-level dict keyed by id(p) outlived its parameters: a later module could get a recycled
+    id + data_ptr and be handed another layer's weights)."""
     if p.dtype == dtype:
         return p
-    key = (id(p), dtype)
-    hit = _cast_cache.get(key)
-    if hit is None or hit[0] != (p._version, p.data_ptr()):
-        hit = ((p._version, p.data_ptr()), p.detach().to(dtype).contiguous())
-        _cast_cache[key] = hit
+    cache = getattr(p, "_mtmp_cast", None)
+    if cache is None:
+        cache = p._mtmp_cast = {}
+    hit = cache.get(dtype)
+    if hit is None or hit[0] != (p._version, p.data_ptr(), tuple(p.shape)):
+        hit = ((p._version, p.data_ptr(), tuple(p.shape)), p.detach().to(dtype).contiguous())
+        cache[dtype] = hit
     return hit[1]
 
 

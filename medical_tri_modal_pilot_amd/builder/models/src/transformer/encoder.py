@@ -61,7 +61,7 @@ class TransformerEncoderLayer(nn.Module):
         a, f = self.self_attention, self.feed_forward
         ps = [a.query_proj.linear.weight, a.key_proj.linear.weight, a.value_proj.linear.weight,
               a.query_proj.linear.bias, a.key_proj.linear.bias, a.value_proj.linear.bias, f.w_1.weight, f.w_2.weight]
-        key = (dtype,) + tuple((p._version, p.data_ptr()) for p in ps)
+        key = (dtype, ops._fused_epoch[0]) + tuple((p._version, p.data_ptr()) for p in ps)
         if key != self._fused_key:
             # parameters living in an optim.FlatParams buffer: views of the fp32 master / the bf16 shadow that the
             # AdamW kernel keeps current -- no cast kernels in the step (only W2^T is materialised)

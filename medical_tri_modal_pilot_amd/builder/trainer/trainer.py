@@ -8,7 +8,7 @@ Differences, all required to run off-CUDA-autocast and on any device:
   * no ``torch.cuda.amp.autocast()``: the model owns its compute dtype (bf16 MFMA or fp32);
     x / img_time / txt_time still pass through fp16 rounding like 2_train.py:164 and :26-27;
   * gradient all-reduce (DDP) is waited for inside ``optimizer.step`` when a reducer is attached;
-  * ``args.hip_graph == 1`` (opt-in; needs the flat-buffer FusedAdamW): zero_grad + forward + loss +
+  * ``args.hip_graph == 1`` (default; needs the flat-buffer FusedAdamW, else eager): zero_grad + forward + loss +
     backward are replayed from a captured hipGraph (graph.GraphedTrainStep) -- same kernels, same order, same
     results, one launch.  The ragged trim (:41-42) then rounds max_len up to a multiple of 128 so that a
     training run needs at most a handful of graphs; the extra rows lie behind kv_len like every other pad row.

@@ -123,7 +123,7 @@ _BUILD_FLAGS = [
                                 help="bf16: MFMA performance build; fp32: parity build (exact fp32 MFMA)")),
     (("--ddp",), dict(type=int, default=0, choices=[0, 1], help="data-parallel training over RCCL (one rank per GPU)")),
     (("--fused-adamw",), dict(type=int, default=1, choices=[0, 1], help="mtmp_adamw_step over flat buffers")),
-    (("--hip-graph",), dict(type=int, default=0, choices=[0, 1],
+    (("--hip-graph",), dict(type=int, default=1, choices=[0, 1],
                             help="replay zero_grad+forward+backward of the training step from a captured hipGraph "
                                  "(pays off when the host cannot enqueue ~770 launches per step fast enough)")),
     (("--n-images",), dict(type=int, default=3, help="images per sample when --multiimages 1 (reference: 3)")),

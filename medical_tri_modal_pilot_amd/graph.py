@@ -29,7 +29,7 @@ import torch
 from . import ops
 
 _GOLDEN = 0x9E3779B1          # odd increment of the step word
-_SYNC_AFTER_REPLAY = os.environ.get("MTMP_GRAPH_NO_SYNC", "") == ""      # (diagnostics only: MTMP_GRAPH_NO_SYNC=1)
+_SYNC_AFTER_REPLAY = os.environ.get("MTMP_GRAPH_SYNC", "") != ""        # diagnostics: host-wait after every replay
 
 
 class GraphedTrainStep:
@@ -60,11 +60,11 @@ class GraphedTrainStep:
     def _capture(self, ent: dict, inputs: Dict[str, torch.Tensor], fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
                  params):
         static = {k: v.detach().clone() for k, v in inputs.items()}
-        if params:
-            torch._C._increment_version(params)      # compute-dtype weight casts must be re-done INSIDE the graph
+        ops.bump_fused_epoch()      # per-layer derived weights (W2^T, casts) must be re-made INSIDE the graph
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
+        # thread_local: other threads (autograd workers, the RCCL watchdog) may keep making HIP calls during capture
+        with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
             self.seed_word.add_(_GOLDEN)
             loss = fn(static)
         if self.pool is None:
@@ -119,11 +119,12 @@ class GraphedTrainStep:
                     v.record_stream(self.stream)
             ent["graph"].replay()
         cur.wait_stream(self.stream)
-        # Host-wait for the replay before anything else is enqueued.  Measured on ROCm 7.2 / torch 2.10 (bench.py with
-        # MTMP_NO_OVERLAP=1 MTMP_GRAPH_NO_SYNC=1 --warmup 10): with the replay launched on the default stream, work
-        # enqueued on that stream right after hipGraphLaunch (the AdamW kernel) could overtake the graph's tail -- the
-        # loss went NaN within ~15 steps, while a wait after the replay keeps it bit-identical to the eager steps.
-        # The trainer reads loss.item() right after the step anyway, so this wait costs nothing extra.
+        # Why not simply graph.replay() on the caller's stream: measured on ROCm 7.2 / torch 2.10 (bench.py, one-stream
+        # graph, --warmup 10), a graph launched on the DEFAULT stream let work enqueued on that stream right after
+        # hipGraphLaunch (the AdamW kernel) overtake the graph's tail -- the loss went NaN within ~15 steps.  Launched
+        # on the capture stream and joined by events as above, 60 replayed steps are bit-identical to eager ones in
+        # every stream configuration.  MTMP_GRAPH_SYNC=1 additionally host-waits for each replay (diagnostics; costs
+        # ~0.7 ms/step because the next step's host work no longer overlaps the GPU).
         if _SYNC_AFTER_REPLAY:
             self.stream.synchronize()
         self.replays += 1

@@ -52,6 +52,15 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 _seed_word: Optional[torch.Tensor] = None
 
 
+_fused_epoch = [0]
+
+
+def bump_fused_epoch():
+    """Invalidate every layer's cached derived weights (encoder.py:_fused_weights) -- graph capture calls this so
+    that W2^T / casts are recomputed by kernels INSIDE the captured step instead of being frozen copies."""
+    _fused_epoch[0] += 1
+
+
 def set_seed_word(t: Optional[torch.Tensor]):
     global _seed_word
     if t is not None and (t.dtype != torch.int64 or t.numel() != 1 or not t.is_cuda):
