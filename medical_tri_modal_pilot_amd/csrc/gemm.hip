@@ -64,21 +64,21 @@ template <typename T> struct GemmArgs {
 // replicated weight rows produce columns >= N, which are never stored.
 template <typename T> struct TileRegs { Frag<T> f[4]; unsigned ok; };
 
-template <typename T>
+template <typename T, int ROWS = 128>
 MTMP_DEV void tile_fetch(TileRegs<T>& t, const T* src, int ld, int row0, int limit, int k0, int tid, int kmax) {
     const int kc = k0 + (tid & 7) * 8;
     const int kcc = min(kc, kmax - 8);
     t.ok = 0;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < ROWS / 32; ++ps) {
         const int row = row0 + (tid >> 3) + 32 * ps;
         t.f[ps] = frag_load<T>(src + (size_t)min(row, limit - 1) * ld + kcc);
         t.ok |= (kc < kmax) ? (1u << ps) : 0u;
     }
 }
-template <typename T> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, int tid) {
+template <typename T, int ROWS = 128> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, int tid) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
+    for (int ps = 0; ps < ROWS / 32; ++ps)
         frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, frag_keep(t.f[ps], (t.ok >> ps) & 1u));
 }
 
@@ -91,35 +91,45 @@ template <typename T> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, in
 // (Storing straight from the accumulator layout writes 8-byte pieces at a row stride: partial-line
 //  writes that made the K = 256, write-heavy projections run at half their HBM bound.)
 constexpr int LDO = BN + 8;
-template <typename T> constexpr size_t stage_bytes() { return (size_t)BM * LDO * sizeof(T); }
 
-template <typename T, bool RELU>
-MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
+// TM = token rows per workgroup: 128 (4 waves x 32 rows, 128 features each) or 64 (2 x 2 waves: 32 rows x 64
+// features each) -- the smaller tile is used when a launch would otherwise have fewer workgroups than ~2 per CU
+// (frozen-encoder stages 3-4, the image / text streams): such launches are bound by the latency chain of ONE
+// workgroup per CU, and more, smaller workgroups overlap their chains.
+template <int TM> struct NtGeom {
+    static constexpr int WR = TM / 32, WC = 4 / WR, NT = 4 / WC;     // row waves, column waves, 32-feature tiles per wave
+};
+
+template <typename T, bool RELU, int TM>
+MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::NT], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
+    using G = NtGeom<TM>;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
-    const int row = min(m0 + 32 * wave + r, p.M - 1);
+    const int wr = wave % G::WR, foff = (wave / G::WR) * 32 * G::NT;
+    const int row = min(m0 + 32 * wr + r, p.M - 1);
     const unsigned thr = dropout_threshold(p.drop_p);
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
     const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
-    // phase-2 operands first: eight independent 16-byte loads per thread stay in flight under phase 1
+    // phase-2 operands first: independent 16-byte loads per thread stay in flight under phase 1
     // (loading them one by one inside the store loop cost one full memory latency per pass)
+    constexpr int PS = TM / 16;
     const int c8 = (tid & 15) * 8, gcol = n0 + c8, gcolc = min(gcol, p.N - 8);
-    Frag<T> gv[8], rv[8];
+    Frag<T> gv[PS], rv[PS];
     if (p.gate) {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps)
+        for (int ps = 0; ps < PS; ++ps)
             gv[ps] = frag_load<T>(p.gate + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.N + gcolc);
     }
     if (p.res) {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps)
+        for (int ps = 0; ps < PS; ++ps)
             rv[ps] = frag_load<T>(p.res + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.ldr + gcolc);
     }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        if (n0 + 32 * nt >= p.N) continue;
+    for (int nt = 0; nt < G::NT; ++nt) {
+        if (n0 + foff + 32 * nt >= p.N) continue;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int cl = 32 * nt + 8 * g + 4 * half, col = n0 + cl;
+            const int cl = foff + 32 * nt + 8 * g + 4 * half, col = n0 + cl;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
             float v[4];
@@ -131,13 +141,13 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[4], const GemmArgs<T>& p, T* sOut, in
                 if (p.act == 2) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752f));
                 if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
             }
-            store4<T>(sOut + (32 * wave + r) * LDO + cl, v[0], v[1], v[2], v[3]);
+            store4<T>(sOut + (32 * wr + r) * LDO + cl, v[0], v[1], v[2], v[3]);
         }
     }
     __syncthreads();
     if (gcol < p.N) {
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
+        for (int ps = 0; ps < PS; ++ps) {
             const int rl = (tid >> 4) + 16 * ps, grow = min(m0 + rl, p.M - 1);
             Frag<T> o = frag_load<T>(sOut + rl * LDO + c8);
             if (p.gate || p.row_scale || p.res) {
@@ -345,39 +355,47 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 }
 
 // ---------------------------------------------------------------------------
-template <typename T, bool RELU>
+// One LDS stage + one register stage (tile k+1 is fetched while tile k is multiplied).  A version with two stages of
+// each (as in gemm_tn_tr_kernel) was measured and rejected: it needs 256 VGPRs and 74 KiB of LDS, i.e. two
+// workgroups per CU instead of three, and every large launch got 20-30 % slower (dH 93 -> 120 us, FFN2 76 -> 97 us);
+// only launches with < 1 workgroup per CU gained.  Occupancy hides this loop's latency better than depth.
+template <typename T, bool RELU, int TM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
+    using G = NtGeom<TM>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sA = reinterpret_cast<T*>(smem_raw);   // [BM][LDW]
-    T* sW = sA + BM * LDW;                    // [BN][LDW]
+    T* sA = reinterpret_cast<T*>(smem_raw);   // [TM][LDW]
+    T* sW = sA + TM * LDW;                    // [BN][LDW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int wr = wave % G::WR, foff = (wave / G::WR) * 32 * G::NT;
     const int ntn = (p.N + BN - 1) / BN;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (w / ntn) * BM, n0 = (w % ntn) * BN;
+    const int m0 = (w / ntn) * TM, n0 = (w % ntn) * BN;
     const int nk = (p.K + BK - 1) / BK;
     TileRegs<T> areg, wreg;
-    tile_fetch<T>(areg, p.a, p.lda, m0, p.M, 0, tid, p.K);
+    tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, 0, tid, p.K);
     tile_fetch<T>(wreg, p.w, p.K, n0, p.N, 0, tid, p.K);
-    f32x16 acc[4] = {{0}, {0}, {0}, {0}};
+    f32x16 acc[G::NT];
+#pragma unroll
+    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x16{0};
     for (int kc = 0; kc < nk; ++kc) {
         __syncthreads();
-        tile_commit<T>(sA, areg, tid);
+        tile_commit<T, TM>(sA, areg, tid);
         tile_commit<T>(sW, wreg, tid);
         __syncthreads();
         if (kc + 1 < nk) {
-            tile_fetch<T>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid, p.K);
+            tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid, p.K);
             tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 1) * BK, tid, p.K);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const Frag<T> a = frag_load<T>(sA + (32 * wave + r) * LDW + 16 * c + 8 * half);
+            const Frag<T> a = frag_load<T>(sA + (32 * wr + r) * LDW + 16 * c + 8 * half);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                mma<T>(acc[nt], frag_load<T>(sW + (32 * nt + r) * LDW + 16 * c + 8 * half), a);
+            for (int nt = 0; nt < G::NT; ++nt)
+                mma<T>(acc[nt], frag_load<T>(sW + (foff + 32 * nt + r) * LDW + 16 * c + 8 * half), a);
         }
     }
     __syncthreads();                          // every wave is done with sA / sW: reuse them as the staging tile
-    epilogue<T, RELU>(acc, p, sA, m0, n0, tid);
+    epilogue<T, RELU, TM>(acc, p, sA, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -712,22 +730,28 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
     MTMP_CHECK_LAUNCH("mtmp_ln_gemm");
     return MTMP_OK;
 }
-template <typename T>
-int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
-    size_t sm = (size_t)(BM + BN) * LDW * sizeof(T);
-    if (sm < stage_bytes<T>()) sm = stage_bytes<T>();
+template <typename T, int TM>
+int launch_gemm_nt_tm(GemmArgs<T> a, int relu, hipStream_t st) {
+    size_t sm = (size_t)(TM + BN) * LDW * sizeof(T);
+    const size_t stage = (size_t)TM * LDO * sizeof(T);
+    if (sm < stage) sm = stage;
     if (sm > 48 * 1024) {
-        const void* f = relu ? (const void*)gemm_nt_kernel<T, true> : (const void*)gemm_nt_kernel<T, false>;
+        const void* f = relu ? (const void*)gemm_nt_kernel<T, true, TM> : (const void*)gemm_nt_kernel<T, false, TM>;
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
             mtmp_set_error("mtmp_gemm_nt: cannot raise dynamic LDS to %zu", sm);
             return MTMP_ERR_LAUNCH;
         }
     }
-    dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN));
-    if (relu) hipLaunchKernelGGL((gemm_nt_kernel<T, true>), grid, dim3(256), sm, st, a);
-    else      hipLaunchKernelGGL((gemm_nt_kernel<T, false>), grid, dim3(256), sm, st, a);
+    dim3 grid(((a.M + TM - 1) / TM) * ((a.N + BN - 1) / BN));
+    if (relu) hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM>), grid, dim3(256), sm, st, a);
+    else      hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM>), grid, dim3(256), sm, st, a);
     MTMP_CHECK_LAUNCH("mtmp_gemm_nt");
     return MTMP_OK;
+}
+template <typename T>
+int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
+    const long long wgs128 = (long long)((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
+    return wgs128 < 512 ? launch_gemm_nt_tm<T, 64>(a, relu, st) : launch_gemm_nt_tm<T, 128>(a, relu, st);
 }
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
