@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 // workgroups per CU instead of three, and every large launch got 20-30 % slower (dH 93 -> 120 us, FFN2 76 -> 97 us);
 // only launches with < 1 workgroup per CU gained.  Occupancy hides this loop's latency better than depth.
 template <typename T, bool RELU, int TM>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void gemm_nt_kernel(GemmArgs<T> p) {
     using G = NtGeom<TM>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sA = reinterpret_cast<T*>(smem_raw);   // [TM][LDW]
