@@ -63,6 +63,8 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             return None
         key = (dev.type, dev.index)
         if getattr(self, "_streams_key", None) != key:
+            # (default priority: high-priority side streams were measured -- 13.4 -> 18.8 ms/step under graph replay,
+            #  13.6 -> 14.4 ms eager)
             self._streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
             self._streams_key = key
         return self._streams

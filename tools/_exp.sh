@@ -1,3 +1,2 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-run() { tag=$1; shift; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/p_$tag -o $tag -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 3 "$@" > gpurun_out/p_$tag.log 2>&1; python tools/trace_summary.py gpurun_out/p_$tag/${tag}_kernel_trace.csv --top 70 > gpurun_out/sum_$tag.txt 2>&1; rm -rf gpurun_out/p_$tag; }
-run eager --hip-graph 0
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep '"metric"' | cut -c1-330
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
