@@ -145,7 +145,7 @@ MTMP_DEV void tile_qk(f32x16& acc, const T* lds_rows, int r, int half, const Fra
 
 // =============================== forward ====================================
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
     T* sVt = sK + KT * LDT;                   // V image for the transposed role (frag_tr)
@@ -248,27 +248,47 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs<T> p) {
     }
 #endif
     l += __shfl_xor(l, 32, 64);
-    if (qrow < p.N) {
-        const float inv = 1.0f / l;
-        const size_t orow = ((size_t)b * p.N + qrow) * p.ld_o + hd * DH;
+    // Epilogue.  A lane owns one query and 4-element pieces of its O row, so direct stores would be 8-byte pieces
+    // at a row stride -- partial-line writes (PMC: 72 MB written per launch for a 33 MB output).  The wave's
+    // 32 x 64 tile goes through a wave-private LDS tile instead and leaves as whole 128-byte head rows.
+    __syncthreads();                                  // all waves are done with sK / sVt: reuse them as staging
+    T* sO = reinterpret_cast<T*>(smem_raw) + wave * 32 * LDT;
+    const float inv = 1.0f / l;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x16& o = dt ? o1 : o0;
-                const int d0 = 32 * dt + 8 * g + 4 * half;
-                float a0 = o[4 * g] * inv, a1 = o[4 * g + 1] * inv, a2 = o[4 * g + 2] * inv, a3 = o[4 * g + 3] * inv;
-                store4<T>(p.o + orow + d0, a0, a1, a2, a3);
-                if (p.o_res) {
-                    // residual epilogue (encoder.py:27 "outputs += residual"): the residual adds the
-                    // value of O as stored (i.e. rounded to T), like the reference's tensor add.
-                    f32x4 rv = load4<T>(p.res + orow + d0);
-                    store4<T>(p.o_res + orow + d0, round_as<T>(a0) + rv[0], round_as<T>(a1) + rv[1],
-                              round_as<T>(a2) + rv[2], round_as<T>(a3) + rv[3]);
-                }
+        for (int g = 0; g < 4; ++g) {
+            const f32x16& o = dt ? o1 : o0;
+            store4<T>(sO + r * LDT + 32 * dt + 8 * g + 4 * half, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv,
+                      o[4 * g + 3] * inv);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS, no barrier needed
+    constexpr int CH = DH * (int)sizeof(T) / 16, RPP = 64 / CH;       // 16-byte chunks per row, rows per pass
+    const int q0w = qt * 128 + wave * 32;
+#pragma unroll
+    for (int ps = 0; ps < 32 / RPP; ++ps) {
+        const int rl = ps * RPP + lane / CH, ch = lane % CH;
+        if (q0w + rl < p.N) {
+            const size_t off = ((size_t)b * p.N + q0w + rl) * p.ld_o + hd * DH + ch * (16 / (int)sizeof(T));
+            const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sO + rl * LDT) + 16 * ch);
+            *reinterpret_cast<u32x4_t*>(p.o + off) = ov;
+            if (p.o_res) {
+                // residual epilogue (encoder.py:27 "outputs += residual"): the residual adds the
+                // value of O as stored (i.e. rounded to T), like the reference's tensor add.
+                constexpr int E = 16 / (int)sizeof(T);
+                T ob[E], rb[E], sb[E];
+                __builtin_memcpy(ob, &ov, 16);
+                const u32x4_t rvv = *reinterpret_cast<const u32x4_t*>(p.res + off);
+                __builtin_memcpy(rb, &rvv, 16);
+#pragma unroll
+                for (int i = 0; i < E; ++i) sb[i] = from_f32<T>(to_f32(ob[i]) + to_f32(rb[i]));
+                u32x4_t sv;
+                __builtin_memcpy(&sv, sb, 16);
+                *reinterpret_cast<u32x4_t*>(p.o_res + off) = sv;
             }
-        if (half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m + log2f(l);
+        }
     }
+    if (qrow < p.N && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m + log2f(l);
 }
 
 // =============================== backward ===================================
