@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 // workgroups per CU instead of three, and every large launch got 20-30 % slower (dH 93 -> 120 us, FFN2 76 -> 97 us);
 // only launches with < 1 workgroup per CU gained.  Occupancy hides this loop's latency better than depth.
 template <typename T, bool RELU, int TM>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void gemm_nt_kernel(GemmArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) void gemm_nt_kernel(GemmArgs<T> p) {
     using G = NtGeom<TM>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sA = reinterpret_cast<T*>(smem_raw);   // [TM][LDW]
@@ -377,21 +377,51 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void gemm_nt_kernel(
     f32x16 acc[G::NT];
 #pragma unroll
     for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x16{0};
-    for (int kc = 0; kc < nk; ++kc) {
-        __syncthreads();
-        tile_commit<T, TM>(sA, areg, tid);
-        tile_commit<T>(sW, wreg, tid);
-        __syncthreads();
-        if (kc + 1 < nk) {
-            tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid, p.K);
-            tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 1) * BK, tid, p.K);
-        }
+    auto multiply = [&]() {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const Frag<T> a = frag_load<T>(sA + (32 * wr + r) * LDW + 16 * c + 8 * half);
 #pragma unroll
             for (int nt = 0; nt < G::NT; ++nt)
                 mma<T>(acc[nt], frag_load<T>(sW + (foff + 32 * nt + r) * LDW + 16 * c + 8 * half), a);
+        }
+    };
+    if constexpr (TM == 64 && sizeof(T) == 2) {
+        // The small tile is chosen for launches of <= ~2 workgroups per CU, where a workgroup's k loop is a serial
+        // latency chain.  It has registers to spare (89 VGPRs), so it keeps TWO tiles in flight: step s+2 is fetched
+        // while step s is multiplied and step s+1 already sits in registers (k steps past the end fetch clamped
+        // addresses with ok = 0: zeros that are never multiplied).
+        TileRegs<T> areg2, wreg2;
+        tile_fetch<T, TM>(areg2, p.a, p.lda, m0, p.M, BK, tid, p.K);
+        tile_fetch<T>(wreg2, p.w, p.K, n0, p.N, BK, tid, p.K);
+        for (int kc = 0; kc < nk; kc += 2) {
+            __syncthreads();
+            tile_commit<T, TM>(sA, areg, tid);
+            tile_commit<T>(sW, wreg, tid);
+            __syncthreads();
+            tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, (kc + 2) * BK, tid, p.K);
+            tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 2) * BK, tid, p.K);
+            multiply();
+            if (kc + 1 >= nk) break;
+            __syncthreads();
+            tile_commit<T, TM>(sA, areg2, tid);
+            tile_commit<T>(sW, wreg2, tid);
+            __syncthreads();
+            tile_fetch<T, TM>(areg2, p.a, p.lda, m0, p.M, (kc + 3) * BK, tid, p.K);
+            tile_fetch<T>(wreg2, p.w, p.K, n0, p.N, (kc + 3) * BK, tid, p.K);
+            multiply();
+        }
+    } else {
+        for (int kc = 0; kc < nk; ++kc) {
+            __syncthreads();
+            tile_commit<T, TM>(sA, areg, tid);
+            tile_commit<T>(sW, wreg, tid);
+            __syncthreads();
+            if (kc + 1 < nk) {
+                tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid, p.K);
+                tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 1) * BK, tid, p.K);
+            }
+            multiply();
         }
     }
     __syncthreads();                          // every wave is done with sA / sW: reuse them as the staging tile
