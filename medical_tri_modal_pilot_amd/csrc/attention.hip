@@ -20,6 +20,7 @@
 // accumulator registers (common.cuh: acc -> Frag).
 #include "common.cuh"
 #include <math.h>
+#include <type_traits>
 
 // Diagnostic build only (make stamp): s_memtime stamps around the phases of the forward loop.
 #ifdef MTMP_STAMP
@@ -40,6 +41,9 @@ __device__ unsigned long long g_stamp[8];
 
 namespace {
 
+#ifndef MTMP_FWD_OCC
+#define MTMP_FWD_OCC 3
+#endif
 constexpr int DH = 64;       // head dim: d_model 256 / 4 heads (tri_mbt_vsltcls.py:29-30)
 constexpr int KT = 64;       // rows per LDS tile
 constexpr int LDT = DH + 8;  // padded LDS row, elements (keeps 16-byte alignment, spreads banks)
@@ -67,7 +71,6 @@ template <typename T> struct AttnArgs {
 //         one 128-byte row, a wave-load covers 8 whole rows.
 //   fp32 (parity build): there is no 32-bit transposing read; the transposed image is written
 //         [col][row] with 8-byte LDS stores from a (row pair, column group) thread mapping.
-template <typename T> struct Tile2 { Frag<T> a, b; bool oka, okb; };
 constexpr int LDR = 96;      // row stride (elements) of the bf16 image that feeds ds_read_b64_tr_b16
 
 template <typename T> constexpr int tr_elems() { return sizeof(T) == 2 ? KT * LDR : DH * LDT; }
@@ -75,45 +78,6 @@ template <typename T> constexpr int tr_elems() { return sizeof(T) == 2 ? KT * LD
 template <typename T> MTMP_DEV void tile_map(int tid, int& ra, int& rb, int& col) {
     if (sizeof(T) == 2) { ra = tid >> 3; rb = ra + 32; col = (tid & 7) * 8; }
     else                { ra = (tid & 31) * 2; rb = ra + 1; col = (tid >> 5) * 8; }
-}
-template <typename T> MTMP_DEV Tile2<T> tile_fetch(const T* src, int ld, int row0, int limit, int tid) {
-    int ra, rb, col;
-    tile_map<T>(tid, ra, rb, col);
-    Tile2<T> t;
-    t.a = frag_load<T>(src + (size_t)min(row0 + ra, limit - 1) * ld + col);
-    t.b = frag_load<T>(src + (size_t)min(row0 + rb, limit - 1) * ld + col);
-    t.oka = row0 + ra < limit;
-    t.okb = row0 + rb < limit;
-    return t;
-}
-template <typename T> MTMP_DEV void put_rows(T* dst, const Tile2<T>& t, int tid) {
-    int ra, rb, col;
-    tile_map<T>(tid, ra, rb, col);
-    if (wave_all(t.oka && t.okb)) {
-        frag_store<T>(dst + ra * LDT + col, t.a);
-        frag_store<T>(dst + rb * LDT + col, t.b);
-    } else {
-        frag_store<T>(dst + ra * LDT + col, frag_keep(t.a, t.oka));
-        frag_store<T>(dst + rb * LDT + col, frag_keep(t.b, t.okb));
-    }
-}
-// image for the TRANSPOSED role
-MTMP_DEV void put_tr(bf16* dst, const Tile2<bf16>& t, int tid) {
-    int ra, rb, col;
-    tile_map<bf16>(tid, ra, rb, col);
-    if (wave_all(t.oka && t.okb)) {
-        frag_store<bf16>(dst + ra * LDR + col, t.a);
-        frag_store<bf16>(dst + rb * LDR + col, t.b);
-    } else {
-        frag_store<bf16>(dst + ra * LDR + col, frag_keep(t.a, t.oka));
-        frag_store<bf16>(dst + rb * LDR + col, frag_keep(t.b, t.okb));
-    }
-}
-MTMP_DEV void put_tr(float* dst, const Tile2<float>& t, int tid) {
-    float* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
-    const Frag<float> a = frag_keep(t.a, t.oka), b = frag_keep(t.b, t.okb);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(d + e * LDT) = f32x2{a.v[e], b.v[e]};
 }
 // fragment of the transposed role: element j = tile[row0 + 8*half + j][col0 + r]   (r = lane & 31)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -134,18 +98,67 @@ MTMP_DEV Frag<float> frag_tr(const float* img, int row0, int col0, int lane) {
     return frag_load<float>(img + (col0 + (lane & 31)) * LDT + row0 + 8 * (lane >> 5));
 }
 
-// 32x32 tile: acc += A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
-template <typename T>
-MTMP_DEV void tile_qk(f32x16& acc, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
-    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
-    acc = mma0<T>(frag_load<T>(arow), bf[0]);
+// =============================== forward ====================================
+// Forward loop, per 64-key tile and wave (32 queries, query = lane):
+//   S'^T = K (c2 Q)^T + (-m)      8 MFMA; the running maximum enters as the MFMA's C operand and the
+//                                 softmax scale c2 = scale*log2(e) is folded into Q once per workgroup,
+//                                 so the scores leave the matrix pipe ready for exp2 (no per-score fma)
+//   row max (v_max3), rescale decision (wave-uniform, rare after the first tiles), exp2, row sum
+//   O^T += V^T P^T                8 MFMA, P^T straight from the accumulator registers
+// The kernel is VALU-issue-bound at d_h = 64 (MI355X_MICROARCH 'vector-instruction ISSUE cost': per score
+// exp 8 + add 4 + max 2 + cvt 2.25 cycles against 16 cycles of matrix pipe), so the loop carries no masks,
+// clamps or address arithmetic: full tiles run a mask-free body, the ragged last tile a second copy of it.
+template <typename T> struct TileR { Frag<T> a, b; };
+
+template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
+    Frag<T> r;
 #pragma unroll
-    for (int c = 1; c < 4; ++c) mma<T>(acc, frag_load<T>(arow + 16 * c), bf[c]);
+    for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
+    return r;
+}
+template <typename T> MTMP_DEV void put_rows_r(T* dst, const TileR<T>& t, int tid) {
+    int ra, rb, col;
+    tile_map<T>(tid, ra, rb, col);
+    frag_store<T>(dst + ra * LDT + col, t.a);
+    frag_store<T>(dst + rb * LDT + col, t.b);
+}
+MTMP_DEV void put_tr_r(bf16* dst, const TileR<bf16>& t, int tid) {
+    int ra, rb, col;
+    tile_map<bf16>(tid, ra, rb, col);
+    frag_store<bf16>(dst + ra * LDR + col, t.a);
+    frag_store<bf16>(dst + rb * LDR + col, t.b);
+}
+MTMP_DEV void put_tr_r(float* dst, const TileR<float>& t, int tid) {
+    float* d = dst + (tid >> 5) * 8 * LDT + (tid & 31) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(d + e * LDT) = f32x2{t.a.v[e], t.b.v[e]};
+}
+// max over the two half-waves (lane i <-> lane i + 32) without the LDS crossbar: v_permlane32_swap
+#ifdef MTMP_NO_SWAP
+MTMP_DEV float half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
+MTMP_DEV float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+#else
+MTMP_DEV float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+MTMP_DEV float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+#endif
+// 32x32 tile: C + A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
+template <typename T>
+MTMP_DEV f32x16 tile_qk_c(const f32x16& c, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
+    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
+    f32x16 acc = mma_c<T>(frag_load<T>(arow), bf[0], c);     // D != C: no copy of the shared C registers
+#pragma unroll
+    for (int cc = 1; cc < 4; ++cc) mma<T>(acc, frag_load<T>(arow + 16 * cc), bf[cc]);
+    return acc;
 }
 
-// =============================== forward ====================================
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
     T* sVt = sK + KT * LDT;                   // V image for the transposed role (frag_tr)
@@ -155,45 +168,91 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
-    const bool uniform = kvl <= 0;            // all keys masked -> reference gives the uniform average
+    // all keys masked -> the reference's masked_fill(-65504) + softmax gives the uniform average over all N
+    // keys: run the ordinary loop with Q = 0 (every score 0, every p = 1).
+    const bool uniform = kvl <= 0;
     if (uniform) kvl = p.N;
     const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int qrow = qt * 128 + wave * 32 + r;
+    const float c2 = p.scale * LOG2E;
     Frag<T> qf[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        qf[c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), qrow < p.N);
+        qf[c] = frag_keep(frag_scale<T>(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
+                          qrow < p.N && !uniform);
     f32x16 o0 = {0}, o1 = {0};
-    float m = -INFINITY, l = 0.f;
-    const float c2 = p.scale * LOG2E;
-    const int ntiles = (kvl + KT - 1) / KT;
-    Tile2<T> kreg = tile_fetch<T>(Kb, p.ld_qkv, 0, kvl, tid);
-    Tile2<T> vreg = tile_fetch<T>(Vb, p.ld_qkv, 0, kvl, tid);
+    f32x16 negm = {0};                         // -m in every register: the C operand of the score MFMAs
+    float m = 0.f, l = 0.f;
+    bool first = true;
+    const int nfull = kvl / KT, ntiles = (kvl + KT - 1) / KT;
+    int ra, rb, col;
+    tile_map<T>(tid, ra, rb, col);
+    const size_t tstep = (size_t)KT * p.ld_qkv;
+    const T* kpa = Kb + (size_t)ra * p.ld_qkv + col;     // this thread's two rows of the NEXT tile to fetch
+    const T* kpb = Kb + (size_t)rb * p.ld_qkv + col;
+    const ptrdiff_t kv_off = Vb - Kb;
+    TileR<T> kreg, vreg;
+    // global -> registers, one tile ahead (the loads fly under the MFMAs of the current tile); rows of the
+    // ragged last tile are clamped to kv_len - 1: keys past kv_len are never read, their scores are masked
+    // and their P is 0, so whatever finite row stands in for them adds nothing.
+    auto fetch = [&](int t) {
+        if (t < nfull) {
+            kreg.a = frag_load<T>(kpa); kreg.b = frag_load<T>(kpb);
+            vreg.a = frag_load<T>(kpa + kv_off); vreg.b = frag_load<T>(kpb + kv_off);
+            kpa += tstep; kpb += tstep;
+        } else {
+            const T* ka = Kb + (size_t)min(t * KT + ra, kvl - 1) * p.ld_qkv + col;
+            const T* kb_ = Kb + (size_t)min(t * KT + rb, kvl - 1) * p.ld_qkv + col;
+            kreg.a = frag_load<T>(ka); kreg.b = frag_load<T>(kb_);
+            vreg.a = frag_load<T>(ka + kv_off); vreg.b = frag_load<T>(kb_ + kv_off);
+        }
+    };
+    fetch(0);
     STAMP_DECL
-    for (int it = 0; it < ntiles; ++it) {
-        const int k0 = it * KT;
+    auto body = [&](int it, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         STAMP(ts0)
         __syncthreads();
-        put_rows<T>(sK, kreg, tid);
-        put_tr(sVt, vreg, tid);
+        put_rows_r<T>(sK, kreg, tid);
+        put_tr_r(sVt, vreg, tid);
         __syncthreads();
         STAMP(ts1)
 #ifndef MTMP_ABLATE_FETCH                      // (ablation builds: tools/ablate_attn.sh -- never shipped)
-        if (it + 1 < ntiles) {                 // next tile's loads fly under this tile's MFMAs
-            kreg = tile_fetch<T>(Kb, p.ld_qkv, k0 + KT, kvl, tid);
-            vreg = tile_fetch<T>(Vb, p.ld_qkv, k0 + KT, kvl, tid);
-        }
+        if (it + 1 < ntiles) fetch(it + 1);
 #endif
-        f32x16 st[2];
-        if (!uniform) {
-            tile_qk<T>(st[0], sK, r, half, qf);
-            tile_qk<T>(st[1], sK + 32 * LDT, r, half, qf);
-        } else {
-            st[0] = f32x16{0};
-            st[1] = f32x16{0};
+        // All eight K fragments are requested before the first MFMA (a read issued right in front of its
+        // MFMA exposes the whole LDS latency, ~100+ cycles against a 32-cycle MFMA), and the eight V^T
+        // fragments right behind the score MFMAs, so that they land under the softmax arithmetic; the two
+        // sets share registers.  sched_barrier pins that order against the compiler's scheduler.
+        Frag<T> kfr[2][4];
+        {
+            const T* arow = sK + swz23(r) * LDT + 8 * half;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kfr[kb][c] = frag_load<T>(arow + 32 * kb * LDT + 16 * c);
         }
-        if (k0 + KT > kvl) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = mma_c<T>(kfr[kb][0], qf[0], negm);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) mma<T>(st[kb], kfr[kb][c], qf[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        Frag<T> vfr[2][2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                vfr[kb][s][0] = frag_tr(sVt, 32 * kb + 16 * s, 0, lane);
+                vfr[kb][s][1] = frag_tr(sVt, 32 * kb + 16 * s, 32, lane);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (TAIL) {
+            const int k0 = it * KT;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -201,28 +260,39 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
                     if (k0 + 32 * kb + acc_row_swz(t, half) >= kvl) st[kb][t] = -INFINITY;
         }
         STAMP(ts2)
-        float mx = st[0][0];
+        // v_max3 is inline asm, which the compiler's hazard recogniser does not see: an asm instruction that
+        // reads an MFMA result too early gets whatever the register holds (found as run-to-run 1-ulp noise:
+        // a wrong maximum is still a valid softmax shift).  `seed` is an ordinary instruction on the LAST
+        // accumulator written, so the required wait states are inserted in front of it, and every asm below
+        // depends on it.
+        const float seed = fmaxf(st[0][15], st[1][15]);
+        float mxa = max3(seed, st[0][0], st[0][1]), mxb = max3(seed, st[1][0], st[1][1]);
 #pragma unroll
-        for (int t = 1; t < 16; t += 2) mx = max3(mx, st[0][t], st[0][t + 1 < 16 ? t + 1 : t]);
-#pragma unroll
-        for (int t = 0; t < 16; t += 2) mx = max3(mx, st[1][t], st[1][t + 1]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
-        // Deferred rescale (exact): O, l and m move only when some row's maximum grew; while it has
-        // not, p = exp2(s - m) <= 1 still holds.  Wave-uniform branch, rare after the first tiles.
-        if (!wave_all(mx <= m)) {
-            const float m_new = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - m_new);
+        for (int t = 2; t < 14; t += 2) {       // two independent chains
+            mxa = max3(mxa, st[0][t], st[0][t + 1]);
+            mxb = max3(mxb, st[1][t], st[1][t + 1]);
+        }
+        const float mx = half_max(max3(mxa, mxb, fmaxf(st[0][14], st[1][14])));
+        // Deferred rescale (exact): mx is the tile's maximum RELATIVE to the running one.  O, l and m move
+        // only when some row's maximum grew (wave-uniform branch, rare after the first tiles); while it has
+        // not, p = exp2(s') <= 1 holds.  The first tile always takes the branch and sets m to its true maximum.
+        if (first || !wave_all(mx <= 0.f)) {
+            const float d = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 1.f : fast_exp2(-d);
             l *= alpha; o0 *= alpha; o1 *= alpha;
-            m = m_new;
+            m += d;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { negm[t] = -m; st[0][t] -= d; st[1][t] -= d; }
+            first = false;
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
 #ifdef MTMP_ABLATE_EXP
-                const float pv = fmaf(st[kb][t], c2, -m);
+                const float pv = st[kb][t];
 #else
-                const float pv = fast_exp2(fmaf(st[kb][t], c2, -m));
+                const float pv = fast_exp2(st[kb][t]);
 #endif
                 l += pv;
                 st[kb][t] = pv;
@@ -233,21 +303,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> pf = frag_from_acc<T>(st[kb], s);
-                // (requesting these eight V^T fragments before the softmax math was tried: +24 VGPRs cost a wave of
-                //  occupancy and the forward got 3 % slower -- it is VALU-bound, not LDS-latency-bound like the backward)
-                mma<T>(o0, frag_tr(sVt, 32 * kb + 16 * s, 0, lane), pf);
-                mma<T>(o1, frag_tr(sVt, 32 * kb + 16 * s, 32, lane), pf);
+                mma<T>(o0, vfr[kb][s][0], pf);
+                mma<T>(o1, vfr[kb][s][1], pf);
             }
         STAMP(ts4)
         STAMP_ACC
-    }
+    };
+    for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
+    if (ntiles > nfull) body(nfull, std::true_type{});
 #ifdef MTMP_STAMP
     if (lane == 0) {
         atomicAdd(&g_stamp[0], sa); atomicAdd(&g_stamp[1], sb); atomicAdd(&g_stamp[2], sc); atomicAdd(&g_stamp[3], sd);
         atomicAdd(&g_stamp[4], (unsigned long long)ntiles);
     }
 #endif
-    l += __shfl_xor(l, 32, 64);
+    l = half_sum(l);
     // Epilogue.  A lane owns one query and 4-element pieces of its O row, so direct stores would be 8-byte pieces
     // at a row stride -- partial-line writes (PMC: 72 MB written per launch for a 33 MB output).  The wave's
     // 32 x 64 tile goes through a wave-private LDS tile instead and leaves as whole 128-byte head rows.
@@ -318,9 +388,50 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* d_
     }
 }
 
+// One thread's share (2 x 16 bytes) of a stream of 64-row x 64-column tiles over rows [0, limit) of a
+// [limit][ld] matrix.  Full tiles are fetched through two running pointers (no address arithmetic in the
+// loop); the ragged last tile clamps its rows to limit - 1 (a finite stand-in row; the kernels make such
+// rows inert through their row constants or masks, never by reading past `limit`).
+template <typename T> struct TileStream {
+    const T* base; const T* pa; const T* pb;
+    size_t step; int ld, limit, ra, rb, col, nfull;
+    MTMP_DEV void init(const T* src, int ld_, int limit_, int tid) {
+        tile_map<T>(tid, ra, rb, col);
+        base = src; ld = ld_; limit = limit_; nfull = limit_ / KT; step = (size_t)KT * ld_;
+        pa = src + (size_t)ra * ld_ + col; pb = src + (size_t)rb * ld_ + col;
+    }
+    MTMP_DEV TileR<T> fetch(int t) {                 // t must run 0, 1, 2, ... (running pointers)
+        TileR<T> x;
+        if (t < nfull) {
+            x.a = frag_load<T>(pa); x.b = frag_load<T>(pb);
+            pa += step; pb += step;
+        } else {
+            x.a = frag_load<T>(base + (size_t)min(t * KT + ra, limit - 1) * ld + col);
+            x.b = frag_load<T>(base + (size_t)min(t * KT + rb, limit - 1) * ld + col);
+        }
+        return x;
+    }
+};
+// rows >= limit - row0 of a fetched tile -> 0 (ragged key tiles of the dQ kernel)
+template <typename T> MTMP_DEV TileR<T> tile_zero_rows(const TileR<T>& x, int row0, int limit, int tid) {
+    int ra, rb, col;
+    tile_map<T>(tid, ra, rb, col);
+    TileR<T> y;
+    y.a = frag_keep(x.a, row0 + ra < limit);
+    y.b = frag_keep(x.b, row0 + rb < limit);
+    return y;
+}
+
+// Both backward kernels fold the row constants into the matrix pipe (cdna_hip_programming.md, 'Attention
+// backward': row constants as the initial accumulator): with the softmax scale folded into one operand
+// (K in dK/dV, Q in dQ) and  -LSE  /  -delta  loaded as the C operand of the two score products,
+//     S' = (c2 K) Q^T - LSE     -> p  = exp2(S')          (no fma, no subtraction)
+//     dP' = V dO^T - delta      -> dS = p * dP'           (one multiply)
+// which leaves exp2 + mul + the bf16 conversions as the only per-score vector work.
+
 // dQ: workgroup = 128 query rows, loops over key tiles (S^T and dP^T with the query on the lane).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]
     T* sV = sK + KT * LDT;                    // [KT][LDT]
@@ -331,37 +442,44 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
-    const bool uniform = kvl <= 0;
+    const bool uniform = kvl <= 0;            // scores are constants -> dQ = 0
     if (uniform) kvl = p.N;
     const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int qrow = qt * 128 + wave * 32 + r;
+    const float c2 = p.scale * LOG2E;
     Frag<T> qf[4], dof[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        qf[c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), qrow < p.N);
+        qf[c] = frag_keep(frag_scale<T>(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
+                          qrow < p.N);
         dof[c] = frag_keep(frag_load<T>(p.d_o + ((size_t)b * p.N + min(qrow, p.N - 1)) * p.ld_do + hd * DH + 16 * c + 8 * half),
                            qrow < p.N);
     }
-    const size_t sidx = ((size_t)b * p.H + hd) * p.N + qrow;
-    const float L2 = (qrow < p.N) ? p.lse[sidx] : INFINITY;
-    const float dl = (qrow < p.N) ? p.delta[sidx] : 0.f;
-    const float c2 = p.scale * LOG2E;
+    const size_t sidx = ((size_t)b * p.H + hd) * p.N + min(qrow, p.N - 1);
+    // rows past N: -LSE = -inf makes p = 0 whatever the (zero) fragments give
+    const float nL = (qrow < p.N) ? -p.lse[sidx] : -INFINITY;
+    const float nD = (qrow < p.N) ? -p.delta[sidx] : 0.f;
+    f32x16 cL, cD;                            // the row constants in every register: C operands
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { cL[t] = nL; cD[t] = nD; }
     f32x16 dq0 = {0}, dq1 = {0};
-    const int ntiles = uniform ? 0 : (kvl + KT - 1) / KT;   // uniform: scores are constants -> dQ = 0
-    Tile2<T> kreg = tile_fetch<T>(Kb, p.ld_qkv, 0, kvl, tid);
-    Tile2<T> vreg = tile_fetch<T>(Vb, p.ld_qkv, 0, kvl, tid);
-    for (int it = 0; it < ntiles; ++it) {
+    const int ntiles = uniform ? 0 : (kvl + KT - 1) / KT;
+    const int nfull = kvl / KT;
+    TileStream<T> ks, vs;
+    ks.init(Kb, p.ld_qkv, kvl, tid);
+    vs.init(Vb, p.ld_qkv, kvl, tid);
+    TileR<T> kreg = ks.fetch(0), vreg = vs.fetch(0);
+    auto body = [&](int it, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = it * KT;
         __syncthreads();
-        put_rows<T>(sK, kreg, tid);
-        put_tr(sKt, kreg, tid);
-        put_rows<T>(sV, vreg, tid);
+        if (TAIL) kreg = tile_zero_rows<T>(kreg, k0, kvl, tid);   // dQ += dS K: masked keys add exactly 0
+        put_rows_r<T>(sK, kreg, tid);
+        put_tr_r(sKt, kreg, tid);
+        put_rows_r<T>(sV, vreg, tid);
         __syncthreads();
-        if (it + 1 < ntiles) {
-            kreg = tile_fetch<T>(Kb, p.ld_qkv, k0 + KT, kvl, tid);
-            vreg = tile_fetch<T>(Vb, p.ld_qkv, k0 + KT, kvl, tid);
-        }
+        if (it + 1 < ntiles) { kreg = ks.fetch(it + 1); vreg = vs.fetch(it + 1); }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             // transposed K fragments of the dQ product requested before the score math (see the dK/dV kernel)
@@ -371,14 +489,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
                 trf[s][0] = frag_tr(sKt, 32 * kb + 16 * s, 0, lane);
                 trf[s][1] = frag_tr(sKt, 32 * kb + 16 * s, 32, lane);
             }
-            f32x16 st = {0}, dp = {0};
-            tile_qk<T>(st, sK + 32 * kb * LDT, r, half, qf);
-            tile_qk<T>(dp, sV + 32 * kb * LDT, r, half, dof);
+            Frag<T> ka[4], va[4];              // ... and so are the row fragments of the two score products
+            {
+                const int ro = (32 * kb + swz23(r)) * LDT + 8 * half;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { ka[c] = frag_load<T>(sK + ro + 16 * c); va[c] = frag_load<T>(sV + ro + 16 * c); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 st = mma_c<T>(ka[0], qf[0], cL);
+            f32x16 dp = mma_c<T>(va[0], dof[0], cD);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { mma<T>(st, ka[c], qf[c]); mma<T>(dp, va[c], dof[c]); }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const bool valid = k0 + 32 * kb + acc_row_swz(t, half) < kvl;
-                const float pv = valid ? fast_exp2(fmaf(st[t], c2, -L2)) : 0.f;
-                st[t] = pv * (dp[t] - dl);
+                float ds = fast_exp2(st[t]) * dp[t];
+                if (TAIL) ds = (k0 + 32 * kb + acc_row_swz(t, half) < kvl) ? ds : 0.f;
+                st[t] = ds;
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -387,7 +513,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
                 mma<T>(dq1, trf[s][1], dsf);
             }
         }
-    }
+    };
+    for (int it = 0; it < min(nfull, ntiles); ++it) body(it, std::false_type{});
+    if (ntiles > nfull) body(nfull, std::true_type{});
     if (qrow < p.N) {
         const size_t orow = ((size_t)b * p.N + qrow) * p.ld_dqkv + hd * DH;
 #pragma unroll
@@ -404,22 +532,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
 
 // dK/dV: workgroup = 128 keys (a wave owns 32 and keeps dK, dV in registers), loops over query tiles
 // (S and dP with the key on the lane; P^T and dS^T feed the dV / dK MFMAs from the accumulators).
+// No masks in the loop: a lane whose key is past kv_len computes garbage that stays in its own output
+// rows (the contraction runs over queries), and those rows are written as zeros; query rows past N carry
+// -LSE = -inf, so their p and dS are exactly 0.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sQ = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]  q x dh
     T* sdO = sQ + KT * LDT;                   // [KT][LDT]
     T* sQt = sdO + KT * LDT;                  // Q image for the transposed role (frag_tr)
     T* sdOt = sQt + tr_elems<T>();             // dO image for the transposed role
-    float* sL = reinterpret_cast<float*>(sdOt + tr_elems<T>());   // [KT] lse (log2 units), +inf past N
-    float* sD = sL + KT;                                     // [KT] delta
+    float* sL = reinterpret_cast<float*>(sdOt + tr_elems<T>());   // [KT] -lse (log2 units), -inf past N
+    float* sD = sL + KT;                                     // [KT] -delta
     const int nkt = (p.N + 127) >> 7;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int kt = w % nkt, bh = w / nkt, hd = bh % p.H, b = bh / p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
-    const bool uniform = kvl <= 0;
+    const bool uniform = kvl <= 0;            // forward = uniform average: p = 1/N (K = 0 below), dS = 0
     if (uniform) kvl = p.N;
     const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
@@ -428,49 +559,89 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
     const float* Db = p.delta + ((size_t)b * p.H + hd) * p.N;
     const int kw0 = kt * 128 + wave * 32;      // first key of this wave
     const int key = kw0 + r;                   // this lane's key (column of S)
-    const bool key_ok = key < kvl;
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+#ifdef MTMP_STAGGER
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(MTMP_STAGGER);
+#endif
     if (kt * 128 < kvl) {                      // workgroup-uniform: keys past kv_len get zero gradients
+        const float c2 = p.scale * LOG2E;
         Frag<T> kf[4], vf[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            kf[c] = frag_keep(frag_load<T>(Kb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), key_ok);
-            vf[c] = frag_keep(frag_load<T>(Vb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), key_ok);
+            kf[c] = frag_keep(frag_scale<T>(frag_load<T>(Kb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
+                              key < kvl && !uniform);
+            vf[c] = frag_keep(frag_load<T>(Vb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), key < kvl);
         }
-        const float c2 = p.scale * LOG2E;
         const int nq = (p.N + KT - 1) / KT;
-        Tile2<T> qreg = tile_fetch<T>(Qb, p.ld_qkv, 0, p.N, tid);
-        Tile2<T> oreg = tile_fetch<T>(dOb, p.ld_do, 0, p.N, tid);
-        float lreg = (tid < KT) ? ((tid < p.N) ? Lb[tid] : INFINITY) : 0.f;
-        float dreg = (tid < KT && tid < p.N) ? Db[tid] : 0.f;
+        TileStream<T> qs, os;
+        qs.init(Qb, p.ld_qkv, p.N, tid);
+        os.init(dOb, p.ld_do, p.N, tid);
+        TileR<T> qreg = qs.fetch(0), oreg = os.fetch(0);
+        // lse / delta of the tile's 64 query rows ride along in wave 0.  The loads are unconditional (clamped
+        // address) and their values are not touched before the put: a guarded load, or any arithmetic on the
+        // loaded value here, makes the compiler wait for it (vmcnt(0): ALL the tile loads just issued) on the
+        // spot, wave 0 then reaches the next barrier a full memory latency late and the other three wait --
+        // 100 of the kernel's 200 us went there.
+        const int lrow = tid & (KT - 1);
+        float lreg = Lb[min(lrow, p.N - 1)], dreg = Db[min(lrow, p.N - 1)];
         for (int it = 0; it < nq; ++it) {
             const int q0 = it * KT;
             __syncthreads();
-            put_rows<T>(sQ, qreg, tid);
-            put_tr(sQt, qreg, tid);
-            put_rows<T>(sdO, oreg, tid);
-            put_tr(sdOt, oreg, tid);
-            if (tid < KT) { sL[tid] = lreg; sD[tid] = dreg; }
+#ifdef MTMP_ABL_NOPUT
+            if (qreg.a.v[0] == (T)12345.f)
+#endif
+            {
+            put_rows_r<T>(sQ, qreg, tid);
+            put_tr_r(sQt, qreg, tid);
+            put_rows_r<T>(sdO, oreg, tid);
+            put_tr_r(sdOt, oreg, tid);
+            }
+            if (tid < KT) {                    // C operands of the score products: -lse (-inf past N), -delta
+                sL[tid] = (q0 + tid < p.N) ? -lreg : -INFINITY;
+                sD[tid] = (q0 + tid < p.N) ? -dreg : 0.f;
+            }
             __syncthreads();
 #ifndef MTMP_DKDV_NOFETCH                      // (ablation builds: tools/ablate_dkdv.sh -- never shipped)
             if (it + 1 < nq) {
-                qreg = tile_fetch<T>(Qb, p.ld_qkv, q0 + KT, p.N, tid);
-                oreg = tile_fetch<T>(dOb, p.ld_do, q0 + KT, p.N, tid);
-                if (tid < KT) {
-                    lreg = (q0 + KT + tid < p.N) ? Lb[q0 + KT + tid] : INFINITY;
-                    dreg = (q0 + KT + tid < p.N) ? Db[q0 + KT + tid] : 0.f;
-                }
+                qreg = qs.fetch(it + 1);
+                oreg = os.fetch(it + 1);
+                const int qn = min(q0 + KT + lrow, p.N - 1);
+                lreg = Lb[qn];
+                dreg = Db[qn];
             }
 #endif
+#ifdef MTMP_ABL_NOCOMPUTE
+            if (kw0 < kvl && lreg == 12345.678f) {
+#else
             if (kw0 < kvl) {                   // wave-uniform
+#endif
+                // A 64-query tile = two 32-query blocks, software-pipelined INSIDE the wave so that the matrix pipe
+                // and the vector ALU run side by side (one wave's chain  reads -> S,dP -> exp/mul -> dV,dK  is serial,
+                // and two waves per SIMD do not cover it: with the blocks done one after the other every unit sat at
+                // 40-50 %):
+                //   phase 0:  S,dP(block 0)                          8 MFMA   (+ LDS reads of block 1's operands)
+                //   phase 1:  S,dP(block 1)  ||  exp/mul/cvt(block 0)  8 MFMA beside 48 VALU
+                //   phase 2:  dV,dK(block 0) ||  exp/mul/cvt(block 1)  8 MFMA beside 48 VALU
+                //   phase 3:  dV,dK(block 1)                         8 MFMA
+                // sched_group_barrier lays the instruction order out (1 MFMA : 2 transcendental : 4 VALU per gap =
+                // 32 issue cycles beside a 32-cycle MFMA); sched_barrier(0) fences the phases.
+                auto load_rowconst = [&](int qb, f32x16& cL, f32x16& cD) {   // row t = query 32qb + 16(t>>3) + 8half + (t&7)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    // Everything this query block reads from LDS is requested up front: the 8 transposed fragments of
-                    // the dV / dK products and the lse / delta of its 16 + 16 query rows as four 16-byte reads each.
-                    // (Ablations, tools/ablate_dkdv.sh: 64 scalar ds_read_b32 of lse/delta per tile cost 94 us of a
-                    //  439 us backward, and transposed reads issued right in front of their MFMA another ~140 us of
-                    //  exposed LDS latency; exp2 and the global loads cost nothing.)
-                    Frag<T> trf[2][4];
+                    for (int h8 = 0; h8 < 2; ++h8)
+#pragma unroll
+                        for (int v = 0; v < 2; ++v) {
+                            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 32 * qb + 16 * h8 + 8 * half + 4 * v);
+                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 32 * qb + 16 * h8 + 8 * half + 4 * v);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { cL[8 * h8 + 4 * v + i] = l4[i]; cD[8 * h8 + 4 * v + i] = d4[i]; }
+                        }
+                };
+                auto load_rows = [&](int qb, Frag<T> (&qa)[4], Frag<T> (&oa)[4]) {
+                    const int ro = (32 * qb + swz23(r)) * LDT + 8 * half;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { qa[c] = frag_load<T>(sQ + ro + 16 * c); oa[c] = frag_load<T>(sdO + ro + 16 * c); }
+                };
+                auto load_tr = [&](int qb, Frag<T> (&trf)[2][4]) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const int q16 = 32 * qb + 16 * s;
@@ -479,59 +650,113 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
                         trf[s][2] = frag_tr(sQt, q16, 0, lane);
                         trf[s][3] = frag_tr(sQt, q16, 32, lane);
                     }
-                    float lq[16], dq_[16];         // row t of the accumulators = query 32qb + 16(t>>3) + 8half + (t&7)
+                };
+                auto scores = [&](f32x16& st, f32x16& ds, const f32x16& cL, const f32x16& cD, const Frag<T> (&qa)[4],
+                                  const Frag<T> (&oa)[4]) {
+                    st = mma_c<T>(qa[0], kf[0], cL);
+                    ds = mma_c<T>(oa[0], vf[0], cD);
 #pragma unroll
-                    for (int h8 = 0; h8 < 2; ++h8)
-#pragma unroll
-                        for (int v = 0; v < 2; ++v) {
-                            const f32x4 l4 = *reinterpret_cast<const f32x4*>(sL + 32 * qb + 16 * h8 + 8 * half + 4 * v);
-                            const f32x4 d4 = *reinterpret_cast<const f32x4*>(sD + 32 * qb + 16 * h8 + 8 * half + 4 * v);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { lq[8 * h8 + 4 * v + i] = l4[i]; dq_[8 * h8 + 4 * v + i] = d4[i]; }
-                        }
-                    f32x16 st = {0}, dp = {0};
-                    if (!uniform) tile_qk<T>(st, sQ + 32 * qb * LDT, r, half, kf);
-                    tile_qk<T>(dp, sdO + 32 * qb * LDT, r, half, vf);
-                    f32x16 ds;
+                    for (int c = 1; c < 4; ++c) { mma<T>(st, qa[c], kf[c]); mma<T>(ds, oa[c], vf[c]); }
+                };
+                auto probs = [&](f32x16& st, f32x16& ds, Frag<T> (&pf)[2], Frag<T> (&dsf)[2]) {
 #pragma unroll
                     for (int t = 0; t < 16; ++t) {
-                        // uniform case: st == 0 and the forward stored lse = log2(N), so pv = 1/N
-                        const float pv = key_ok ? fast_exp2(fmaf(st[t], c2, -lq[t])) : 0.f;
+                        const float pv = fast_exp2(st[t]);
                         st[t] = pv;
-                        ds[t] = uniform ? 0.f : pv * (dp[t] - dq_[t]);
+                        ds[t] *= pv;
                     }
 #pragma unroll
+                    for (int s = 0; s < 2; ++s) { pf[s] = frag_from_acc<T>(st, s); dsf[s] = frag_from_acc<T>(ds, s); }
+                };
+                auto grads = [&](const Frag<T> (&pf)[2], const Frag<T> (&dsf)[2], const Frag<T> (&trf)[2][4]) {
+#pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const Frag<T> pf = frag_from_acc<T>(st, s);
-                        const Frag<T> dsf = frag_from_acc<T>(ds, s);
-                        mma<T>(dv0, pf, trf[s][0]);
-                        mma<T>(dv1, pf, trf[s][1]);
-                        mma<T>(dk0, dsf, trf[s][2]);
-                        mma<T>(dk1, dsf, trf[s][3]);
+                        mma<T>(dv0, pf[s], trf[s][0]);
+                        mma<T>(dv1, pf[s], trf[s][1]);
+                        mma<T>(dk0, dsf[s], trf[s][2]);
+                        mma<T>(dk1, dsf[s], trf[s][3]);
                     }
+                };
+                f32x16 st0, ds0, st1, ds1, cL1, cD1;
+                Frag<T> qa1[4], oa1[4], pf0[2], dsf0[2], pf1[2], dsf1[2];
+                {   // phase 0
+                    f32x16 cL0, cD0;
+                    Frag<T> qa0[4], oa0[4];
+                    load_rowconst(0, cL0, cD0);
+                    load_rows(0, qa0, oa0);
+                    load_rowconst(1, cL1, cD1);
+                    load_rows(1, qa1, oa1);
+                    scores(st0, ds0, cL0, cD0, qa0, oa0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // phase 1
+                    scores(st1, ds1, cL1, cD1, qa1, oa1);
+                    probs(st0, ds0, pf0, dsf0);
+                    if (sizeof(T) == 2) {
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // phase 2
+                    Frag<T> trf0[2][4];
+                    load_tr(0, trf0);
+                    grads(pf0, dsf0, trf0);
+                    probs(st1, ds1, pf1, dsf1);
+                    if (sizeof(T) == 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);     // under the LDS latency
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+#pragma unroll
+                        for (int g = 0; g < 8; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (g < 6) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                            if (g < 6) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // phase 3
+                    Frag<T> trf1[2][4];
+                    load_tr(1, trf1);
+                    grads(pf1, dsf1, trf1);
                 }
             }
         }
     }
-    // rows = keys (registers), cols = dh (lanes)
+    // rows = keys (registers), cols = dh (lanes); keys past kv_len (and the whole dK of a fully masked
+    // sample) are written as zeros
     const size_t obase = (size_t)b * p.N * p.ld_dqkv + hd * DH;
+    const float kscale = uniform ? 0.f : p.scale;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int krow = kw0 + acc_row(t, half);
+#ifdef MTMP_ABL_NOSTORE
+        if (krow < p.N && dk0[t] == 12345.678f) {
+#else
         if (krow < p.N) {
+#endif
+            const bool live = krow < kvl;
             T* dkp = p.dk + obase + (size_t)krow * p.ld_dqkv;
             T* dvp = p.dv + obase + (size_t)krow * p.ld_dqkv;
-            dkp[r] = from_f32<T>(dk0[t] * p.scale);
-            dkp[32 + r] = from_f32<T>(dk1[t] * p.scale);
-            dvp[r] = from_f32<T>(dv0[t]);
-            dvp[32 + r] = from_f32<T>(dv1[t]);
+            dkp[r] = from_f32<T>(live && !uniform ? dk0[t] * kscale : 0.f);
+            dkp[32 + r] = from_f32<T>(live && !uniform ? dk1[t] * kscale : 0.f);
+            dvp[r] = from_f32<T>(live ? dv0[t] : 0.f);
+            dvp[32 + r] = from_f32<T>(live ? dv1[t] : 0.f);
         }
     }
 }
 
-template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T); }
-template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T); }
-template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float); }
+#ifndef MTMP_LDS_PAD          // (occupancy experiments only: extra dynamic LDS per workgroup)
+#define MTMP_LDS_PAD 0
+#endif
+template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T) + MTMP_LDS_PAD; }
+template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T) + MTMP_LDS_PAD; }
+template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float) + MTMP_LDS_PAD; }
 
 template <typename K> int set_smem(K kern, size_t bytes) {
     if (bytes > 48 * 1024) {

@@ -99,7 +99,20 @@ template <> MTMP_DEV f32x16 mma0<float>(const Frag<float>& a, const Frag<float>&
     for (int u = 1; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u], b.v[u], acc, 0, 0, 0);
     return acc;
 }
-// max of three as ONE v_max3_f32 (fmaxf() on MFMA outputs costs an extra canonicalising v_max each)
+// acc = A*B + C with C left untouched (the destination is a different register block)
+template <typename T> MTMP_DEV f32x16 mma_c(const Frag<T>& a, const Frag<T>& b, const f32x16& c);
+template <> MTMP_DEV f32x16 mma_c<bf16>(const Frag<bf16>& a, const Frag<bf16>& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+template <> MTMP_DEV f32x16 mma_c<float>(const Frag<float>& a, const Frag<float>& b, const f32x16& c) {
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[0], b.v[0], c, 0, 0, 0);
+#pragma unroll
+    for (int u = 1; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[u], b.v[u], acc, 0, 0, 0);
+    return acc;
+}
+// max of three as ONE v_max3_f32 (fmaxf() on MFMA outputs costs an extra canonicalising v_max each).
+// CAUTION: inline asm is invisible to the compiler's hazard recogniser -- never let it be the first reader
+// of an MFMA (or permlane-swap) result; see the forward attention kernel for the guard pattern.
 MTMP_DEV float max3(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
