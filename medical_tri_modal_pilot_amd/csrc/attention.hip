@@ -41,9 +41,6 @@ __device__ unsigned long long g_stamp[8];
 
 namespace {
 
-#ifndef MTMP_FWD_OCC
-#define MTMP_FWD_OCC 3
-#endif
 constexpr int DH = 64;       // head dim: d_model 256 / 4 heads (tri_mbt_vsltcls.py:29-30)
 constexpr int KT = 64;       // rows per LDS tile
 constexpr int LDT = DH + 8;  // padded LDS row, elements (keeps 16-byte alignment, spreads banks)
@@ -59,8 +56,9 @@ template <typename T> struct AttnArgs {
 
 // ---- LDS staging of a 64-row x 64-col tile by 256 threads, split into FETCH (global ->
 // registers, issued one tile ahead so the loads fly under the MFMAs of the current tile) and
-// PUT (registers -> LDS, after the barrier).  Rows >= limit are zero (masked at PUT time, so
-// the loads carry no use while in flight).
+// PUT (registers -> LDS, after the barrier).  Full tiles are fetched through running pointers; rows
+// of a ragged last tile are clamped to the last valid row (never read past it) and made inert by the
+// kernels' masks / row constants.
 //
 // A tile is needed in two roles: as ROW operand (fragment = 8 consecutive columns of one row:
 // ds_read_b128 from a row-major image, stride LDT) and as TRANSPOSED operand (fragment = 8
@@ -98,24 +96,36 @@ MTMP_DEV Frag<float> frag_tr(const float* img, int row0, int col0, int lane) {
     return frag_load<float>(img + (col0 + (lane & 31)) * LDT + row0 + 8 * (lane >> 5));
 }
 
+// 32x32 tile: acc += A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
+template <typename T>
+MTMP_DEV void tile_qk(f32x16& acc, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
+    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
+    acc = mma0<T>(frag_load<T>(arow), bf[0]);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) mma<T>(acc, frag_load<T>(arow + 16 * c), bf[c]);
+}
+
+// max over the two half-waves (lane i <-> lane i + 32) without the LDS crossbar: v_permlane32_swap
+MTMP_DEV float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+MTMP_DEV float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // =============================== forward ====================================
-// Forward loop, per 64-key tile and wave (32 queries, query = lane):
-//   S'^T = K (c2 Q)^T + (-m)      8 MFMA; the running maximum enters as the MFMA's C operand and the
-//                                 softmax scale c2 = scale*log2(e) is folded into Q once per workgroup,
-//                                 so the scores leave the matrix pipe ready for exp2 (no per-score fma)
-//   row max (v_max3), rescale decision (wave-uniform, rare after the first tiles), exp2, row sum
-//   O^T += V^T P^T                8 MFMA, P^T straight from the accumulator registers
-// The kernel is VALU-issue-bound at d_h = 64 (MI355X_MICROARCH 'vector-instruction ISSUE cost': per score
-// exp 8 + add 4 + max 2 + cvt 2.25 cycles against 16 cycles of matrix pipe), so the loop carries no masks,
-// clamps or address arithmetic: full tiles run a mask-free body, the ragged last tile a second copy of it.
+// Per 64-key tile and wave (32 queries, query = lane):  S^T = K Q^T (8 MFMA), row max (v_max3), rescale
+// decision (wave-uniform, rare after the first tiles), p = exp2(s*c2 - m), row sum, O^T += V^T P^T (8 MFMA,
+// P^T straight from the accumulator registers).  The kernel is VALU-issue-bound at d_h = 64 (per score:
+// fma 4 + exp 8 + add 4 + max 2 + cvt 2.25 issue cycles against 16 cycles of matrix pipe, PMC: vector issue
+// ~60 %, MFMA ~30 % busy), so the loop carries no masks, clamps or address arithmetic: full tiles run a
+// mask-free body on running pointers, the ragged last tile a second copy of the body.
+// (Measured and rejected here: the running maximum as the C operand of the score MFMAs -- saves the fma but
+//  its 16 registers cost the fourth wave per SIMD: 116-121 us against 107; 256-query workgroups with two
+//  query blocks per wave software-pipelined against each other, double-buffered LDS: 128 us.)
 template <typename T> struct TileR { Frag<T> a, b; };
 
-template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
-    Frag<T> r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
-    return r;
-}
 template <typename T> MTMP_DEV void put_rows_r(T* dst, const TileR<T>& t, int tid) {
     int ra, rb, col;
     tile_map<T>(tid, ra, rb, col);
@@ -133,32 +143,8 @@ MTMP_DEV void put_tr_r(float* dst, const TileR<float>& t, int tid) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(d + e * LDT) = f32x2{t.a.v[e], t.b.v[e]};
 }
-// max over the two half-waves (lane i <-> lane i + 32) without the LDS crossbar: v_permlane32_swap
-#ifdef MTMP_NO_SWAP
-MTMP_DEV float half_max(float x) { return fmaxf(x, __shfl_xor(x, 32, 64)); }
-MTMP_DEV float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
-#else
-MTMP_DEV float half_max(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-MTMP_DEV float half_sum(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-#endif
-// 32x32 tile: C + A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
 template <typename T>
-MTMP_DEV f32x16 tile_qk_c(const f32x16& c, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
-    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
-    f32x16 acc = mma_c<T>(frag_load<T>(arow), bf[0], c);     // D != C: no copy of the shared C registers
-#pragma unroll
-    for (int cc = 1; cc < 4; ++cc) mma<T>(acc, frag_load<T>(arow + 16 * cc), bf[cc]);
-    return acc;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
     T* sVt = sK + KT * LDT;                   // V image for the transposed role (frag_tr)
@@ -175,21 +161,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
     const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int qrow = qt * 128 + wave * 32 + r;
-    const float c2 = p.scale * LOG2E;
     Frag<T> qf[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        qf[c] = frag_keep(frag_scale<T>(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
+        qf[c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half),
                           qrow < p.N && !uniform);
     f32x16 o0 = {0}, o1 = {0};
-    f32x16 negm = {0};                         // -m in every register: the C operand of the score MFMAs
-    float m = 0.f, l = 0.f;
-    bool first = true;
+    float m = -INFINITY, l = 0.f;
+    const float c2 = p.scale * LOG2E;
     const int nfull = kvl / KT, ntiles = (kvl + KT - 1) / KT;
     int ra, rb, col;
     tile_map<T>(tid, ra, rb, col);
     const size_t tstep = (size_t)KT * p.ld_qkv;
-    const T* kpa = Kb + (size_t)ra * p.ld_qkv + col;     // this thread's two rows of the NEXT tile to fetch
+    const T* kpa = Kb + (size_t)ra * p.ld_qkv + col;     // this thread's two rows of the NEXT full tile to fetch
     const T* kpb = Kb + (size_t)rb * p.ld_qkv + col;
     const ptrdiff_t kv_off = Vb - Kb;
     TileR<T> kreg, vreg;
@@ -221,36 +205,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
 #ifndef MTMP_ABLATE_FETCH                      // (ablation builds: tools/ablate_attn.sh -- never shipped)
         if (it + 1 < ntiles) fetch(it + 1);
 #endif
-        // All eight K fragments are requested before the first MFMA (a read issued right in front of its
-        // MFMA exposes the whole LDS latency, ~100+ cycles against a 32-cycle MFMA), and the eight V^T
-        // fragments right behind the score MFMAs, so that they land under the softmax arithmetic; the two
-        // sets share registers.  sched_barrier pins that order against the compiler's scheduler.
-        Frag<T> kfr[2][4];
-        {
-            const T* arow = sK + swz23(r) * LDT + 8 * half;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) kfr[kb][c] = frag_load<T>(arow + 32 * kb * LDT + 16 * c);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         f32x16 st[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            st[kb] = mma_c<T>(kfr[kb][0], qf[0], negm);
-#pragma unroll
-            for (int c = 1; c < 4; ++c) mma<T>(st[kb], kfr[kb][c], qf[c]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        Frag<T> vfr[2][2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                vfr[kb][s][0] = frag_tr(sVt, 32 * kb + 16 * s, 0, lane);
-                vfr[kb][s][1] = frag_tr(sVt, 32 * kb + 16 * s, 32, lane);
-            }
-        __builtin_amdgcn_sched_barrier(0);
+        tile_qk<T>(st[0], sK, r, half, qf);
+        tile_qk<T>(st[1], sK + 32 * LDT, r, half, qf);
         if (TAIL) {
             const int k0 = it * KT;
 #pragma unroll
@@ -272,27 +229,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
             mxa = max3(mxa, st[0][t], st[0][t + 1]);
             mxb = max3(mxb, st[1][t], st[1][t + 1]);
         }
-        const float mx = half_max(max3(mxa, mxb, fmaxf(st[0][14], st[1][14])));
-        // Deferred rescale (exact): mx is the tile's maximum RELATIVE to the running one.  O, l and m move
-        // only when some row's maximum grew (wave-uniform branch, rare after the first tiles); while it has
-        // not, p = exp2(s') <= 1 holds.  The first tile always takes the branch and sets m to its true maximum.
-        if (first || !wave_all(mx <= 0.f)) {
-            const float d = first ? mx : fmaxf(mx, 0.f);
-            const float alpha = first ? 1.f : fast_exp2(-d);
+        const float mx = half_max(max3(mxa, mxb, fmaxf(st[0][14], st[1][14]))) * c2;
+        // Deferred rescale (exact): O, l and m move only when some row's maximum grew; while it has
+        // not, p = exp2(s - m) <= 1 still holds.  Wave-uniform branch, rare after the first tiles.
+        if (!wave_all(mx <= m)) {
+            const float m_new = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - m_new);
             l *= alpha; o0 *= alpha; o1 *= alpha;
-            m += d;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) { negm[t] = -m; st[0][t] -= d; st[1][t] -= d; }
-            first = false;
+            m = m_new;
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
 #ifdef MTMP_ABLATE_EXP
-                const float pv = st[kb][t];
+                const float pv = fmaf(st[kb][t], c2, -m);
 #else
-                const float pv = fast_exp2(st[kb][t]);
+                const float pv = fast_exp2(fmaf(st[kb][t], c2, -m));
 #endif
                 l += pv;
                 st[kb][t] = pv;
@@ -303,8 +256,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const Frag<T> pf = frag_from_acc<T>(st[kb], s);
-                mma<T>(o0, vfr[kb][s][0], pf);
-                mma<T>(o1, vfr[kb][s][1], pf);
+                mma<T>(o0, frag_tr(sVt, 32 * kb + 16 * s, 0, lane), pf);
+                mma<T>(o1, frag_tr(sVt, 32 * kb + 16 * s, 32, lane), pf);
             }
         STAMP(ts4)
         STAMP_ACC
@@ -361,6 +314,48 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
     if (qrow < p.N && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m + log2f(l);
 }
 
+// ---- helpers of the backward kernels ----
+
+template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
+    Frag<T> r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
+    return r;
+}
+// 32x32 tile: C + A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
+template <typename T>
+MTMP_DEV f32x16 tile_qk_c(const f32x16& c, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
+    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
+    f32x16 acc = mma_c<T>(frag_load<T>(arow), bf[0], c);     // D != C: no copy of the shared C registers
+#pragma unroll
+    for (int cc = 1; cc < 4; ++cc) mma<T>(acc, frag_load<T>(arow + 16 * cc), bf[cc]);
+    return acc;
+}
+
+// One thread's share (2 x 16 bytes) of a stream of 64-row x 64-column tiles over rows [0, limit) of a
+// [limit][ld] matrix.  Full tiles are fetched through two running pointers (no address arithmetic in the
+// loop); the ragged last tile clamps its rows to limit - 1 (a finite stand-in row; the kernels make such
+// rows inert through their row constants or masks, never by reading past `limit`).
+template <typename T> struct TileStream {
+    const T* base; const T* pa; const T* pb;
+    size_t step; int ld, limit, ra, rb, col, nfull;
+    MTMP_DEV void init(const T* src, int ld_, int limit_, int tid) {
+        tile_map<T>(tid, ra, rb, col);
+        base = src; ld = ld_; limit = limit_; nfull = limit_ / KT; step = (size_t)KT * ld_;
+        pa = src + (size_t)ra * ld_ + col; pb = src + (size_t)rb * ld_ + col;
+    }
+    MTMP_DEV TileR<T> fetch(int t) {                 // t must run 0, 1, 2, ... (running pointers)
+        TileR<T> x;
+        if (t < nfull) {
+            x.a = frag_load<T>(pa); x.b = frag_load<T>(pb);
+            pa += step; pb += step;
+        } else {
+            x.a = frag_load<T>(base + (size_t)min(t * KT + ra, limit - 1) * ld + col);
+            x.b = frag_load<T>(base + (size_t)min(t * KT + rb, limit - 1) * ld + col);
+        }
+        return x;
+    }
+};
 // =============================== backward ===================================
 template <typename T> struct AttnBwdArgs {
     const T* q; const T* k; const T* v; const T* d_o;
@@ -388,30 +383,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* d_
     }
 }
 
-// One thread's share (2 x 16 bytes) of a stream of 64-row x 64-column tiles over rows [0, limit) of a
-// [limit][ld] matrix.  Full tiles are fetched through two running pointers (no address arithmetic in the
-// loop); the ragged last tile clamps its rows to limit - 1 (a finite stand-in row; the kernels make such
-// rows inert through their row constants or masks, never by reading past `limit`).
-template <typename T> struct TileStream {
-    const T* base; const T* pa; const T* pb;
-    size_t step; int ld, limit, ra, rb, col, nfull;
-    MTMP_DEV void init(const T* src, int ld_, int limit_, int tid) {
-        tile_map<T>(tid, ra, rb, col);
-        base = src; ld = ld_; limit = limit_; nfull = limit_ / KT; step = (size_t)KT * ld_;
-        pa = src + (size_t)ra * ld_ + col; pb = src + (size_t)rb * ld_ + col;
-    }
-    MTMP_DEV TileR<T> fetch(int t) {                 // t must run 0, 1, 2, ... (running pointers)
-        TileR<T> x;
-        if (t < nfull) {
-            x.a = frag_load<T>(pa); x.b = frag_load<T>(pb);
-            pa += step; pb += step;
-        } else {
-            x.a = frag_load<T>(base + (size_t)min(t * KT + ra, limit - 1) * ld + col);
-            x.b = frag_load<T>(base + (size_t)min(t * KT + rb, limit - 1) * ld + col);
-        }
-        return x;
-    }
-};
 // rows >= limit - row0 of a fetched tile -> 0 (ragged key tiles of the dQ kernel)
 template <typename T> MTMP_DEV TileR<T> tile_zero_rows(const TileR<T>& x, int row0, int limit, int tid) {
     int ra, rb, col;
@@ -560,9 +531,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     const int kw0 = kt * 128 + wave * 32;      // first key of this wave
     const int key = kw0 + r;                   // this lane's key (column of S)
     f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-#ifdef MTMP_STAGGER
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(MTMP_STAGGER);
-#endif
     if (kt * 128 < kvl) {                      // workgroup-uniform: keys past kv_len get zero gradients
         const float c2 = p.scale * LOG2E;
         Frag<T> kf[4], vf[4];
@@ -587,15 +555,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
         for (int it = 0; it < nq; ++it) {
             const int q0 = it * KT;
             __syncthreads();
-#ifdef MTMP_ABL_NOPUT
-            if (qreg.a.v[0] == (T)12345.f)
-#endif
-            {
             put_rows_r<T>(sQ, qreg, tid);
             put_tr_r(sQt, qreg, tid);
             put_rows_r<T>(sdO, oreg, tid);
             put_tr_r(sdOt, oreg, tid);
-            }
             if (tid < KT) {                    // C operands of the score products: -lse (-inf past N), -delta
                 sL[tid] = (q0 + tid < p.N) ? -lreg : -INFINITY;
                 sD[tid] = (q0 + tid < p.N) ? -dreg : 0.f;
@@ -610,11 +573,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
                 dreg = Db[qn];
             }
 #endif
-#ifdef MTMP_ABL_NOCOMPUTE
-            if (kw0 < kvl && lreg == 12345.678f) {
-#else
             if (kw0 < kvl) {                   // wave-uniform
-#endif
                 // A 64-query tile = two 32-query blocks, software-pipelined INSIDE the wave so that the matrix pipe
                 // and the vector ALU run side by side (one wave's chain  reads -> S,dP -> exp/mul -> dV,dK  is serial,
                 // and two waves per SIMD do not cover it: with the blocks done one after the other every unit sat at
@@ -735,11 +694,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int krow = kw0 + acc_row(t, half);
-#ifdef MTMP_ABL_NOSTORE
-        if (krow < p.N && dk0[t] == 12345.678f) {
-#else
         if (krow < p.N) {
-#endif
             const bool live = krow < kvl;
             T* dkp = p.dk + obase + (size_t)krow * p.ld_dqkv;
             T* dvp = p.dv + obase + (size_t)krow * p.ld_dqkv;
@@ -751,12 +706,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     }
 }
 
-#ifndef MTMP_LDS_PAD          // (occupancy experiments only: extra dynamic LDS per workgroup)
-#define MTMP_LDS_PAD 0
-#endif
-template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T) + MTMP_LDS_PAD; }
-template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T) + MTMP_LDS_PAD; }
-template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float) + MTMP_LDS_PAD; }
+template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T); }
+template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T); }
+template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float); }
 
 template <typename K> int set_smem(K kern, size_t bytes) {
     if (bytes > 48 * 1024) {
