@@ -77,6 +77,11 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hip-graph", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--workload", default="full", choices=["full", "ragged"],
+                    help="full = BASELINE configs[1] (every series at TIE-len, all modalities; the headline number); "
+                         "ragged = configs[3] shape: len ~ U{3..T}, mixed missing modalities (SURVEY 8d)")
+    ap.add_argument("--packed", type=int, default=0, choices=[0, 1],
+                    help="feed the vital-sign events as the ragged PackedTieBatch of builder/data (SURVEY 8 f-1)")
     ap.add_argument("--probe-steps", type=int, default=5, help="eager steps after the timed region that time "
                     "the roofline kernel with HIP events (only when the timed region replays a hipGraph)")
     a = ap.parse_args()
@@ -130,10 +135,16 @@ def main():
         def log_lr(self, *_):
             pass
 
-    bt = filler.make_batch(1234 + rank, B_PER_GPU, TIE_LEN, ragged=False, missing_mode="none")
+    ragged = a.workload == "ragged"
+    bt = filler.make_batch(1234 + rank, B_PER_GPU, TIE_LEN, ragged=ragged, missing_mode="mixed" if ragged else "none")
     d = {k: v.to(dev) for k, v in bt.items() if k != "missing"}
     static = torch.stack([d["gen"], d["age"]], 1)
-    kw = dict(args=args, x=d["x"], static=static, y=d["y"], output_lengths=None, model=model, logger=Log(),
+    x_in = d["x"]
+    if a.packed:
+        from medical_tri_modal_pilot_amd.builder.data import collate_packed
+        x_in = collate_packed([(bt["x"][b, :int(n)].numpy(), static[b].cpu().numpy(), float(bt["txt_time"][b]))
+                               for b, n in enumerate(bt["input_lengths"])])
+    kw = dict(args=args, x=x_in, static=static, y=d["y"], output_lengths=None, model=model, logger=Log(),
               device=dev, scheduler=sched, optimizer=opt, criterion=crit, x_txt=d["txt"], x_img=d["img"],
               imgtxt_time=(d["img_time"], d["txt_time"]), scaler=None, missing=bt["missing"], flow_type="train",
               reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
@@ -230,9 +241,12 @@ def main():
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
-            "config": {"workload": "BASELINE configs[1]: vslt_img_txt tri_mbt_vsltcls, 6 layers, d_model 256, "
-                                   "batch 64/GPU, TIE-len 1000 (N_v=1005), 224x224 CXR, 128-tok text, "
-                                   f"dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1",
+            "config": {"workload": ("BASELINE configs[1]: vslt_img_txt tri_mbt_vsltcls, 6 layers, d_model 256, "
+                                    "batch 64/GPU, TIE-len 1000 (N_v=1005), 224x224 CXR, 128-tok text, "
+                                    f"dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1")
+                                   + (" -- RAGGED variant (configs[3] shape): len ~ U{3..1000}, mixed missing modalities;"
+                                      " roofline flops still count the dense N^2" if ragged else "")
+                                   + (" -- events fed as PackedTieBatch" if a.packed else ""),
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel<bf16> (vslt stream, N=1005)" if a.dtype == "bf16"
                          else "attn_fwd_kernel<float>", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,

@@ -103,6 +103,16 @@ int mtmp_tie_bwd_ws_floats(int n);
 int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
                        float* ws, int n, void* stream);
 
+/* The same on the PACKED (ragged) batch layout of the collate (replaces the zero-padded
+ * [B, TIE_len, 3] tensor of dataset_new.py:2177 + the [:, :max_len] trim of trainer.py:41-42):
+ * events float[cu[B]][3] back to back, cu_seqlens int32[B+1] (device), out / d_out [B, t_pad, 256];
+ * output rows past a sample's length are zero and receive no gradient.
+ * ws: mtmp_tie_bwd_ws_floats(B * t_pad) floats. */
+int mtmp_tie_embed_packed_fwd(int dtype, const float* events, const int32_t* cu_seqlens, int B, int t_pad,
+                              const float* params, const float* ftab, void* out, void* stream);
+int mtmp_tie_embed_packed_bwd(int dtype, const float* events, const int32_t* cu_seqlens, int B, int t_pad,
+                              const float* params, const void* d_out, float* grads, float* ws, void* stream);
+
 /* Swin-T patch-embedding stem: Conv2d(1,96,4,stride 4) -> NHWC -> LayerNorm(96)
  * (builder/models/src/swin_transformer.py:559-567,646) as an implicit GEMM.
  * img float[n_img,1,H,W]; out [n_img,H/4,W/4,96] in `dtype`. */

@@ -15,7 +15,10 @@ Differences, all required to run off-CUDA-autocast and on any device:
 """
 import torch
 
+from medical_tri_modal_pilot_amd.builder.data.tie_dataset import PackedTie, PackedTieBatch
+
 GRAPH_LEN_BUCKET = 128
+GRAPH_EVENT_BUCKET = 4096       # packed batches: the event count is rounded up to this for hipGraph replays
 
 _TEMPLATE = {
     3: [[0., 0., 0.], [0., 0., 1.], [0., 1., 0.], [0., 1., 1.]],
@@ -49,15 +52,24 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
     img_time, txt_time = imgtxt_time
     img_time = img_time.half().float().to(device, non_blocking=True)          # fp16 rounding, trainer.py:26-27
     txt_time = txt_time.half().float().to(device, non_blocking=True)
-    if args.vslt_type == "carryforward":
+    cu_seqlens = None
+    if isinstance(train_x, PackedTieBatch):
+        # Ragged batch (builder/data): the events travel packed, there is nothing to trim; the padded
+        # row count of the stream buffers is the batch maximum (bucketed for graph replays like the trim below).
+        graphed = _use_graph(args, flow_type, device, optimizer, scaler)
+        max_len = int(torch.max(input_lengths))
+        if graphed:
+            max_len = min(int(args.TIE_len), -(-max_len // GRAPH_LEN_BUCKET) * GRAPH_LEN_BUCKET)
+        pk = train_x.on_device(device, max_len, GRAPH_EVENT_BUCKET if graphed else 0)   # fp16 rounding inside
+        data, cu_seqlens, t_pad = pk.events, pk.cu_seqlens, pk.t_pad
+    elif args.vslt_type == "carryforward":
         train_x = train_x.permute(1, 0, 2, 3)
-        data = train_x[0]
+        data = train_x[0].half().float().to(device, non_blocking=True)
     else:
         max_len = int(torch.max(input_lengths))                               # ragged trim, trainer.py:41-42
         if _use_graph(args, flow_type, device, optimizer, scaler):
             max_len = min(train_x.shape[1], -(-max_len // GRAPH_LEN_BUCKET) * GRAPH_LEN_BUCKET)
-        data = train_x[:, :max_len, :]
-    data = data.half().float().to(device, non_blocking=True)                  # 2_train.py:164
+        data = train_x[:, :max_len, :].half().float().to(device, non_blocking=True)   # 2_train.py:164
     if "rmse" in args.auxiliary_loss_type:
         final_target = train_y[0].float().to(device, non_blocking=True)
     else:
@@ -79,12 +91,17 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
     txt_lengths = txt_lengths.to(device, non_blocking=True)
     feasible = None if output_lengths is None else output_lengths.type(torch.IntTensor).to(device, non_blocking=True)
 
+    packed_extra = {}
+    if cu_seqlens is not None:       # t_pad rides in the graph signature as the shape of an empty tensor
+        packed_extra = dict(cu_seqlens=cu_seqlens, t_pad_marker=torch.empty(t_pad, 0, device=device))
+
     def run_model(t=None):
         if t is None:
             t = dict(data=data, age=age, gender=gender, input_lengths=input_lengths, x_txt=x_txt,
                      txt_lengths=txt_lengths, x_img=x_img, missing_num=missing_num, img_time=img_time,
-                     txt_time=txt_time)
-        out, _, _ = model(t["data"], None, None, None, None, t["age"], t["gender"], t["input_lengths"], t["x_txt"],
+                     txt_time=txt_time, **packed_extra)
+        x_in = t["data"] if "cu_seqlens" not in t else PackedTie(t["data"], t["cu_seqlens"], t["t_pad_marker"].shape[0])
+        out, _, _ = model(x_in, None, None, None, None, t["age"], t["gender"], t["input_lengths"], t["x_txt"],
                           t["txt_lengths"], t["x_img"], t["missing_num"], feasible, t["img_time"], t["txt_time"],
                           flow_type, reports_tokens, reports_lengths)
         return out.squeeze()
@@ -106,7 +123,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
 
         loss = gs.run(dict(data=data, age=age, gender=gender, input_lengths=input_lengths, x_txt=x_txt,
                            txt_lengths=txt_lengths, x_img=x_img, missing_num=missing_num, img_time=img_time,
-                           txt_time=txt_time, final_target=final_target), fwd_bwd, optimizer.flat.params)
+                           txt_time=txt_time, final_target=final_target, **packed_extra), fwd_bwd, optimizer.flat.params)
         optimizer.step()
         scheduler.step(iteration)
         logger.log_lr(scheduler.get_lr()[0], iteration)

@@ -145,18 +145,36 @@ MTMP_DEV void tie_chain_fwd(const TieChain& c, float s, float (&y)[4], float (&x
     for (int i = 0; i < 4; ++i) { xh[i] = (u[i] - mu) * rstd; y[i] = fmaf(xh[i], c.g[i], c.be[i]); }
 }
 
+// Row map of the PACKED event layout (the ragged collate): the batch's events are stored back to
+// back, events[cu[b] .. cu[b+1]) belong to sample b, and the embeddings go to the padded [B, t_pad, 256]
+// stream layout the fusion stack reads.  Output row (b, t) takes event cu[b] + t when t < cu[b+1] - cu[b]
+// and is zero otherwise (a pad row: masked as a key by kv_len, its own output is never read).  With
+// cu == nullptr the layout is the reference's padded [n, 3]: row == event.
+MTMP_DEV int tie_event_of_row(const int* cu, int t_pad, int row) {
+    if (!cu) return row;
+    const int b = row / t_pad, t = row - b * t_pad;
+    const int lo = cu[b], hi = cu[b + 1];
+    return t < hi - lo ? lo + t : -1;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void tie_fwd_kernel(const float* ev, const float* prm, const float* ftab, T* out, int n) {
+__global__ __launch_bounds__(256) void tie_fwd_kernel(const float* ev, const float* prm, const float* ftab, T* out, int n,
+                                                      const int* cu, int t_pad) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const TieChain cv = tie_load_chain(prm, 0, lane), ct = tie_load_chain(prm, 1, lane);
-    for (int e = blockIdx.x * 4 + wave; e < n; e += gridDim.x * 4) {
+    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+        const int e = tie_event_of_row(cu, t_pad, row);
+        if (e < 0) {                                                            // wave-uniform
+            store4<T>(out + (size_t)row * D + 4 * lane, 0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
         const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
         const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);          // x[:,:,2].type(IntTensor), :187
         float yv[4], yt[4], xh[4], rstd;
         tie_chain_fwd(cv, val, yv, xh, rstd);
         tie_chain_fwd(ct, tau, yt, xh, rstd);
         const f32x4 fe = ld4f(ftab + f * D + 4 * lane);
-        store4<T>(out + (size_t)e * D + 4 * lane, fmaxf(yv[0], 0.f) + fmaxf(yt[0], 0.f) + fe[0],
+        store4<T>(out + (size_t)row * D + 4 * lane, fmaxf(yv[0], 0.f) + fmaxf(yt[0], 0.f) + fe[0],
                   fmaxf(yv[1], 0.f) + fmaxf(yt[1], 0.f) + fe[1], fmaxf(yv[2], 0.f) + fmaxf(yt[2], 0.f) + fe[2],
                   fmaxf(yv[3], 0.f) + fmaxf(yt[3], 0.f) + fe[3]);
     }
@@ -187,7 +205,8 @@ MTMP_DEV void tie_chain_bwd(const TieChain& c, float s, const f32x4& dE, float (
 
 // slab row layout: [8][256] chain grads (same order as prm) then [20][256] feature-table grads
 template <typename T>
-__global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const float* prm, const T* dE, int n, float* slab) {
+__global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const float* prm, const T* dE, int n, float* slab,
+                                                      const int* cu, int t_pad) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 8 * D];          // 32 KiB (also used for the table)
     __shared__ __attribute__((aligned(16))) float ftab_acc[20 * D];        // 20 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -199,10 +218,12 @@ __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const flo
     for (int v = 0; v < 8; ++v)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
-    for (int e = blockIdx.x * 4 + wave; e < n; e += gridDim.x * 4) {
+    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+        const int e = tie_event_of_row(cu, t_pad, row);
+        if (e < 0) continue;                                                    // pad row: no event, no gradient
         const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
         const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);
-        const f32x4 g = load4<T>(dE + (size_t)e * D + 4 * lane);
+        const f32x4 g = load4<T>(dE + (size_t)row * D + 4 * lane);
         tie_chain_bwd(cv, val, g, acc, 0);
         tie_chain_bwd(ct, tau, g, acc, 4);
 #pragma unroll
@@ -267,16 +288,44 @@ extern "C" int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats
 }
 
 // out[n,256] = TIE embedding of events[n,3]; params [8][256] fp32, ftab [20][256] fp32.
+namespace {
+int launch_tie_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out, int rows,
+                   const int* cu, int t_pad, hipStream_t st, const char* who) {
+    const int nb = max(1, min((rows + 3) / 4, 2048));
+    if (dtype == 0) hipLaunchKernelGGL(tie_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, ftab, (float*)out, rows, cu, t_pad);
+    else if (dtype == 1) hipLaunchKernelGGL(tie_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, ftab, (bf16*)out, rows, cu, t_pad);
+    else { mtmp_set_error("%s: unknown dtype %d", who, dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH(who);
+    return MTMP_OK;
+}
+int launch_tie_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads, float* ws,
+                   int rows, const int* cu, int t_pad, hipStream_t st, const char* who) {
+    const int nb = max(1, min((rows + 3) / 4, 512));
+    if (dtype == 0) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad);
+    else if (dtype == 1) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad);
+    else { mtmp_set_error("%s: unknown dtype %d", who, dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH(who);
+    launch_slab_reduce(ws, nb, 28 * D, ws + (size_t)nb * 28 * D, grads, st);
+    MTMP_CHECK_LAUNCH(who);
+    return MTMP_OK;
+}
+}  // namespace
+
 extern "C" int mtmp_tie_embed_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out,
                                   int n, void* stream) {
     MTMP_CHECK_ARG(events && params && ftab && out && n > 0, "mtmp_tie_embed_fwd: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    const int nb = max(1, min((n + 3) / 4, 2048));
-    if (dtype == 0) hipLaunchKernelGGL(tie_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, ftab, (float*)out, n);
-    else if (dtype == 1) hipLaunchKernelGGL(tie_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, ftab, (bf16*)out, n);
-    else { mtmp_set_error("mtmp_tie_embed_fwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
-    MTMP_CHECK_LAUNCH("mtmp_tie_embed_fwd");
-    return MTMP_OK;
+    return launch_tie_fwd(dtype, events, params, ftab, out, n, nullptr, 0, (hipStream_t)stream, "mtmp_tie_embed_fwd");
+}
+
+// Packed (ragged) input: events float[cu[B]][3] back to back, cu int32[B+1] on the device (cu[0] = 0);
+// out [B, t_pad, 256] with zero rows past each sample's length (rows past t_pad are dropped: the caller
+// truncates to --TIE-len before packing, as dataset_new.py:2020-2021 does).
+extern "C" int mtmp_tie_embed_packed_fwd(int dtype, const float* events, const int32_t* cu_seqlens, int B, int t_pad,
+                                         const float* params, const float* ftab, void* out, void* stream) {
+    MTMP_CHECK_ARG(events && cu_seqlens && params && ftab && out && B > 0 && t_pad > 0 && (long long)B * t_pad < (1ll << 31),
+                   "mtmp_tie_embed_packed_fwd: bad argument (B=%d t_pad=%d)", B, t_pad);
+    return launch_tie_fwd(dtype, events, params, ftab, out, B * t_pad, cu_seqlens, t_pad, (hipStream_t)stream,
+                          "mtmp_tie_embed_packed_fwd");
 }
 
 extern "C" int mtmp_tie_bwd_ws_floats(int n) { return (max(1, min((n + 3) / 4, 512)) + RED_GROUPS) * 28 * D; }
@@ -285,15 +334,17 @@ extern "C" int mtmp_tie_bwd_ws_floats(int n) { return (max(1, min((n + 3) / 4, 5
 extern "C" int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
                                   float* ws, int n, void* stream) {
     MTMP_CHECK_ARG(events && params && d_out && grads && ws && n > 0, "mtmp_tie_embed_bwd: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    const int nb = max(1, min((n + 3) / 4, 512));
-    if (dtype == 0) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, n, ws);
-    else if (dtype == 1) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, n, ws);
-    else { mtmp_set_error("mtmp_tie_embed_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
-    MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd");
-    launch_slab_reduce(ws, nb, 28 * D, ws + (size_t)nb * 28 * D, grads, st);
-    MTMP_CHECK_LAUNCH("mtmp_tie_embed_bwd(reduce)");
-    return MTMP_OK;
+    return launch_tie_bwd(dtype, events, params, d_out, grads, ws, n, nullptr, 0, (hipStream_t)stream, "mtmp_tie_embed_bwd");
+}
+
+// d_out [B, t_pad, 256]; ws: mtmp_tie_bwd_ws_floats(B * t_pad) floats.
+extern "C" int mtmp_tie_embed_packed_bwd(int dtype, const float* events, const int32_t* cu_seqlens, int B, int t_pad,
+                                         const float* params, const void* d_out, float* grads, float* ws, void* stream) {
+    MTMP_CHECK_ARG(events && cu_seqlens && params && d_out && grads && ws && B > 0 && t_pad > 0 &&
+                       (long long)B * t_pad < (1ll << 31),
+                   "mtmp_tie_embed_packed_bwd: bad argument (B=%d t_pad=%d)", B, t_pad);
+    return launch_tie_bwd(dtype, events, params, d_out, grads, ws, B * t_pad, cu_seqlens, t_pad, (hipStream_t)stream,
+                          "mtmp_tie_embed_packed_bwd");
 }
 
 // In-place AdamW step over flat fp32 buffers of n elements (n % 4 == 0); bf16_shadow may be null.

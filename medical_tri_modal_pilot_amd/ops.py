@@ -261,6 +261,42 @@ class TieEmbed(torch.autograd.Function):
                 g[8:28], None)
 
 
+class TieEmbedPacked(torch.autograd.Function):
+    """The same embedding on the ragged batch layout of builder/data: events [E,3] fp32 back to
+    back, cu_seqlens [B+1] int32; returns the padded stream layout [B, t_pad, 256] with zero rows past each
+    sample's length (they lie behind kv_len).  Parameter gradients sum over the real events only, which is what
+    the reference's padded computation gives too (its pad rows feed nothing)."""
+
+    @staticmethod
+    def forward(ctx, events, cu_seqlens, t_pad, wv, bv, gv, hv, wt, bt, gt, ht, ftab, dtype):
+        _gpu(events, cu_seqlens, ftab)
+        if cu_seqlens.dtype != torch.int32:
+            raise TypeError("cu_seqlens must be int32")
+        B = cu_seqlens.numel() - 1
+        ev = _c(events.float())
+        cu = _c(cu_seqlens)
+        prm = torch.stack([wv.reshape(-1), bv, gv, hv, wt.reshape(-1), bt, gt, ht]).float().contiguous()
+        ft = _c(ftab.float())
+        out = torch.empty(B, t_pad, D_MODEL, dtype=dtype, device=events.device)
+        call("mtmp_tie_embed_packed_fwd", _dt(out), _p(ev), _p(cu), B, t_pad, _p(prm), _p(ft), _p(out), _stream())
+        ctx.save_for_backward(ev, cu, prm)
+        ctx.wshape, ctx.t_pad = (wv.shape, wt.shape), t_pad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ev, cu, prm = ctx.saved_tensors
+        B, t_pad = cu.numel() - 1, ctx.t_pad
+        d_out = _c(d_out)
+        grads = torch.empty(28, D_MODEL, dtype=torch.float32, device=ev.device)
+        ws = torch.empty(_lib.lib().mtmp_tie_bwd_ws_floats(B * t_pad), dtype=torch.float32, device=ev.device)
+        call("mtmp_tie_embed_packed_bwd", _dt(d_out), _p(ev), _p(cu), B, t_pad, _p(prm), _p(d_out), _p(grads), _p(ws),
+             _stream())
+        g = grads
+        return (None, None, None, g[0].view(ctx.wshape[0]), g[1], g[2], g[3], g[4].view(ctx.wshape[1]), g[5], g[6],
+                g[7], g[8:28], None)
+
+
 # ----------------------------------------------------------------------------- encoder layer
 # One pre-LN encoder block (builder/models/src/transformer/encoder.py:23-34) on a [B, N, 256]
 # stream with per-sample valid-key counts:

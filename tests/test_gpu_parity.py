@@ -223,6 +223,41 @@ def test_tie_embedding(ops, dt):
         check(t + ".dF", prm_d[8].grad, torch.from_numpy(Gd["tie_dF"]), 2e-2)
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_tie_embedding_packed_equals_padded(ops, dt):
+    """Ragged batch layout: same kernel arithmetic through the cu_seqlens row map -- valid rows are
+    bit-identical to the padded path, pad rows are zero, parameter gradients agree (summation order differs)."""
+    from medical_tri_modal_pilot_amd.builder.data import collate_packed
+    sd = _model_sd(2)
+    prm = [sd["ie_vslt.0.weight"], sd["ie_vslt.0.bias"], sd["ie_vslt.1.weight"], sd["ie_vslt.1.bias"],
+           sd["ie_time.0.weight"], sd["ie_time.0.bias"], sd["ie_time.1.weight"], sd["ie_time.1.bias"],
+           sd["ie_feat.weight"]]
+    g = torch.Generator().manual_seed(21)
+    lens = [37, 1, 200, 64, 0, 199]
+    T = 200
+    x = torch.zeros(len(lens), T, 3)
+    for b, n in enumerate(lens):
+        x[b, :n, 0] = -24 * torch.rand(n, generator=g)
+        x[b, :n, 1] = torch.rand(n, generator=g)
+        x[b, :n, 2] = torch.randint(0, 18, (n,), generator=g).float()
+    pb = collate_packed([(x[b, :n].numpy(), np.zeros(2, np.float32), 0.0) for b, n in enumerate(lens)])
+    pk = pb.on_device(DEV, t_pad=T, bucket=256)
+    xr = x.half().float()                                   # the trainer's fp16 rounding, as on_device applies it
+    p1 = [p.clone().to(DEV).requires_grad_() for p in prm]
+    p2 = [p.clone().to(DEV).requires_grad_() for p in prm]
+    e_pad = ops.TieEmbed.apply(xr.to(DEV), *p1, dt)
+    e_pk = ops.TieEmbedPacked.apply(pk.events, pk.cu_seqlens, pk.t_pad, *p2, dt)
+    assert e_pk.shape == e_pad.shape
+    valid = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).to(DEV)
+    assert torch.equal(e_pk[valid], e_pad[valid])
+    assert float(e_pk[~valid].float().abs().sum()) == 0.0
+    w = torch.randn(len(lens), T, 256, generator=g).to(DEV)
+    (e_pad.float() * w * valid[..., None]).sum().backward()
+    (e_pk.float() * w).sum().backward()                     # pad rows carry no gradient by construction
+    for i, (a, b) in enumerate(zip(p1, p2)):
+        check(f"tie_packed[{str(dt)[6:]}].grad{i}", b.grad, a.grad, 1e-5 if dt == torch.float32 else 1e-2)
+
+
 def _product_model(L, multi, dtype, **over):
     from medical_tri_modal_pilot_amd.control.config import parse_args
     from medical_tri_modal_pilot_amd.builder.models import get_model
@@ -381,12 +416,12 @@ def _digest(t):
     return torch.cat([f.norm().view(1), f[torch.linspace(0, f.numel() - 1, 8).long()]])
 
 
-def _run_steps(dtype, multi, tag, fused):
+def _run_steps(dtype, multi, tag, fused, packed=False, **over):
     from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
     from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     Gd = G(tag)
-    args, model = _product_model(2, multi, dtype)
+    args, model = _product_model(2, multi, dtype, **over)
     bt = filler.make_batch(int(Gd["seed"]), int(Gd["B"]), int(Gd["T"]), multiimages=multi)
     model.train()
     model.img_encoder.eval()
@@ -400,7 +435,13 @@ def _run_steps(dtype, multi, tag, fused):
     crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
     lg = _Logger()
     static = torch.stack([bt["gen"], bt["age"]], 1)
-    kw = dict(args=args, x=bt["x"], static=static, y=bt["y"], output_lengths=None, model=model, logger=lg,
+    x_in = bt["x"]
+    if packed:                        # the same batch in the ragged layout of builder/data
+        from medical_tri_modal_pilot_amd.builder.data import collate_packed
+        x_in = collate_packed([(bt["x"][b, :int(n)].numpy(), static[b].numpy(), float(bt["txt_time"][b]))
+                               for b, n in enumerate(bt["input_lengths"])])
+        args.TIE_len = bt["x"].shape[1]
+    kw = dict(args=args, x=x_in, static=static, y=bt["y"], output_lengths=None, model=model, logger=lg,
               device=torch.device(DEV), scheduler=sched, optimizer=opt, criterion=crit, x_txt=bt["txt"],
               x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None, missing=bt["missing"],
               reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
@@ -465,6 +506,19 @@ def test_full_training_step_fp32_vs_golden(ops, multi, tag, fused):
     assert abs(tl - float(Gd["test_loss"])) < 1e-4
     check(t + ".test_sigmoid", lg.evaluator.calls[-1][1], torch.from_numpy(Gd["test_sigmoid"]), 1e-4)
     check(t + ".bn_running_mean", model.fc_list[1].running_mean, torch.from_numpy(Gd["bn_running_mean"]), 1e-4)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_packed_batch_training_steps_vs_golden(ops, graph):
+    """Two train steps + one test step fed with the ragged PackedTieBatch instead of the padded x: same losses as
+    the reference-generated golden (1e-4), eager and through the hipGraph replay path."""
+    Gd, model, grads, params1, loss1, loss2, tl, lg, _ = _run_steps("fp32", 0, "model_step", True, packed=True,
+                                                                    hip_graph=graph)
+    t = f"step_packed[fp32,graph={graph}]"
+    REPORT[t + ".loss"] = {"rel_err": abs(loss1 - float(Gd["loss"])), "tol": 1e-4}
+    assert abs(loss1 - float(Gd["loss"])) < 1e-4 * max(1.0, abs(float(Gd["loss"])))
+    assert abs(loss2 - float(Gd["loss2"])) < 1e-4
+    assert abs(tl - float(Gd["test_loss"])) < 1e-4
 
 
 def test_full_training_step_bf16_tolerance(ops):
