@@ -82,8 +82,30 @@ class StochasticDepth(nn.Module):
     def row_scale(self, n: int, device):
         if not self.training or self.p == 0.0:
             return None
+        pre = getattr(self, "_predrawn", None)
+        if pre:                                  # drawn for the whole encoder in one go (draw_row_scales)
+            return pre.pop()
         keep = 1.0 - self.p
         return torch.empty(n, dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
+
+def draw_row_scales(model: nn.Module, n: int, device):
+    """All StochasticDepth draws of one encoder forward in three launches instead of two tiny kernels per
+    residual branch (46 per forward of Swin-T: each cost ~5 us on the critical path): one uniform draw
+    [branches, n], one compare against each branch's keep probability, one scale.  Same distribution as the
+    per-branch ``bernoulli_(keep).div_(keep)`` (1/keep with probability keep, else 0)."""
+    mods = [m for m in model.modules() if isinstance(m, StochasticDepth) and m.training and m.p > 0.0]
+    if not mods:
+        return
+    key = (str(device), tuple(m.p for m in mods))
+    cached = getattr(model, "_sd_keep", None)
+    if cached is None or cached[0] != key:       # built once: no host-to-device copy inside a captured step
+        keep = torch.tensor([1.0 - m.p for m in mods for _ in range(2)], dtype=torch.float32).unsqueeze(1).to(device)
+        model._sd_keep = cached = (key, keep)
+    keep = cached[1]
+    scales = (torch.rand(keep.shape[0], n, device=device) < keep).float() / keep
+    for i, m in enumerate(mods):
+        m._predrawn = [scales[2 * i + 1], scales[2 * i]]         # popped in call order: attention branch, then MLP
 
 
 class ShiftedWindowAttention(nn.Module):
@@ -205,6 +227,7 @@ class SwinTransformer(nn.Module):
     def forward(self, x):
         """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] in the compute dtype."""
         stem = self.features[0]
+        draw_row_scales(self, x.shape[0], x.device)
         x = ops.swin_stem(x, stem[0].weight, stem[0].bias, stem[2].weight, stem[2].bias, self.compute_dtype)
         for layer in list(self.features)[1:]:
             x = layer(x)

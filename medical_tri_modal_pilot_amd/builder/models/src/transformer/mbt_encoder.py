@@ -116,11 +116,12 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         # bottleneck tokens in rows 0..3 of their own buffer: [bottleneck | CLS | tokens] (:745)
         fl = list(self.layer_stacks)[n_pre:]
         params, fused, seeds, p = [], [], [], 0.0
+        all_fused = iter(type(fl[0][0]).fused_weights_of([layer for layers in fl for layer in layers], dt))
         for layers in fl:
             frow, srow = [], []
             for layer in layers:
                 params += layer.param_list()
-                frow.append(layer._fused_weights(dt))
+                frow.append(next(all_fused))
                 p, sd = layer.dropout_args()
                 srow.append(sd)
             fused.append(frow)
