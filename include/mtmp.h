@@ -113,6 +113,21 @@ int mtmp_tie_embed_packed_fwd(int dtype, const float* events, const int32_t* cu_
 int mtmp_tie_embed_packed_bwd(int dtype, const float* events, const int32_t* cu_seqlens, int B, int t_pad,
                               const float* params, const void* d_out, float* grads, float* ws, void* stream);
 
+/* Stream input of the fusion encoder (mbt_encoder.py:697-729 and the concatenation of :745) in one launch:
+ * out[b] = [ bott (nb rows) | dropout(LN(cls) + pe[0]) | dropout(LN(x[b,t]) + pe[t+1]), t = 0..N-1 ],
+ * nn.LayerNorm semantics (biased variance, eps inside the root) in fp32; x, out, dz, dx in `dtype`;
+ * cls / gamma / beta float[256], pe float[>= N+1][256] or NULL, bott float[nb][256] (nb <= 4);
+ * stats float[B*(N+1)][2] is written by the forward and read by the backward; dropout as in mtmp_dropout_bwd
+ * (seed ^ *seed_dev). grads float[7][256] = dgamma, dbeta, dcls, dbott[0..3], overwritten.
+ * ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats. */
+int mtmp_stream_input_ws_floats(int rows);
+int mtmp_stream_input_fwd(int dtype, const void* x, const float* cls, const float* gamma, const float* beta,
+                          const float* pe, const float* bott, void* out, float* stats, int B, int N, int nb, float eps,
+                          float p, unsigned seed, const unsigned* seed_dev, void* stream);
+int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float* cls, const float* gamma,
+                          const float* stats, void* dx, float* grads, float* ws, int B, int N, int nb, float p,
+                          unsigned seed, const unsigned* seed_dev, void* stream);
+
 /* Swin-T patch-embedding stem: Conv2d(1,96,4,stride 4) -> NHWC -> LayerNorm(96)
  * (builder/models/src/swin_transformer.py:559-567,646) as an implicit GEMM.
  * img float[n_img,1,H,W]; out [n_img,H/4,W/4,96] in `dtype`. */

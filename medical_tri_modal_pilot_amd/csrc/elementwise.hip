@@ -119,6 +119,133 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* z, int ldz, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// Stream input of the fusion encoder (K4, mbt_encoder.py:697-729 + the concatenation of :745):
+//     z[b] = [ bottleneck tokens (nb rows) | dropout(LN(CLS) + PE[0]) | dropout(LN(x[b,t]) + PE[t+1]) ... ]
+// nn.LayerNorm (biased variance, eps inside the root) in fp32 on the stream's compute-dtype embeddings, the
+// sinusoid rows only for the stream that uses them, dropout by the counter hash of common.cuh (regenerated in
+// the backward), output straight into the [B, nb+1+N, 256] buffer the fusion stack reads -- one launch instead
+// of cat + layer_norm + add + dropout + cast + two copies per stream.  One wave per row.
+constexpr int NB_MAX = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const float* cls, const float* gamma,
+                                                            const float* beta, const float* pe, const float* bott, T* out,
+                                                            float* stats, int B, int N, int nb, float eps, float p,
+                                                            unsigned seed0, const unsigned* seed_dev) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = nb + 1 + N;
+    const f32x4 gm = ld4f(gamma + 4 * lane), be = ld4f(beta + 4 * lane);
+    const unsigned seed = seed0 ^ (seed_dev ? *seed_dev : 0u);
+    const unsigned thr = dropout_threshold(p);
+    const float sc = 1.0f / (1.0f - p);
+    for (int row = blockIdx.x * 4 + wave; row < B * R; row += gridDim.x * 4) {
+        const int b = row / R, r = row - b * R;
+        T* o = out + (size_t)row * D + 4 * lane;
+        if (r < nb) {                                                          // wave-uniform
+            const f32x4 v = ld4f(bott + r * D + 4 * lane);
+            store4<T>(o, v[0], v[1], v[2], v[3]);
+            continue;
+        }
+        const int t = r - nb;                                                  // 0 = CLS
+        f32x4 v;
+        if (t == 0) {
+            const f32x4 c = ld4f(cls + 4 * lane);                              // cls.to(x.dtype) then .float()
+            v = f32x4{round_as<T>(c[0]), round_as<T>(c[1]), round_as<T>(c[2]), round_as<T>(c[3])};
+        } else {
+            v = load4<T>(x + ((size_t)b * N + t - 1) * D + 4 * lane);
+        }
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / D);
+        float d[4], sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d[i] = v[i] - mean; sq += d[i] * d[i]; }
+        const float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + eps);
+        float y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(d[i] * rstd, gm[i], be[i]);
+        if (pe) {
+            const f32x4 pv = ld4f(pe + (size_t)t * D + 4 * lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] += pv[i];
+        }
+        const int lnrow = b * (N + 1) + t;
+        if (thr) {
+            const unsigned keep = dropout_keep4(seed, (unsigned)lnrow * 64u + lane, thr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (keep >> i) & 1u ? y[i] * sc : 0.f;
+        }
+        store4<T>(o, y[0], y[1], y[2], y[3]);
+        if (lane == 0) { stats[2 * (size_t)lnrow] = mean; stats[2 * (size_t)lnrow + 1] = rstd; }
+    }
+}
+
+// slab row: [dgamma | dbeta | dcls | dbott[0..3]] = 7 x 256
+template <typename T>
+__global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T* x, const float* cls, const float* gamma,
+                                                            const float* stats, T* dx, float* slab, int B, int N, int nb,
+                                                            float p, unsigned seed0, const unsigned* seed_dev) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 7 * D];              // 28 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int R = nb + 1 + N;
+    const f32x4 gm = ld4f(gamma + 4 * lane);
+    const unsigned seed = seed0 ^ (seed_dev ? *seed_dev : 0u);
+    const unsigned thr = dropout_threshold(p);
+    const float sc = 1.0f / (1.0f - p);
+    float acc[7][4];
+#pragma unroll
+    for (int v = 0; v < 7; ++v)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < B * R; row += gridDim.x * 4) {
+        const int b = row / R, r = row - b * R;
+        f32x4 g = load4<T>(dz + (size_t)row * D + 4 * lane);
+        if (r < nb) {                                                          // wave-uniform
+#pragma unroll
+            for (int k = 0; k < NB_MAX; ++k)
+                if (r == k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[3 + k][i] += g[i];
+            continue;
+        }
+        const int t = r - nb, lnrow = b * (N + 1) + t;
+        if (thr) {
+            const unsigned keep = dropout_keep4(seed, (unsigned)lnrow * 64u + lane, thr);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = (keep >> i) & 1u ? g[i] * sc : 0.f;
+        }
+        f32x4 v;
+        if (t == 0) {
+            const f32x4 c = ld4f(cls + 4 * lane);
+            v = f32x4{round_as<T>(c[0]), round_as<T>(c[1]), round_as<T>(c[2]), round_as<T>(c[3])};
+        } else {
+            v = load4<T>(x + ((size_t)b * N + t - 1) * D + 4 * lane);
+        }
+        const float mean = stats[2 * (size_t)lnrow], rstd = stats[2 * (size_t)lnrow + 1];
+        float xh[4], gy[4], sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xh[i] = (v[i] - mean) * rstd;
+            acc[0][i] += g[i] * xh[i];
+            acc[1][i] += g[i];
+            gy[i] = g[i] * gm[i];
+            sg += gy[i];
+            sgx += gy[i] * xh[i];
+        }
+        wave_sum2(sg, sgx);
+        const float mg = sg * (1.0f / D), mgx = sgx * (1.0f / D);
+        float dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dv[i] = rstd * (gy[i] - mg - xh[i] * mgx);
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[2][i] += dv[i];
+        } else {
+            store4<T>(dx + ((size_t)b * N + t - 1) * D + 4 * lane, dv[0], dv[1], dv[2], dv[3]);
+        }
+    }
+    flush_partials<7>(acc, slab + (size_t)blockIdx.x * 7 * D, lds, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------
 // TIE / UMSE event embedding (tri_mbt_vsltcls.py:59-71,183-190):
 //   E[e,:] = ReLU(LN(v_e * w_v + b_v)) + ReLU(LN(tau_e * w_t + b_t)) + F[f_e]
 // events: [n,3] fp32 (time, value, feature index); params: 8 vectors of 256 (w,b,ln_w,ln_b for the
@@ -345,6 +472,52 @@ extern "C" int mtmp_tie_embed_packed_bwd(int dtype, const float* events, const i
                    "mtmp_tie_embed_packed_bwd: bad argument (B=%d t_pad=%d)", B, t_pad);
     return launch_tie_bwd(dtype, events, params, d_out, grads, ws, B * t_pad, cu_seqlens, t_pad, (hipStream_t)stream,
                           "mtmp_tie_embed_packed_bwd");
+}
+
+extern "C" int mtmp_stream_input_ws_floats(int rows) { return (max(1, min((rows + 15) / 16, 1024)) + RED_GROUPS) * 7 * D; }
+
+// z [B, nb+1+N, 256] (dtype) from x [B, N, 256] (dtype); cls, gamma, beta [256], pe [>= N+1][256] or NULL,
+// bott [nb][256] fp32; stats float[B*(N+1)][2] (mean, 1/sqrt(var+eps)) kept for the backward.
+extern "C" int mtmp_stream_input_fwd(int dtype, const void* x, const float* cls, const float* gamma, const float* beta,
+                                     const float* pe, const float* bott, void* out, float* stats, int B, int N, int nb,
+                                     float eps, float p, unsigned seed, const unsigned* seed_dev, void* stream) {
+    MTMP_CHECK_ARG(x && cls && gamma && beta && out && stats && B > 0 && N > 0 && nb >= 0 && nb <= NB_MAX && (nb == 0 || bott) &&
+                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25),
+                   "mtmp_stream_input_fwd: bad argument (B=%d N=%d nb=%d p=%f)", B, N, nb, p);
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = B * (nb + 1 + N), nbk = max(1, min((rows + 3) / 4, 2048));
+    if (dtype == 0)
+        hipLaunchKernelGGL(stream_in_fwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)x, cls, gamma, beta, pe,
+                           bott, (float*)out, stats, B, N, nb, eps, p, seed, seed_dev);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(stream_in_fwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)x, cls, gamma, beta, pe,
+                           bott, (bf16*)out, stats, B, N, nb, eps, p, seed, seed_dev);
+    else { mtmp_set_error("mtmp_stream_input_fwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_stream_input_fwd");
+    return MTMP_OK;
+}
+
+// dx [B, N, 256] (dtype); grads float[7][256] = dgamma, dbeta, dcls, dbott[0..3] (rows past nb are zero),
+// overwritten; ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats.
+extern "C" int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float* cls, const float* gamma,
+                                     const float* stats, void* dx, float* grads, float* ws, int B, int N, int nb, float p,
+                                     unsigned seed, const unsigned* seed_dev, void* stream) {
+    MTMP_CHECK_ARG(dz && x && cls && gamma && stats && dx && grads && ws && B > 0 && N > 0 && nb >= 0 && nb <= NB_MAX &&
+                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25),
+                   "mtmp_stream_input_bwd: bad argument (B=%d N=%d nb=%d p=%f)", B, N, nb, p);
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = B * (nb + 1 + N), nbk = max(1, min((rows + 15) / 16, 1024));
+    if (dtype == 0)
+        hipLaunchKernelGGL(stream_in_bwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)dz, (const float*)x, cls,
+                           gamma, stats, (float*)dx, ws, B, N, nb, p, seed, seed_dev);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(stream_in_bwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)dz, (const bf16*)x, cls,
+                           gamma, stats, (bf16*)dx, ws, B, N, nb, p, seed, seed_dev);
+    else { mtmp_set_error("mtmp_stream_input_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_stream_input_bwd");
+    launch_slab_reduce(ws, nbk, 7 * D, ws + (size_t)nbk * 7 * D, grads, st);
+    MTMP_CHECK_LAUNCH("mtmp_stream_input_bwd(reduce)");
+    return MTMP_OK;
 }
 
 // In-place AdamW step over flat fp32 buffers of n elements (n % 4 == 0); bf16_shadow may be null.

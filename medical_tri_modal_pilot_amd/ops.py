@@ -297,6 +297,45 @@ class TieEmbedPacked(torch.autograd.Function):
                 g[7], g[8:28], None)
 
 
+# ----------------------------------------------------------------------------- stream input (K4)
+class StreamInputFn(torch.autograd.Function):
+    """mbt_encoder.py:697-729 + the [bottleneck | CLS | tokens] concatenation of :745 as one launch each way.
+    apply(x [B,N,256] compute dtype, cls [1,1,256], ln_w, ln_b, pe [L,256] | None, bott [1,nb,256] | None, eps, p, seed)
+    -> z [B, nb+1+N, 256] (the buffer ops.FusionStackFn reads in place, cfg["prebuilt"])."""
+
+    @staticmethod
+    def forward(ctx, x, cls, ln_w, ln_b, pe, bott, eps, p, seed):
+        _gpu(x)
+        B, N, _ = x.shape
+        nb = 0 if bott is None else bott.shape[-2]
+        x = _c(x)
+        cls_f, g_f, b_f = _c(cls.detach().float().view(-1)), _c(ln_w.detach().float()), _c(ln_b.detach().float())
+        bott_f = None if bott is None else _c(bott.detach().float().view(nb, D_MODEL))
+        pe_f = None if pe is None else _c(pe.float().view(-1, D_MODEL))
+        if pe_f is not None and pe_f.shape[0] < N + 1:
+            raise ValueError("positional table shorter than the stream")
+        out = torch.empty(B, nb + 1 + N, D_MODEL, dtype=x.dtype, device=x.device)
+        stats = torch.empty(B * (N + 1), 2, dtype=torch.float32, device=x.device)
+        call("mtmp_stream_input_fwd", _dt(x), _p(x), _p(cls_f), _p(g_f), _p(b_f), _p(pe_f), _p(bott_f), _p(out), _p(stats),
+             B, N, nb, float(eps), float(p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _stream())
+        ctx.save_for_backward(x, cls_f, g_f, stats)
+        ctx.meta = (B, N, nb, float(p), int(seed) & 0xFFFFFFFF, cls.shape, None if bott is None else bott.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, cls_f, g_f, stats = ctx.saved_tensors
+        B, N, nb, p, seed, cls_shape, bott_shape = ctx.meta
+        dz = _c(dz)
+        dx = torch.empty_like(x)
+        grads = torch.empty(7, D_MODEL, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.lib().mtmp_stream_input_ws_floats(B * (nb + 1 + N)), dtype=torch.float32, device=x.device)
+        call("mtmp_stream_input_bwd", _dt(x), _p(dz), _p(x), _p(cls_f), _p(g_f), _p(stats), _p(dx), _p(grads), _p(ws),
+             B, N, nb, p, seed, _p(_seed_word), _stream())
+        d_bott = None if bott_shape is None else grads[3:3 + nb].view(bott_shape)
+        return dx, grads[2].view(cls_shape), grads[0], grads[1], None, d_bott, None, None, None
+
+
 # ----------------------------------------------------------------------------- encoder layer
 # One pre-LN encoder block (builder/models/src/transformer/encoder.py:23-34) on a [B, N, 256]
 # stream with per-sample valid-key counts:
@@ -444,13 +483,17 @@ class FusionStackFn(torch.autograd.Function):
         xs = [xv, xi, xt]
         _gpu(xv)
         B, dev = xv.shape[0], xv.device
-        Ns = [x.shape[1] + NB for x in xs]
-        z = []
-        for m, x in enumerate(xs):
-            buf = torch.empty(B, Ns[m], D_MODEL, dtype=dt, device=dev)
-            buf[:, NB:] = x
-            buf[:, :NB] = bott.to(dt)
-            z.append(buf)
+        if cfg.get("prebuilt"):            # xs ARE the [B, 4+N, 256] buffers (ops.StreamInputFn); read, never written
+            Ns = [x.shape[1] for x in xs]
+            z = [_c(x) for x in xs]
+        else:
+            Ns = [x.shape[1] + NB for x in xs]
+            z = []
+            for m, x in enumerate(xs):
+                buf = torch.empty(B, Ns[m], D_MODEL, dtype=dt, device=dev)
+                buf[:, NB:] = x
+                buf[:, :NB] = bott.to(dt)
+                z.append(buf)
         wsel = _exchange_w(dev)
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
@@ -548,6 +591,9 @@ class FusionStackFn(torch.autograd.Function):
                 for m in (1, 2):
                     nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
             dz = nxt
+        if cfg.get("prebuilt"):            # the bottleneck rows' gradient flows on through the stream-input nodes
+            d_bott = None if d_prev_bott is None else d_prev_bott.sum(0, keepdim=True)
+            return (dz[0], dz[1], dz[2], d_bott, *pgrads, None)
         d_bott = sum(dz[m][:, :NB].float() for m in range(3) if dz[m] is not None)
         if d_prev_bott is not None:
             d_bott = d_bott + d_prev_bott

@@ -258,6 +258,60 @@ def test_tie_embedding_packed_equals_padded(ops, dt):
         check(f"tie_packed[{str(dt)[6:]}].grad{i}", b.grad, a.grad, 1e-5 if dt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("use_pe", [False, True])
+def test_stream_input_vs_torch_chain(ops, dt, use_pe):
+    """K4 (mbt_encoder.py:697-729 + the concatenation of :745): the fused launch against the op chain it replaces
+    (cat CLS -> F.layer_norm fp32 -> + sinusoid rows -> cast, bottleneck rows in front), forward and all gradients;
+    then the dropout mask: the backward regenerates exactly the forward's mask."""
+    from oracle import tri_mbt_oracle as O
+    g = torch.Generator().manual_seed(5 + int(use_pe))
+    B, N, nb = 3, 37, 4
+    x = torch.randn(B, N, 256, generator=g).to(dt)
+    cls, gam, bet = torch.randn(1, 1, 256, generator=g), 1 + 0.1 * torch.randn(256, generator=g), 0.1 * torch.randn(256, generator=g)
+    bott = torch.randn(1, nb, 256, generator=g)
+    pe = O.sinusoid_table(2500, 256)[:N + 1] if use_pe else None
+    w = torch.randn(B, nb + 1 + N, 256, generator=g)
+    # reference chain on the CPU in fp32 (inputs rounded to dt like the product sees them)
+    xr, cr, gr, br, tr = (t.clone().float().requires_grad_() for t in (x, cls, gam, bet, bott))
+    xc = torch.cat([cr.expand(B, -1, -1).to(dt).float(), xr], 1)
+    y = F_layer_norm(xc, gr, br)
+    if use_pe:
+        y = y + pe[None]
+    z_ref = torch.cat([tr.expand(B, -1, -1), y], 1)
+    (z_ref * w).sum().backward()
+    xd, cd, gd, bd, td = (t.clone().to(DEV).requires_grad_() for t in (x, cls, gam, bet, bott))
+    z = ops.StreamInputFn.apply(xd, cd, gd, bd, None if pe is None else pe.to(DEV), td, 1e-5, 0.0, 0)
+    t = f"stream_in[{str(dt)[6:]},pe={int(use_pe)}]"
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    check(t + ".z", z.float(), z_ref, tol)
+    (z.float() * w.to(DEV)).sum().backward()
+    check(t + ".dx", xd.grad.float(), xr.grad, 1e-4 if dt == torch.float32 else 2e-2)
+    check(t + ".dcls", cd.grad, cr.grad, 1e-4 if dt == torch.float32 else 2e-2)
+    check(t + ".dgamma", gd.grad, gr.grad, 1e-4 if dt == torch.float32 else 2e-2)
+    check(t + ".dbeta", bd.grad, br.grad, 1e-4 if dt == torch.float32 else 2e-2)
+    check(t + ".dbott", td.grad, tr.grad, 1e-5 if dt == torch.float32 else 1e-2)
+    # dropout: kept elements are scaled by 1/(1-p), dropped ones are exactly 0 in z and get exactly 0 gradient
+    p = 0.25
+    x2 = xd.detach().clone().requires_grad_()
+    zd = ops.StreamInputFn.apply(x2, cd.detach(), gd.detach(), bd.detach(), None, td.detach(), 1e-5, p, 1234)
+    body, body0 = zd[:, nb:].float(), z[:, nb:].float().detach() - (0 if pe is None else pe.to(DEV)[None])
+    kept = body != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    assert torch.equal(zd[:, :nb], z[:, :nb].detach())                      # bottleneck rows are never dropped
+    if pe is None:
+        check(t + ".dropout_scale", body[kept], body0[kept] / (1 - p), tol)
+    # d(sum z)/dx with everything kept would be rstd*(gamma - mean - xh*mean(gamma*xh)); a fully dropped row gives 0
+    zd.float().sum().backward()
+    row_dropped = ~kept.any(dim=2)[:, 1:]
+    assert float(x2.grad[row_dropped].float().abs().sum()) == 0.0
+
+
+def F_layer_norm(x, w, b):
+    return torch.nn.functional.layer_norm(x, (256,), w, b, 1e-5)
+
+
 def _product_model(L, multi, dtype, **over):
     from medical_tri_modal_pilot_amd.control.config import parse_args
     from medical_tri_modal_pilot_amd.builder.models import get_model
