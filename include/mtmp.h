@@ -103,6 +103,14 @@ int mtmp_tie_bwd_ws_floats(int n);
 int mtmp_tie_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
                        float* ws, int n, void* stream);
 
+/* Time + modality-id embedding added to every image / text token (tri_mbt_vsltcls.py:216-224):
+ * out[n,256] = ReLU(LN(time*w_t+b_t)) + ftab[feature], i.e. the event embedding without its value chain;
+ * same events / params / grads layout as above (ws: mtmp_tie_bwd_ws_floats(n)). */
+int mtmp_time_embed_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out, int n,
+                        void* stream);
+int mtmp_time_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
+                        float* ws, int n, void* stream);
+
 /* The same on the PACKED (ragged) batch layout of the collate (replaces the zero-padded
  * [B, TIE_len, 3] tensor of dataset_new.py:2177 + the [:, :max_len] trim of trainer.py:41-42):
  * events float[cu[B]][3] back to back, cu_seqlens int32[B+1] (device), out / d_out [B, t_pad, 256];

@@ -32,6 +32,8 @@ SIGNATURES = {
     "mtmp_tie_embed_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_tie_bwd_ws_floats": (c_int, [c_int]),
     "mtmp_tie_embed_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
+    "mtmp_time_embed_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
+    "mtmp_time_embed_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p]),
     "mtmp_tie_embed_packed_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_tie_embed_packed_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_stream_input_ws_floats": (c_int, [c_int]),

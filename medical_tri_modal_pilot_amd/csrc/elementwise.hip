@@ -284,7 +284,9 @@ MTMP_DEV int tie_event_of_row(const int* cu, int t_pad, int row) {
     return t < hi - lo ? lo + t : -1;
 }
 
-template <typename T>
+// VAL = false: the value chain is left out, E = ReLU(LN(tau*w_t+b_t)) + F[f] -- the time + modality-id embedding
+// that is added to every image / text token (tri_mbt_vsltcls.py:216-224: ie_time(t) + ie_feat(18 | 19)).
+template <typename T, bool VAL = true>
 __global__ __launch_bounds__(256) void tie_fwd_kernel(const float* ev, const float* prm, const float* ftab, T* out, int n,
                                                       const int* cu, int t_pad) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -297,8 +299,8 @@ __global__ __launch_bounds__(256) void tie_fwd_kernel(const float* ev, const flo
         }
         const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
         const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);          // x[:,:,2].type(IntTensor), :187
-        float yv[4], yt[4], xh[4], rstd;
-        tie_chain_fwd(cv, val, yv, xh, rstd);
+        float yv[4] = {0.f, 0.f, 0.f, 0.f}, yt[4], xh[4], rstd;
+        if (VAL) tie_chain_fwd(cv, val, yv, xh, rstd);
         tie_chain_fwd(ct, tau, yt, xh, rstd);
         const f32x4 fe = ld4f(ftab + f * D + 4 * lane);
         store4<T>(out + (size_t)row * D + 4 * lane, fmaxf(yv[0], 0.f) + fmaxf(yt[0], 0.f) + fe[0],
@@ -331,7 +333,7 @@ MTMP_DEV void tie_chain_bwd(const TieChain& c, float s, const f32x4& dE, float (
 }
 
 // slab row layout: [8][256] chain grads (same order as prm) then [20][256] feature-table grads
-template <typename T>
+template <typename T, bool VAL = true>
 __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const float* prm, const T* dE, int n, float* slab,
                                                       const int* cu, int t_pad) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 8 * D];          // 32 KiB (also used for the table)
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const flo
         const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
         const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);
         const f32x4 g = load4<T>(dE + (size_t)row * D + 4 * lane);
-        tie_chain_bwd(cv, val, g, acc, 0);
+        if (VAL) tie_chain_bwd(cv, val, g, acc, 0);
         tie_chain_bwd(ct, tau, g, acc, 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) atomicAdd(&ftab_acc[f * D + 4 * lane + i], g[i]);   // LDS ds_add_f32
@@ -417,19 +419,23 @@ extern "C" int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats
 // out[n,256] = TIE embedding of events[n,3]; params [8][256] fp32, ftab [20][256] fp32.
 namespace {
 int launch_tie_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out, int rows,
-                   const int* cu, int t_pad, hipStream_t st, const char* who) {
+                   const int* cu, int t_pad, hipStream_t st, const char* who, bool val = true) {
     const int nb = max(1, min((rows + 3) / 4, 2048));
-    if (dtype == 0) hipLaunchKernelGGL(tie_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, ftab, (float*)out, rows, cu, t_pad);
-    else if (dtype == 1) hipLaunchKernelGGL(tie_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, ftab, (bf16*)out, rows, cu, t_pad);
+    if (dtype == 0 && val) hipLaunchKernelGGL(tie_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, ftab, (float*)out, rows, cu, t_pad);
+    else if (dtype == 1 && val) hipLaunchKernelGGL(tie_fwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, ftab, (bf16*)out, rows, cu, t_pad);
+    else if (dtype == 0) hipLaunchKernelGGL((tie_fwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, events, params, ftab, (float*)out, rows, cu, t_pad);
+    else if (dtype == 1) hipLaunchKernelGGL((tie_fwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, events, params, ftab, (bf16*)out, rows, cu, t_pad);
     else { mtmp_set_error("%s: unknown dtype %d", who, dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH(who);
     return MTMP_OK;
 }
 int launch_tie_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads, float* ws,
-                   int rows, const int* cu, int t_pad, hipStream_t st, const char* who) {
+                   int rows, const int* cu, int t_pad, hipStream_t st, const char* who, bool val = true) {
     const int nb = max(1, min((rows + 3) / 4, 512));
-    if (dtype == 0) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad);
-    else if (dtype == 1) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad);
+    if (dtype == 0 && val) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad);
+    else if (dtype == 1 && val) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad);
+    else if (dtype == 0) hipLaunchKernelGGL((tie_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad);
+    else if (dtype == 1) hipLaunchKernelGGL((tie_bwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad);
     else { mtmp_set_error("%s: unknown dtype %d", who, dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH(who);
     launch_slab_reduce(ws, nb, 28 * D, ws + (size_t)nb * 28 * D, grads, st);
@@ -442,6 +448,21 @@ extern "C" int mtmp_tie_embed_fwd(int dtype, const float* events, const float* p
                                   int n, void* stream) {
     MTMP_CHECK_ARG(events && params && ftab && out && n > 0, "mtmp_tie_embed_fwd: bad argument");
     return launch_tie_fwd(dtype, events, params, ftab, out, n, nullptr, 0, (hipStream_t)stream, "mtmp_tie_embed_fwd");
+}
+
+// Time + modality-id embedding of the image / text tokens (tri_mbt_vsltcls.py:216-224): out[n,256] =
+// ReLU(LN(time*w_t+b_t)) + ftab[feature]; events float[n,3] = (time, unused, feature index); same params / grads
+// layout as mtmp_tie_embed_* (the value chain's four gradient rows come back zero).
+extern "C" int mtmp_time_embed_fwd(int dtype, const float* events, const float* params, const float* ftab, void* out,
+                                   int n, void* stream) {
+    MTMP_CHECK_ARG(events && params && ftab && out && n > 0, "mtmp_time_embed_fwd: bad argument");
+    return launch_tie_fwd(dtype, events, params, ftab, out, n, nullptr, 0, (hipStream_t)stream, "mtmp_time_embed_fwd", false);
+}
+extern "C" int mtmp_time_embed_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads,
+                                   float* ws, int n, void* stream) {
+    MTMP_CHECK_ARG(events && params && d_out && grads && ws && n > 0, "mtmp_time_embed_bwd: bad argument");
+    return launch_tie_bwd(dtype, events, params, d_out, grads, ws, n, nullptr, 0, (hipStream_t)stream, "mtmp_time_embed_bwd",
+                          false);
 }
 
 // Packed (ragged) input: events float[cu[B]][3] back to back, cu int32[B+1] on the device (cu[0] = 0);

@@ -261,6 +261,35 @@ class TieEmbed(torch.autograd.Function):
                 g[8:28], None)
 
 
+class TimeEmbed(torch.autograd.Function):
+    """tri_mbt_vsltcls.py:216-224: ie_time(t) + ie_feat(18 | 19), the embedding added to every image / text token,
+    for all image and text times of the batch in one launch each way (was two Linear+LayerNorm+ReLU chains through
+    autograd, ~30 small kernels).  events [n,3] fp32 = (time, 0, feature index); returns [n,256] in `dtype`."""
+
+    @staticmethod
+    def forward(ctx, events, wt, bt, gt, ht, ftab, dtype):
+        _gpu(events, ftab)
+        ev = _c(events.float())
+        z = torch.zeros_like(bt, dtype=torch.float32)
+        prm = torch.stack([z, z, z, z, wt.reshape(-1).float(), bt.float(), gt.float(), ht.float()]).contiguous()
+        ft = _c(ftab.float())
+        out = torch.empty(ev.shape[0], D_MODEL, dtype=dtype, device=events.device)
+        call("mtmp_time_embed_fwd", _dt(out), _p(ev), _p(prm), _p(ft), _p(out), ev.shape[0], _stream())
+        ctx.save_for_backward(ev, prm)
+        ctx.wshape = wt.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        ev, prm = ctx.saved_tensors
+        n = ev.shape[0]
+        d_out = _c(d_out)
+        grads = torch.empty(28, D_MODEL, dtype=torch.float32, device=ev.device)
+        ws = torch.empty(_lib.lib().mtmp_tie_bwd_ws_floats(n), dtype=torch.float32, device=ev.device)
+        call("mtmp_time_embed_bwd", _dt(d_out), _p(ev), _p(prm), _p(d_out), _p(grads), _p(ws), n, _stream())
+        return None, grads[4].view(ctx.wshape), grads[5], grads[6], grads[7], grads[8:28], None
+
+
 class TieEmbedPacked(torch.autograd.Function):
     """The same embedding on the ragged batch layout of builder/data: events [E,3] fp32 back to
     back, cu_seqlens [B+1] int32; returns the padded stream layout [B, t_pad, 256] with zero rows past each
@@ -295,6 +324,31 @@ class TieEmbedPacked(torch.autograd.Function):
         g = grads
         return (None, None, None, g[0].view(ctx.wshape[0]), g[1], g[2], g[3], g[4].view(ctx.wshape[1]), g[5], g[6],
                 g[7], g[8:28], None)
+
+
+# ----------------------------------------------------------------------------- projections of data tensors
+class DataLinearFn(torch.autograd.Function):
+    """y = x W^T + b for an input that is DATA (no gradient wanted): the text projection Linear(768,256) on the
+    BioBERT embeddings (tri_mbt_vsltcls.py:200) and the projection of the frozen image encoder's features
+    (:205-211).  Forward mtmp_gemm_nt, backward ONE mtmp_gemm_tn (dW with the bias gradient fused) -- the autograd
+    of F.linear ran a library TN GEMM (60 us for the text weight) plus cast and column-sum kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype):
+        _gpu(x, weight)
+        lead = x.shape[:-1]
+        x2 = _c(x.reshape(-1, x.shape[-1]).to(dtype))
+        y = gemm_nt(x2, _c(weight.detach().to(dtype)), _c(bias.detach().float()))
+        ctx.save_for_backward(x2)
+        ctx.wshape = weight.shape
+        return y.view(*lead, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        dy2 = _c(dy.reshape(-1, dy.shape[-1]).to(x2.dtype))
+        dw, db = gemm_tn(dy2, x2)
+        return None, dw.view(ctx.wshape), db, None
 
 
 # ----------------------------------------------------------------------------- stream input (K4)

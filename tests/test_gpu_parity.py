@@ -308,6 +308,46 @@ def test_stream_input_vs_torch_chain(ops, dt, use_pe):
     assert float(x2.grad[row_dropped].float().abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("dt", DT)
+def test_time_embed_and_data_linear_vs_torch(ops, dt):
+    """ie_time(t) + ie_feat(18|19) (tri_mbt_vsltcls.py:216-224) and the Linear(768,256) projections of data tensors
+    (:200, :205-211) against the torch modules they replace, forward and parameter gradients."""
+    g = torch.Generator().manual_seed(9)
+    n_i, n_t = 6, 5
+    t_all = torch.cat([-10 * torch.rand(n_i, generator=g), -torch.randint(3, 100, (n_t,), generator=g).float()]).half().float()
+    lin, ln = torch.nn.Linear(1, 256), torch.nn.LayerNorm(256)
+    ftab = torch.randn(20, 256, generator=g)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(256, generator=g)); ln.bias.copy_(0.1 * torch.randn(256, generator=g))
+    fr = ftab.clone().requires_grad_()
+    idx = torch.tensor([18] * n_i + [19] * n_t)
+    ref = torch.relu(ln(lin(t_all[:, None]))) + fr[idx]
+    w = torch.randn(n_i + n_t, 256, generator=g)
+    (ref * w).sum().backward()
+    ev = torch.zeros(n_i + n_t, 3); ev[:, 0] = t_all; ev[:, 2] = idx.float()
+    prm = [p_.detach().clone().to(DEV).requires_grad_() for p_ in (lin.weight, lin.bias, ln.weight, ln.bias, ftab)]
+    out = ops.TimeEmbed.apply(ev.to(DEV), *prm, dt)
+    t = f"time_embed[{str(dt)[6:]}]"
+    check(t + ".out", out.float(), ref, 1e-5 if dt == torch.float32 else 1e-2)
+    (out.float() * w.to(DEV).to(dt).float()).sum().backward()
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    for nm, a, b in (("dw", prm[0].grad, lin.weight.grad), ("db", prm[1].grad, lin.bias.grad), ("dg", prm[2].grad, ln.weight.grad),
+                     ("dbeta", prm[3].grad, ln.bias.grad), ("dftab", prm[4].grad, fr.grad)):
+        check(f"{t}.{nm}", a, b, tol)
+    # projection of a data tensor: forward + dW/db through mtmp_gemm_nt / mtmp_gemm_tn
+    x = torch.randn(3, 128, 768, generator=g).to(dt).float()
+    proj = torch.nn.Linear(768, 256)
+    yr = proj(x)
+    wy = torch.randn(3, 128, 256, generator=g)
+    (yr * wy).sum().backward()
+    pw, pb = proj.weight.detach().clone().to(DEV).requires_grad_(), proj.bias.detach().clone().to(DEV).requires_grad_()
+    y = ops.DataLinearFn.apply(x.to(DEV), pw, pb, dt)
+    check(f"data_linear[{str(dt)[6:]}].y", y.float(), yr, 1e-5 if dt == torch.float32 else 2e-2)
+    (y.float() * wy.to(DEV).to(dt).float()).sum().backward()
+    check(f"data_linear[{str(dt)[6:]}].dW", pw.grad, proj.weight.grad, 1e-4 if dt == torch.float32 else 3e-2)
+    check(f"data_linear[{str(dt)[6:]}].db", pb.grad, proj.bias.grad, 1e-4 if dt == torch.float32 else 3e-2)
+
+
 def F_layer_norm(x, w, b):
     return torch.nn.functional.layer_norm(x, (256,), w, b, 1e-5)
 
