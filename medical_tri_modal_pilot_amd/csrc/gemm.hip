@@ -138,7 +138,7 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::NT], const GemmArgs<T>& p
             for (int i = 0; i < 4; ++i) {
                 v[i] = acc[nt][4 * g + i] + bv[i];
                 if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
-                if (p.act == 2) v[i] = 0.5f * v[i] * (1.0f + erf_as(v[i] * 0.70710678118654752f));
+                if (p.act == 2) v[i] = gelu<T>(v[i]);
                 if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
             }
             store4<T>(sOut + (32 * wr + r) * LDO + cl, v[0], v[1], v[2], v[3]);
