@@ -10,6 +10,7 @@ how the work reaches the GPU:
   * the caller's length tensors are NOT mutated (the reference does ``varying_lengths[n] += 1``
     in place, :704 -- nothing downstream reads them again).
 """
+import contextlib
 from typing import List, Optional
 
 import torch
@@ -99,20 +100,27 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         fused_in = (n_pre == 0 and self.n_layers > 0 and enc_outputs[0].is_cuda and len(enc_outputs) == 3
                     and all(x.dtype == dt for x in enc_outputs))
         streams = []
+        # the model may have produced the image / text embeddings on the two side streams (inputs_on_side_streams):
+        # their stream-input kernels stay there, and the main stream joins before the fusion stack
+        side_in = self._side_streams(dev) if (fused_in and getattr(self, "inputs_on_side_streams", False)) else None
         for m, x in enumerate(enc_outputs):
             ln = self.layer_norms_in[m]
             if fused_in:      # one HIP launch: LN + PE + dropout written behind the bottleneck rows (ops.StreamInputFn)
                 pdrop = self.dropout.p if self.training else 0.0
                 pe = self.positional_encoding(x.size(1) + 1) if self.use_pe[m] else None
-                streams.append(ops.StreamInputFn.apply(x, self.cls_token_per_modality[m], ln.weight, ln.bias, pe,
-                                                       self.bottlenecks, ln.eps, pdrop,
-                                                       next_dropout_seed() if pdrop > 0 else 0))
+                seed = next_dropout_seed() if pdrop > 0 else 0
+                with (torch.cuda.stream(side_in[m - 1]) if (side_in is not None and m > 0) else contextlib.nullcontext()):
+                    streams.append(ops.StreamInputFn.apply(x, self.cls_token_per_modality[m], ln.weight, ln.bias, pe,
+                                                           self.bottlenecks, ln.eps, pdrop, seed))
                 continue
             x = torch.cat([self.cls_token_per_modality[m].expand(B, -1, -1).to(x.dtype), x], dim=1)
             y = F.layer_norm(x.float(), (self.d_model,), ln.weight, ln.bias, ln.eps)
             if self.use_pe[m]:
                 y = y + self.positional_encoding(x.size(1))
             streams.append(self.dropout(y).to(dt))
+        if side_in is not None:
+            for s_ in side_in:
+                torch.cuda.current_stream().wait_stream(s_)
         kv_plain = [None if l is None else l.to(torch.int32).contiguous() for l in lens]
         kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
         missing = missing.to(dev).long()
