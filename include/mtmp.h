@@ -136,6 +136,22 @@ int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float*
                           const float* stats, void* dx, float* grads, float* ws, int B, int N, int nb, float p,
                           unsigned seed, const unsigned* seed_dev, void* stream);
 
+/* Classification head (tri_mbt_vsltcls.py:59-76 ie_demo, :248-255): out[b] = fc3(ReLU(BatchNorm1d(fc0([LN(cls[b]) |
+ * ReLU(LN(ie_demo.0(age, gender)))])))), fp32, B <= 64, six launches forward + backward instead of ~65 torch kernels.
+ * params: 14 device pointers (float): ie_demo.0.weight[256][2], ie_demo.0.bias, ie_demo.1.weight, ie_demo.1.bias,
+ * layer_norms_after_concat.{weight,bias}, fc_list.0.{weight[256][512],bias}, fc_list.1.{weight,bias,running_mean,
+ * running_var} (the running statistics are updated in place when training != 0), fc_list.3.{weight[256],bias[1]}.
+ * ws_fwd: mtmp_head_ws_floats(B) floats, written by the forward and read by the backward.
+ * backward outputs (overwritten): dcls[B][256]; g_rows[7][256] = d layer_norms_after_concat.{weight,bias}, d ie_demo.1.{weight,
+ * bias}, d ie_demo.0.weight[:,0], [:,1], d ie_demo.0.bias; dw1[256][512]; g_feat[4][256] = d fc_list.0.bias, d fc_list.1.{weight,
+ * bias}, d fc_list.3.weight; db2[1].  ws_bwd: B*256*8 floats. */
+int mtmp_head_ws_floats(int B);
+int mtmp_head_fwd(const float* cls, const float* age, const float* gender, const void* const* params, float* out, float* ws,
+                  int B, float ln_eps, float bn_eps, float momentum, int training, void* stream);
+int mtmp_head_bwd(const float* d_out, const float* cls, const float* age, const float* gender, const void* const* params,
+                  const float* ws_fwd, float* dcls, float* g_rows, float* dw1, float* g_feat, float* db2, float* ws_bwd, int B,
+                  float ln_eps, int training, void* stream);
+
 /* Swin-T patch-embedding stem: Conv2d(1,96,4,stride 4) -> NHWC -> LayerNorm(96)
  * (builder/models/src/swin_transformer.py:559-567,646) as an implicit GEMM.
  * img float[n_img,1,H,W]; out [n_img,H/4,W/4,96] in `dtype`. */

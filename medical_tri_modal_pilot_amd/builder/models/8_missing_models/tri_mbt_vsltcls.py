@@ -161,8 +161,12 @@ class TRI_MBT_VSLTCLS(nn.Module):
             B = x.size(0)
             x = x.float()
         age, gen = age.float(), gen.float()
-        demographic = torch.stack([age, gen], dim=1)
-        demo_embedding = self.ie_demo(demographic)                                            # [B,256] fp32
+        # head + ie_demo as six HIP launches (ops.HeadFn) when the demographic embedding feeds nothing but the head
+        fused_head = (age.is_cuda and not _TORCH_SMALL and B <= ops.HEAD_MAX_B and self.args.vslt_type != "QIE"
+                      and "rmse" not in self.args.auxiliary_loss_type and (B > 1 or not self.training))
+        if not fused_head:
+            demographic = torch.stack([age, gen], dim=1)
+            demo_embedding = self.ie_demo(demographic)                                        # [B,256] fp32
         # ---- vital-sign / lab stream
         if self.args.vslt_type == "carryforward":
             vslt_embedding = self.vslt_enc(x).to(dt)
@@ -245,6 +249,16 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # ---- head (:248-255), fp32
         cls = self.fusion_transformer.last_cls             # outputs[0][:, 0, :] as a dedicated autograd output
         cls = (outputs[0][:, 0, :] if cls is None else cls).float()
+        if fused_head:
+            bn, ln, dm = self.fc_list[1], self.layer_norms_after_concat, self.ie_demo
+            if bn.training and bn.track_running_stats:
+                bn.num_batches_tracked.add_(1)
+            use_batch = bn.training or not bn.track_running_stats
+            output1 = ops.HeadFn.apply(cls, age, gen, use_batch, 0.1 if bn.momentum is None else bn.momentum, bn.eps,
+                                       bn.running_mean, bn.running_var, dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias,
+                                       ln.weight, ln.bias, self.fc_list[0].weight, self.fc_list[0].bias, bn.weight, bn.bias,
+                                       self.fc_list[3].weight, self.fc_list[3].bias)
+            return output1, None, None
         class_input = self.layer_norms_after_concat(cls)
         if self.args.vslt_type != "QIE":
             class_input = torch.cat([class_input, demo_embedding], dim=1)

@@ -336,12 +336,18 @@ MTMP_DEV void tie_chain_bwd(const TieChain& c, float s, const f32x4& dE, float (
 template <typename T, bool VAL = true>
 __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const float* prm, const T* dE, int n, float* slab,
                                                       const int* cu, int t_pad) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 8 * D];          // 32 KiB (also used for the table)
-    __shared__ __attribute__((aligned(16))) float ftab_acc[20 * D];        // 20 KiB
+    // Feature-table gradient: one private [20][256] table per wave (80 KiB), summed in wave order at the end.  A
+    // single table with LDS float atomics (the first version) added the four waves' contributions in arrival order:
+    // run-to-run 1-ulp differences in d ie_feat (found by the graph-vs-eager bit-equality test once the time
+    // embeddings, a handful of events per workgroup, went through this kernel).  The first 32 KiB double as the
+    // staging area of flush_partials afterwards.
+    __shared__ __attribute__((aligned(16))) float ftab_acc[4 * 20 * D];
+    float* lds = ftab_acc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const TieChain cv = tie_load_chain(prm, 0, lane), ct = tie_load_chain(prm, 1, lane);
-    for (int i = threadIdx.x; i < 20 * D; i += 256) ftab_acc[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * 20 * D; i += 256) ftab_acc[i] = 0.f;
     __syncthreads();
+    float* my_tab = ftab_acc + wave * 20 * D;
     float acc[8][4];
 #pragma unroll
     for (int v = 0; v < 8; ++v)
@@ -355,12 +361,17 @@ __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const flo
         const f32x4 g = load4<T>(dE + (size_t)row * D + 4 * lane);
         if (VAL) tie_chain_bwd(cv, val, g, acc, 0);
         tie_chain_bwd(ct, tau, g, acc, 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(&ftab_acc[f * D + 4 * lane + i], g[i]);   // LDS ds_add_f32
+        f32x4* tp = reinterpret_cast<f32x4*>(my_tab + f * D + 4 * lane);        // wave-private: plain read-modify-write
+        f32x4 tv = *tp;
+        tv += g;
+        *tp = tv;
     }
     float* row = slab + (size_t)blockIdx.x * 28 * D;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 20 * D; i += 256)
+        row[8 * D + i] = ((ftab_acc[i] + ftab_acc[20 * D + i]) + ftab_acc[2 * 20 * D + i]) + ftab_acc[3 * 20 * D + i];
+    __syncthreads();
     flush_partials<8>(acc, row, lds, lane, wave);
-    for (int i = threadIdx.x; i < 20 * D; i += 256) row[8 * D + i] = ftab_acc[i];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,264 @@
+// Classification head of TRI_MBT_VSLTCLS (K10, tri_mbt_vsltcls.py:59-76 `ie_demo`, :248-255 head) for gfx950:
+//     demo = ReLU(LN(age * w[:,0] + gender * w[:,1] + b))                         ie_demo (Linear(2,256), LayerNorm, ReLU)
+//     x    = [ LN(cls) | demo ]                                                   layer_norms_after_concat, torch.cat
+//     h    = x W1^T + b1 ;  y = BatchNorm1d(h) ;  a = ReLU(y) ;  out = a W2^T + b2  fc_list.{0,1,2,3}
+// Everything here is a few hundred KFLOP on B <= 64 rows: the torch modules cost ~65 launches of ~5 us forward +
+// backward, all of them on the critical path between the forward and the backward of the step.  Six launches here.
+//   forward : head_x (one wave per row: the two LayerNorms) -> head_fc (feature-parallel: 4 features per workgroup,
+//             a wave = one feature x all rows, so the BatchNorm statistics are wave reductions) -> head_out
+//   backward: head_fc_bwd (feature-parallel: BatchNorm / Linear weight gradients, dh) -> head_x_bwd (row-parallel:
+//             dx = dh W1, both LayerNorm backwards, per-row partials of the row-summed gradients) -> slab reduce
+// fp32 throughout (the reference runs the head in fp32 under autocast too).  Deterministic: no float atomics.
+#include "common.cuh"
+
+namespace {
+
+constexpr int D = 256, DX = 512, MAXB = 64, FPW = 4;   // d_model, head input width, rows per wave, features per workgroup
+
+MTMP_DEV float block_sum(float v, float* red, int tid) {   // 256 threads -> every thread gets the sum
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+struct HeadParams {
+    const float* demo_w; const float* demo_b; const float* demo_g; const float* demo_be;   // ie_demo.{0.weight[256][2],0.bias,1.weight,1.bias}
+    const float* ln_g; const float* ln_b;                                                   // layer_norms_after_concat
+    const float* w1; const float* b1;                                                       // fc_list.0 [256][512]
+    const float* bn_g; const float* bn_b; float* run_mean; float* run_var;                  // fc_list.1
+    const float* w2; const float* b2;                                                       // fc_list.3 [1][256]
+};
+
+// x[b] = [LN(cls[b]) | ReLU(LN(age*w0 + gen*w1 + b))]; one wave per row, lane owns 4 columns of each half.
+__global__ __launch_bounds__(256) void head_x_kernel(const float* cls, const float* age, const float* gen, HeadParams p,
+                                                     float* x, int B, float eps) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int c = 4 * lane;
+    f32x4 v = *reinterpret_cast<const f32x4*>(cls + (size_t)b * D + c);
+    float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / D), d[4], sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { d[i] = v[i] - mean; sq += d[i] * d[i]; }
+    float rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + eps);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(d[i] * rstd, p.ln_g[c + i], p.ln_b[c + i]);
+    *reinterpret_cast<f32x4*>(x + (size_t)b * DX + c) = o;
+    const float a = age[b], g = gen[b];
+    float u[4], su = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { u[i] = fmaf(a, p.demo_w[2 * (c + i)], fmaf(g, p.demo_w[2 * (c + i) + 1], p.demo_b[c + i])); su += u[i]; }
+    mean = wave_sum(su) * (1.0f / D);
+    sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { d[i] = u[i] - mean; sq += d[i] * d[i]; }
+    rstd = rsqrtf(wave_sum(sq) * (1.0f / D) + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaxf(fmaf(d[i] * rstd, p.demo_g[c + i], p.demo_be[c + i]), 0.f);
+    *reinterpret_cast<f32x4*>(x + (size_t)b * DX + D + c) = o;
+}
+
+// workgroup g owns features 4g..4g+3; thread = (row b = lane, feature jj = wave)
+__global__ __launch_bounds__(256) void head_fc_kernel(const float* x, HeadParams p, float* hhat, float* rstd_out, float* partial,
+                                                      int B, float eps, float momentum, int training) {
+    __shared__ float xT[64][MAXB + 1];          // one 64-column chunk of x, transposed: xT[k][b]
+    __shared__ float pl[FPW][MAXB];
+    const int tid = threadIdx.x, b = tid & 63, jj = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x * FPW + jj;
+    const bool live = b < B;
+    const float* wrow = p.w1 + (size_t)j * DX;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < DX; k0 += 64) {
+        __syncthreads();
+        // 64 rows x 64 columns: thread t loads row t>>2, columns 16*(t&3) .. +15
+        const int r = tid >> 2, cs = 16 * (tid & 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < B) v = *reinterpret_cast<const f32x4*>(x + (size_t)r * DX + k0 + cs + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xT[cs + 4 * q + i][r] = v[i];
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int kk = 0; kk < 64; ++kk) acc = fmaf(xT[kk][b], wrow[k0 + kk], acc);
+    }
+    const float h = acc + p.b1[j];
+    float mean, var;
+    if (training) {
+        mean = wave_sum(live ? h : 0.f) / (float)B;
+        const float dv = live ? h - mean : 0.f;
+        var = wave_sum(dv * dv) / (float)B;                                    // biased, used for normalisation
+        if (b == 0) {                                                          // running statistics (unbiased variance)
+            p.run_mean[j] = (1.0f - momentum) * p.run_mean[j] + momentum * mean;
+            p.run_var[j] = (1.0f - momentum) * p.run_var[j] + momentum * var * ((float)B / (float)max(B - 1, 1));
+        }
+    } else {
+        mean = p.run_mean[j];
+        var = p.run_var[j];
+    }
+    const float rstd = rsqrtf(var + eps);
+    const float hh = (h - mean) * rstd;
+    const float a = fmaxf(fmaf(hh, p.bn_g[j], p.bn_b[j]), 0.f);
+    if (live) hhat[(size_t)b * D + j] = hh;
+    if (b == 0) rstd_out[j] = rstd;
+    pl[jj][b] = live ? a * p.w2[j] : 0.f;
+    __syncthreads();
+    if (tid < MAXB) partial[(size_t)blockIdx.x * MAXB + tid] = pl[0][tid] + pl[1][tid] + pl[2][tid] + pl[3][tid];
+}
+
+__global__ __launch_bounds__(64) void head_out_kernel(const float* partial, const float* b2, float* out, int B) {
+    const int b = threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int g = 0; g < D / FPW; ++g) s += partial[(size_t)g * MAXB + b];
+    out[b] = s + b2[0];
+}
+
+// feature-parallel backward: dW2, db2, dbn_g, dbn_b, db1, dW1, dh[b][j]
+__global__ __launch_bounds__(256) void head_fc_bwd_kernel(const float* dout, const float* x, const float* hhat, const float* rstd_in,
+                                                          HeadParams p, float* dh_out, float* dw1, float* db1, float* dbn_g,
+                                                          float* dbn_b, float* dw2, float* db2, int B, int training) {
+    __shared__ float dhs[FPW][MAXB];
+    const int tid = threadIdx.x, b = tid & 63, jj = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x * FPW + jj;
+    const bool live = b < B;
+    const float dl = live ? dout[b] : 0.f;
+    const float hh = live ? hhat[(size_t)b * D + j] : 0.f;
+    const float gam = p.bn_g[j], y = fmaf(hh, gam, p.bn_b[j]);
+    const float a = fmaxf(y, 0.f);
+    const float dy = (live && y > 0.f) ? dl * p.w2[j] : 0.f;
+    const float s_w2 = wave_sum(dl * a), s_g = wave_sum(dy * hh), s_b = wave_sum(dy);
+    const float rstd = rstd_in[j];
+    const float dh = training ? gam * rstd * (dy - s_b / (float)B - hh * s_g / (float)B) : gam * rstd * dy;
+    const float dhl = live ? dh : 0.f;
+    const float s_b1 = wave_sum(dhl);
+    if (b == 0) { dw2[j] = s_w2; dbn_g[j] = s_g; dbn_b[j] = s_b; db1[j] = s_b1; }
+    if (blockIdx.x == 0 && jj == 0) {
+        const float s = wave_sum(dl);
+        if (b == 0) db2[0] = s;
+    }
+    if (live) dh_out[(size_t)b * D + j] = dh;
+    dhs[jj][b] = dhl;
+    __syncthreads();
+    // dW1[j][k] = sum_b dh[b][j] x[b][k]: thread t owns columns t and t + 256 of the workgroup's four rows of W1
+    float s0[FPW] = {0.f, 0.f, 0.f, 0.f}, s1[FPW] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < B; ++r) {
+        const float x0 = x[(size_t)r * DX + tid], x1 = x[(size_t)r * DX + D + tid];
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) { s0[f] = fmaf(dhs[f][r], x0, s0[f]); s1[f] = fmaf(dhs[f][r], x1, s1[f]); }
+    }
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) {
+        dw1[(size_t)(blockIdx.x * FPW + f) * DX + tid] = s0[f];
+        dw1[(size_t)(blockIdx.x * FPW + f) * DX + D + tid] = s1[f];
+    }
+}
+
+// row-parallel backward: workgroup = row b, thread = column k of each half of x.
+// slab row b: [dln_g | dln_b | ddemo_g | ddemo_be | ddemo_w0 | ddemo_w1 | ddemo_b] = 7 x 256
+__global__ __launch_bounds__(256) void head_x_bwd_kernel(const float* dh, const float* cls, const float* age, const float* gen,
+                                                         HeadParams p, float* dcls, float* slab, float eps) {
+    __shared__ float dhr[D];
+    __shared__ float red[4];
+    const int b = blockIdx.x, k = threadIdx.x;
+    dhr[k] = dh[(size_t)b * D + k];
+    __syncthreads();
+    float dxc = 0.f, dxd = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float g = dhr[j];
+        dxc = fmaf(g, p.w1[(size_t)j * DX + k], dxc);
+        dxd = fmaf(g, p.w1[(size_t)j * DX + D + k], dxd);
+    }
+    float* row = slab + (size_t)b * 7 * D;
+    // LayerNorm(cls) backward
+    {
+        const float v = cls[(size_t)b * D + k];
+        const float mean = block_sum(v, red, k) * (1.0f / D);
+        const float d = v - mean;
+        const float rstd = rsqrtf(block_sum(d * d, red, k) * (1.0f / D) + eps);
+        const float xh = d * rstd, gy = dxc * p.ln_g[k];
+        const float m1 = block_sum(gy, red, k) * (1.0f / D), m2 = block_sum(gy * xh, red, k) * (1.0f / D);
+        dcls[(size_t)b * D + k] = rstd * (gy - m1 - xh * m2);
+        row[k] = dxc * xh;
+        row[D + k] = dxc;
+    }
+    // ie_demo backward
+    {
+        const float a = age[b], g = gen[b];
+        const float u = fmaf(a, p.demo_w[2 * k], fmaf(g, p.demo_w[2 * k + 1], p.demo_b[k]));
+        const float mean = block_sum(u, red, k) * (1.0f / D);
+        const float d = u - mean;
+        const float rstd = rsqrtf(block_sum(d * d, red, k) * (1.0f / D) + eps);
+        const float xh = d * rstd;
+        const float dyd = fmaf(xh, p.demo_g[k], p.demo_be[k]) > 0.f ? dxd : 0.f;
+        const float gy = dyd * p.demo_g[k];
+        const float m1 = block_sum(gy, red, k) * (1.0f / D), m2 = block_sum(gy * xh, red, k) * (1.0f / D);
+        const float du = rstd * (gy - m1 - xh * m2);
+        row[2 * D + k] = dyd * xh;
+        row[3 * D + k] = dyd;
+        row[4 * D + k] = du * a;
+        row[5 * D + k] = du * g;
+        row[6 * D + k] = du;
+    }
+}
+
+// out[c] = sum_r slab[r][c], r < rows <= 64: 256 threads over columns
+__global__ __launch_bounds__(256) void head_rows_reduce_kernel(const float* slab, int rows, int cols, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += slab[(size_t)r * cols + c];
+    out[c] = s;
+}
+
+}  // namespace
+
+// ws_fwd: x[B][512] + hhat[B][256] + rstd[256] + partial[64][64] floats (kept for the backward)
+extern "C" int mtmp_head_ws_floats(int B) { return B * DX + B * D + D + (D / FPW) * MAXB; }
+
+// params: 14 device pointers in HeadParams order (float; run_mean / run_var are updated in place when training).
+// cls float[B][256], age / gender float[B]; out float[B]; B <= 64.
+extern "C" int mtmp_head_fwd(const float* cls, const float* age, const float* gender, const void* const* params, float* out,
+                             float* ws, int B, float ln_eps, float bn_eps, float momentum, int training, void* stream) {
+    MTMP_CHECK_ARG(cls && age && gender && params && out && ws && B > 0 && B <= MAXB && (training == 0 || B > 1),
+                   "mtmp_head_fwd: bad argument (B=%d, needs 1 <= B <= %d, and B > 1 in training mode)", B, MAXB);
+    HeadParams p{(const float*)params[0], (const float*)params[1], (const float*)params[2], (const float*)params[3],
+                 (const float*)params[4], (const float*)params[5], (const float*)params[6], (const float*)params[7],
+                 (const float*)params[8], (const float*)params[9], (float*)params[10], (float*)params[11],
+                 (const float*)params[12], (const float*)params[13]};
+    hipStream_t st = (hipStream_t)stream;
+    float* x = ws; float* hhat = x + (size_t)B * DX; float* rstd = hhat + (size_t)B * D; float* partial = rstd + D;
+    hipLaunchKernelGGL(head_x_kernel, dim3((B + 3) / 4), dim3(256), 0, st, cls, age, gender, p, x, B, ln_eps);
+    MTMP_CHECK_LAUNCH("mtmp_head_fwd(x)");
+    hipLaunchKernelGGL(head_fc_kernel, dim3(D / FPW), dim3(256), 0, st, (const float*)x, p, hhat, rstd, partial, B, bn_eps,
+                       momentum, training);
+    MTMP_CHECK_LAUNCH("mtmp_head_fwd(fc)");
+    hipLaunchKernelGGL(head_out_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, p.b2, out, B);
+    MTMP_CHECK_LAUNCH("mtmp_head_fwd(out)");
+    return MTMP_OK;
+}
+
+// grads (float, overwritten): dcls[B][256]; g_rows[7][256] = dln_g, dln_b, ddemo_g, ddemo_be, ddemo_w[:,0], ddemo_w[:,1],
+// ddemo_b; dw1[256][512]; g_feat[4][256] = db1, dbn_g, dbn_b, dw2; db2[1].  ws_bwd: B*256 + B*7*256 floats.
+extern "C" int mtmp_head_bwd(const float* d_out, const float* cls, const float* age, const float* gender,
+                             const void* const* params, const float* ws_fwd, float* dcls, float* g_rows, float* dw1,
+                             float* g_feat, float* db2, float* ws_bwd, int B, float ln_eps, int training, void* stream) {
+    MTMP_CHECK_ARG(d_out && cls && age && gender && params && ws_fwd && dcls && g_rows && dw1 && g_feat && db2 && ws_bwd &&
+                       B > 0 && B <= MAXB, "mtmp_head_bwd: bad argument (B=%d)", B);
+    HeadParams p{(const float*)params[0], (const float*)params[1], (const float*)params[2], (const float*)params[3],
+                 (const float*)params[4], (const float*)params[5], (const float*)params[6], (const float*)params[7],
+                 (const float*)params[8], (const float*)params[9], (float*)params[10], (float*)params[11],
+                 (const float*)params[12], (const float*)params[13]};
+    hipStream_t st = (hipStream_t)stream;
+    const float* x = ws_fwd; const float* hhat = x + (size_t)B * DX; const float* rstd = hhat + (size_t)B * D;
+    float* dh = ws_bwd; float* slab = dh + (size_t)B * D;
+    hipLaunchKernelGGL(head_fc_bwd_kernel, dim3(D / FPW), dim3(256), 0, st, d_out, x, hhat, rstd, p, dh, dw1, g_feat,
+                       g_feat + D, g_feat + 2 * D, g_feat + 3 * D, db2, B, training);
+    MTMP_CHECK_LAUNCH("mtmp_head_bwd(fc)");
+    hipLaunchKernelGGL(head_x_bwd_kernel, dim3(B), dim3(256), 0, st, (const float*)dh, cls, age, gender, p, dcls, slab, ln_eps);
+    MTMP_CHECK_LAUNCH("mtmp_head_bwd(x)");
+    hipLaunchKernelGGL(head_rows_reduce_kernel, dim3(7), dim3(256), 0, st, (const float*)slab, B, 7 * D, g_rows);
+    MTMP_CHECK_LAUNCH("mtmp_head_bwd(reduce)");
+    return MTMP_OK;
+}

@@ -351,6 +351,58 @@ class DataLinearFn(torch.autograd.Function):
         return None, dw.view(ctx.wshape), db, None
 
 
+# ----------------------------------------------------------------------------- classification head (K10)
+HEAD_MAX_B = 64
+
+
+class HeadFn(torch.autograd.Function):
+    """tri_mbt_vsltcls.py:248-255 with the ie_demo chain of :59-76: logits [B,1] from the vital-sign CLS vector and
+    (age, gender).  apply(cls [B,256] fp32, age [B], gender [B], training, momentum, bn_eps, run_mean, run_var,
+    *12 parameters in include/mtmp.h order without the two running statistics)."""
+
+    @staticmethod
+    def forward(ctx, cls, age, gender, training, momentum, bn_eps, run_mean, run_var, *prm):
+        _gpu(cls)
+        B = cls.shape[0]
+        if B > HEAD_MAX_B:
+            raise ValueError(f"HeadFn handles up to {HEAD_MAX_B} rows per rank (got {B})")
+        cls, age, gender = _c(cls.detach().float()), _c(age.detach().float()), _c(gender.detach().float())
+        P = [_c(t.detach().float()) for t in prm]
+        # order of include/mtmp.h: demo_w, demo_b, demo_g, demo_be, ln_g, ln_b, w1, b1, bn_g, bn_b, run_mean, run_var, w2, b2
+        ptrs = P[:10] + [run_mean, run_var] + P[10:]
+        table = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in ptrs])
+        out = torch.empty(B, 1, dtype=torch.float32, device=cls.device)
+        ws = torch.empty(_lib.lib().mtmp_head_ws_floats(B), dtype=torch.float32, device=cls.device)
+        call("mtmp_head_fwd", _p(cls), _p(age), _p(gender), ctypes.cast(table, ctypes.c_void_p), _p(out), _p(ws), B, 1e-5,
+             float(bn_eps), float(momentum), int(bool(training)), _stream())
+        ctx.save_for_backward(cls, age, gender, ws, run_mean, run_var, *P)
+        ctx.training = bool(training)
+        ctx.shapes = [t.shape for t in prm]
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        cls, age, gender, ws, run_mean, run_var, *P = ctx.saved_tensors
+        B, dev = cls.shape[0], cls.device
+        ptrs = P[:10] + [run_mean, run_var] + P[10:]
+        table = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in ptrs])
+        d_out = _c(d_out.float().view(-1))
+        dcls = torch.empty(B, D_MODEL, dtype=torch.float32, device=dev)
+        g_rows = torch.empty(7, D_MODEL, dtype=torch.float32, device=dev)
+        dw1 = torch.empty(D_MODEL, 2 * D_MODEL, dtype=torch.float32, device=dev)
+        g_feat = torch.empty(4, D_MODEL, dtype=torch.float32, device=dev)
+        db2 = torch.empty(1, dtype=torch.float32, device=dev)
+        wsb = torch.empty(B * D_MODEL * 8, dtype=torch.float32, device=dev)
+        call("mtmp_head_bwd", _p(d_out), _p(cls), _p(age), _p(gender), ctypes.cast(table, ctypes.c_void_p), _p(ws), _p(dcls),
+             _p(g_rows), _p(dw1), _p(g_feat), _p(db2), _p(wsb), B, 1e-5, int(ctx.training), _stream())
+        sh = ctx.shapes
+        grads = (torch.stack([g_rows[4], g_rows[5]], 1).view(sh[0]), g_rows[6], g_rows[2], g_rows[3],      # ie_demo
+                 g_rows[0], g_rows[1],                                                                      # LN after concat
+                 dw1.view(sh[6]), g_feat[0], g_feat[1], g_feat[2],                                          # fc0, bn
+                 g_feat[3].view(sh[10]), db2.view(sh[11]))                                                  # fc3
+        return (dcls, None, None, None, None, None, None, None) + grads
+
+
 # ----------------------------------------------------------------------------- stream input (K4)
 class StreamInputFn(torch.autograd.Function):
     """mbt_encoder.py:697-729 + the [bottleneck | CLS | tokens] concatenation of :745 as one launch each way.

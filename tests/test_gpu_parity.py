@@ -348,6 +348,53 @@ def test_time_embed_and_data_linear_vs_torch(ops, dt):
     check(f"data_linear[{str(dt)[6:]}].db", pb.grad, proj.bias.grad, 1e-4 if dt == torch.float32 else 3e-2)
 
 
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("B", [64, 5])
+def test_head_vs_torch_modules(ops, training, B):
+    """K10 (tri_mbt_vsltcls.py:59-76 ie_demo + :248-255 head): six HIP launches against the torch modules
+    (Linear, LayerNorm, BatchNorm1d with its running statistics, ReLU), forward, every gradient, running stats."""
+    torch.manual_seed(3)
+    dm = torch.nn.Sequential(torch.nn.Linear(2, 256), torch.nn.LayerNorm(256), torch.nn.ReLU())
+    ln = torch.nn.LayerNorm(256)
+    fc = torch.nn.Sequential(torch.nn.Linear(512, 256), torch.nn.BatchNorm1d(256), torch.nn.ReLU(), torch.nn.Linear(256, 1))
+    with torch.no_grad():
+        for m_ in (dm[1], ln, fc[1]):
+            m_.weight.add_(0.2 * torch.randn(256)); m_.bias.add_(0.2 * torch.randn(256))
+        fc[1].running_mean.copy_(0.1 * torch.randn(256)); fc[1].running_var.copy_(1 + 0.2 * torch.rand(256))
+    for m_ in (dm, ln, fc):
+        m_.train(training)
+    cls = torch.randn(B, 256).requires_grad_()
+    age, gen = torch.rand(B), torch.randint(0, 2, (B,)).float()
+    rm0, rv0 = fc[1].running_mean.clone(), fc[1].running_var.clone()
+    ref = fc(torch.cat([ln(cls), dm(torch.stack([age, gen], 1))], 1))
+    w = torch.randn(B, 1)
+    (ref * w).sum().backward()
+    prm_mods = [dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias, ln.weight, ln.bias, fc[0].weight, fc[0].bias,
+                fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias]
+    prm = [p_.detach().clone().to(DEV).requires_grad_() for p_ in prm_mods]
+    rm, rv = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    cd = cls.detach().clone().to(DEV).requires_grad_()
+    out = ops.HeadFn.apply(cd, age.to(DEV), gen.to(DEV), training, 0.1, 1e-5, rm, rv, *prm)
+    t = f"head[B={B},train={int(training)}]"
+    check(t + ".out", out, ref, 1e-5)
+    (out * w.to(DEV)).sum().backward()
+    check(t + ".dcls", cd.grad, cls.grad, 1e-4)
+    names = ["demo_w", "demo_b", "demo_g", "demo_be", "ln_g", "ln_b", "w1", "b1", "bn_g", "bn_b", "w2", "b2"]
+    scale = float(prm_mods[4].grad.abs().max())
+    for nm, a, b in zip(names, prm, prm_mods):
+        if training and nm in ("ln_b", "b1"):
+            # BatchNorm removes the batch mean of h, so sum_b dh = 0: these two gradients are mathematically zero and
+            # both sides hold rounding noise (cf. the key-projection bias in DESIGN.md 2)
+            assert float(a.grad.abs().max()) < 1e-4 * scale and float(b.grad.abs().max()) < 1e-4 * scale, nm
+            continue
+        check(f"{t}.d{nm}", a.grad, b.grad, 1e-4)
+    if training:
+        check(t + ".running_mean", rm, fc[1].running_mean, 1e-6)
+        check(t + ".running_var", rv, fc[1].running_var, 1e-6)
+    else:
+        assert torch.equal(rm.cpu(), rm0) and torch.equal(rv.cpu(), rv0)
+
+
 def F_layer_norm(x, w, b):
     return torch.nn.functional.layer_norm(x, (256,), w, b, 1e-5)
 
