@@ -33,6 +33,11 @@ def _lin_ln_relu(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     return seq(x)
 
 
+# The image / text input chains run on side streams on purpose (their backward tails overlap); autograd's warning
+# about AccumulateGrad nodes living on another stream than their gradient's producer is expected then.
+_quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+if _quiet is not None:
+    _quiet(False)
 _NO_SIDE_INPUTS = bool(os.environ.get("MTMP_NO_SIDE_INPUTS"))   # A/B switch: input chains on the main stream
 _TORCH_SMALL = bool(os.environ.get("MTMP_TORCH_SMALL"))     # A/B switch: the torch op chains instead of ops.TimeEmbed / DataLinearFn
 

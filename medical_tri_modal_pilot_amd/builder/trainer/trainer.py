@@ -95,6 +95,11 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
     if cu_seqlens is not None:       # t_pad rides in the graph signature as the shape of an empty tensor
         packed_extra = dict(cu_seqlens=cu_seqlens, t_pad_marker=torch.empty(t_pad, 0, device=device))
 
+    red = getattr(optimizer, "reducer", None)
+    if red is not None and not getattr(red, "_mtmp_streams_set", False) and hasattr(model, "fusion_transformer"):
+        red.extra_streams = list(model.fusion_transformer._side_streams(torch.device(device)) or [])
+        red._mtmp_streams_set = True
+
     def run_model(t=None):
         if t is None:
             t = dict(data=data, age=age, gender=gender, input_lengths=input_lengths, x_txt=x_txt,

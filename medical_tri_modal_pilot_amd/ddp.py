@@ -32,6 +32,10 @@ class GradReducer:
         self.world = dist.get_world_size(group)
         self.cuda = flat.grad.is_cuda
         self.side = torch.cuda.Stream(device=flat.grad.device) if self.cuda else None
+        # other streams gradients are produced on (the encoder's modality side streams): a bucket's all-reduce waits
+        # for everything enqueued on them too -- the slice that completed the bucket says nothing about its
+        # neighbours written from another stream
+        self.extra_streams: List["torch.cuda.Stream"] = []
         # buckets: contiguous [lo, hi) element ranges, built from the END of the flat buffer
         self.buckets: List[List[int]] = []       # [lo, hi, n_params]
         self.bucket_of = [0] * len(flat.params)
@@ -71,6 +75,8 @@ class GradReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.side.wait_event(ev)
+            for s in self.extra_streams:
+                self.side.wait_stream(s)
             with torch.cuda.stream(self.side):
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
