@@ -152,6 +152,10 @@ int mtmp_head_bwd(const float* d_out, const float* cls, const float* age, const 
                   const float* ws_fwd, float* dcls, float* g_rows, float* dw1, float* g_feat, float* db2, float* ws_bwd, int B,
                   float ln_eps, int training, void* stream);
 
+/* BCEWithLogitsLoss(reduction="mean") (2_train.py:76, trainer.py:128): loss[0] = mean_b [max(o,0) - o t + log1p(exp(-|o|))],
+ * dlogit[b] = (sigmoid(o_b) - t_b) / n; logits / target / dlogit float[n]. */
+int mtmp_bce_logits_mean(const float* logits, const float* target, float* loss, float* dlogit, int n, void* stream);
+
 /* Swin-T patch-embedding stem: Conv2d(1,96,4,stride 4) -> NHWC -> LayerNorm(96)
  * (builder/models/src/swin_transformer.py:559-567,646) as an implicit GEMM.
  * img float[n_img,1,H,W]; out [n_img,H/4,W/4,96] in `dtype`. */

@@ -212,7 +212,28 @@ __global__ __launch_bounds__(256) void head_rows_reduce_kernel(const float* slab
     out[c] = s;
 }
 
+// BCEWithLogitsLoss(reduction="mean") (2_train.py:76, trainer.py:128): loss = mean_b [max(o,0) - o t + log(1 + exp(-|o|))];
+// dlogit[b] = (sigmoid(o) - t) / n is produced alongside (the backward is a scale by the incoming scalar).
+__global__ __launch_bounds__(256) void bce_logits_kernel(const float* o, const float* t, float* loss, float* dlogit, int n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float x = o[i], y = t[i];
+        s += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+        dlogit[i] = (1.0f / (1.0f + expf(-x)) - y) / (float)n;
+    }
+    s = block_sum(s, red, threadIdx.x);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+
 }  // namespace
+
+extern "C" int mtmp_bce_logits_mean(const float* logits, const float* target, float* loss, float* dlogit, int n, void* stream) {
+    MTMP_CHECK_ARG(logits && target && loss && dlogit && n > 0, "mtmp_bce_logits_mean: bad argument");
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, dlogit, n);
+    MTMP_CHECK_LAUNCH("mtmp_bce_logits_mean");
+    return MTMP_OK;
+}
 
 // ws_fwd: x[B][512] + hhat[B][256] + rstd[256] + partial[64][64] floats (kept for the backward)
 extern "C" int mtmp_head_ws_floats(int B) { return B * DX + B * D + D + (D / FPW) * MAXB; }

@@ -423,6 +423,35 @@ class HeadFn(torch.autograd.Function):
         return (dcls, None, None, None, None, None, None, None) + tuple(sink_param_grads(ctx.prm, list(grads)))
 
 
+class BceLogitsMean(torch.autograd.Function):
+    """torch.nn.BCEWithLogitsLoss(reduction="mean") on fp32 logits (2_train.py:76): one launch forward, one scale backward."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _gpu(logits)
+        o, t = _c(logits.detach().float().reshape(-1)), _c(target.detach().float().reshape(-1))
+        loss = torch.empty(1, dtype=torch.float32, device=o.device)
+        d = torch.empty_like(o)
+        call("mtmp_bce_logits_mean", _p(o), _p(t), _p(loss), _p(d), o.numel(), _stream())
+        ctx.save_for_backward(d)
+        ctx.shape = logits.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return (d * g).view(ctx.shape), None
+
+
+def bce_with_logits(criterion, output, target):
+    """criterion(output, target), through BceLogitsMean when it is the plain mean-reduced BCEWithLogitsLoss on the GPU."""
+    if (isinstance(criterion, torch.nn.BCEWithLogitsLoss) and criterion.reduction == "mean" and criterion.weight is None
+            and criterion.pos_weight is None and output.is_cuda and output.dtype == torch.float32
+            and output.shape == target.shape):
+        return BceLogitsMean.apply(output, target)
+    return criterion(output, target)
+
+
 # ----------------------------------------------------------------------------- stream input (K4)
 class StreamInputFn(torch.autograd.Function):
     """mbt_encoder.py:697-729 + the [bottleneck | CLS | tokens] concatenation of :745 as one launch each way.

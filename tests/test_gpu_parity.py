@@ -395,6 +395,20 @@ def test_head_vs_torch_modules(ops, training, B):
         assert torch.equal(rm.cpu(), rm0) and torch.equal(rv.cpu(), rv0)
 
 
+def test_bce_logits_mean_vs_torch(ops):
+    g = torch.Generator().manual_seed(2)
+    for n in (1, 4, 64, 300):
+        o = (4 * torch.randn(n, generator=g)).requires_grad_()
+        t = torch.randint(0, 2, (n,), generator=g).float()
+        ref = torch.nn.functional.binary_cross_entropy_with_logits(o, t)
+        (3.0 * ref).backward()
+        od = o.detach().clone().to(DEV).requires_grad_()
+        loss = ops.bce_with_logits(torch.nn.BCEWithLogitsLoss(), od, t.to(DEV))
+        (3.0 * loss).backward()
+        check(f"bce[{n}].loss", loss, ref, 1e-6)
+        check(f"bce[{n}].dlogit", od.grad, o.grad, 1e-5)
+
+
 def F_layer_norm(x, w, b):
     return torch.nn.functional.layer_norm(x, (256,), w, b, 1e-5)
 
