@@ -207,11 +207,13 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # ---- image stream: frozen Swin-T -> [B*K,7,7,768] -> flatten -> Linear(768,256) (:205-211)
         if self.args.multiimages == 1:
             img = img.reshape(-1, 1, img.shape[-2], img.shape[-1])
-        with torch.no_grad():
-            feat = self.img_encoder(img)
-        feat = self.flatten(feat)
-        if side is not None:
-            side[0].wait_stream(cur)                 # the frozen encoder ran on the main stream
+        # The frozen encoder itself runs on the image side stream: nothing of the vital-sign stream depends on it before
+        # the first bottleneck exchange, so the main stream goes on (TIE embedding, stream input, the vital-sign
+        # stream's first layer) beside the encoder's small-M stages, which cannot fill the chip on their own.
+        with on_side(0):
+            with torch.no_grad():
+                feat = self.img_encoder(img)
+            feat = self.flatten(feat)
         with on_side(0):
             img_embedding = (F.linear(feat, self.linear.weight.to(dt), self.linear.bias.to(dt)) if _TORCH_SMALL else
                              ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt))

@@ -118,9 +118,8 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             if self.use_pe[m]:
                 y = y + self.positional_encoding(x.size(1))
             streams.append(self.dropout(y).to(dt))
-        if side_in is not None:
-            for s_ in side_in:
-                torch.cuda.current_stream().wait_stream(s_)
+        # (no join here when the inputs live on the side streams: ops.FusionStackFn issues each modality's first layer
+        #  on that same stream and joins at the first bottleneck exchange)
         kv_plain = [None if l is None else l.to(torch.int32).contiguous() for l in lens]
         kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
         missing = missing.to(dev).long()

@@ -688,6 +688,9 @@ class FusionStackFn(torch.autograd.Function):
             bottleneck_exchange_fwd(outs, cfg["missing"], cfg["resbottle"], prev_bott if cfg["resbottle"] else None, keep)
             prev_bott = keep
             z = outs
+        if streams is not None and cfg.get("prebuilt"):
+            for s in streams:              # inputs made on the side streams but never consumed there (single vslt-only layer)
+                cur.wait_stream(s)
         ctx.saved, ctx.active, ctx.cfg, ctx.wsel = saved, active, cfg, wsel
         ctx.shapes = (B, Ns, [p.shape for p in params])
         ctx.set_materialize_grads(False)
