@@ -97,14 +97,13 @@ class PackedTieBatch:
     def on_device(self, device, t_pad: int, bucket: int = 0) -> PackedTie:
         """Events through the trainer's fp16 rounding (2_train.py:164) on ``device``; ``bucket`` > 0 rounds the
         event count up to a multiple (zero rows, never read) so that hipGraph replays see few distinct shapes."""
-        ev = self.events
+        ev = self.events.to(device, non_blocking=True).half().float()
         if bucket > 0:
             n = -(-max(ev.shape[0], 1) // bucket) * bucket
-            if n != ev.shape[0]:
-                pad = torch.zeros(n, 3, dtype=ev.dtype)
+            if n != ev.shape[0]:             # padded on the device: pinning a fresh host buffer costs milliseconds per step
+                pad = torch.zeros(n, 3, dtype=ev.dtype, device=ev.device)
                 pad[:ev.shape[0]] = ev
-                ev = pad.pin_memory() if ev.is_pinned() else pad
-        ev = ev.to(device, non_blocking=True).half().float()
+                ev = pad
         return PackedTie(ev, self.cu_seqlens.to(device, non_blocking=True), int(t_pad))
 
 
