@@ -359,29 +359,12 @@ template <typename T> struct TileStream {
 // =============================== backward ===================================
 template <typename T> struct AttnBwdArgs {
     const T* q; const T* k; const T* v; const T* d_o;
-    const float* lse; const float* delta; const int* kv_len;
+    const float* lse; float* delta; const int* kv_len;     // delta: written by the dQ kernel, read by the dK/dV kernel
     T* dq; T* dk; T* dv;
     int B, N, H, ld_qkv, ld_do, ld_dqkv;
     float scale;
+    const T* o; int ld_o;
 };
-
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]; one wave per token row (4 heads x 64).
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, const T* d_o, float* delta, int B, int N, int H,
-                                                         int ld_o, int ld_do) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= B * N) return;
-    f32x4 a = load4<T>(o + (size_t)row * ld_o + 4 * lane);
-    f32x4 g = load4<T>(d_o + (size_t)row * ld_do + 4 * lane);
-    float s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if ((lane & 15) == 0) {
-        const int b = row / N, q = row - b * N, hd = lane >> 4;
-        if (hd < H) delta[((size_t)b * H + hd) * N + q] = s;
-    }
-}
 
 // rows >= limit - row0 of a fetched tile -> 0 (ragged key tiles of the dQ kernel)
 template <typename T> MTMP_DEV TileR<T> tile_zero_rows(const TileR<T>& x, int row0, int limit, int tid) {
@@ -428,9 +411,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
                            qrow < p.N);
     }
     const size_t sidx = ((size_t)b * p.H + hd) * p.N + min(qrow, p.N - 1);
+    // delta[q] = sum_d dO[q,d] O[q,d] (the softmax backward's row constant) is computed here, from the dO fragments
+    // this lane already holds and the matching O fragments, and handed to the dK/dV kernel through p.delta -- the
+    // separate delta pass (one launch, 66 MB of traffic per call) is gone; the dQ kernel therefore runs FIRST.
+    float dsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const Frag<T> of = frag_load<T>(p.o + ((size_t)b * p.N + min(qrow, p.N - 1)) * p.ld_o + hd * DH + 16 * c + 8 * half);
+#pragma unroll
+        for (int jx = 0; jx < 8; ++jx) dsum = fmaf(to_f32(dof[c].v[jx]), to_f32(of.v[jx]), dsum);
+    }
+    dsum = half_sum(dsum);                                 // the two half-lanes hold the two halves of the row
+    if (qrow < p.N && half == 0) p.delta[sidx] = dsum;
     // rows past N: -LSE = -inf makes p = 0 whatever the (zero) fragments give
     const float nL = (qrow < p.N) ? -p.lse[sidx] : -INFINITY;
-    const float nD = (qrow < p.N) ? -p.delta[sidx] : 0.f;
+    const float nD = (qrow < p.N) ? -dsum : 0.f;
     f32x16 cL, cD;                            // the row constants in every register: C operands
 #pragma unroll
     for (int t = 0; t < 16; ++t) { cL[t] = nL; cD[t] = nD; }
@@ -738,18 +733,15 @@ template <typename T>
 int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                const int* kv_len, void* dq, void* dk, void* dv, float* delta, int B, int N, int H, int ld_qkv,
                int ld_o, int ld_do, int ld_dqkv, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((B * N + 3) / 4), dim3(256), 0, st, (const T*)o, (const T*)d_o,
-                       delta, B, N, H, ld_o, ld_do);
-    MTMP_CHECK_LAUNCH("mtmp_attn_bwd(delta)");
     AttnBwdArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, kv_len,
-                     (T*)dq, (T*)dk, (T*)dv, B, N, H, ld_qkv, ld_do, ld_dqkv, scale};
+                     (T*)dq, (T*)dk, (T*)dv, B, N, H, ld_qkv, ld_do, ld_dqkv, scale, (const T*)o, ld_o};
     const int nwg = ((N + 127) / 128) * H * B;
+    if (int e = set_smem(attn_bwd_dq_kernel<T>, dq_smem<T>())) return e;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(nwg), dim3(256), dq_smem<T>(), st, a);      // also writes delta
+    MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dq)");
     if (int e = set_smem(attn_bwd_dkdv_kernel<T>, dkdv_smem<T>())) return e;
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(nwg), dim3(256), dkdv_smem<T>(), st, a);
     MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dkdv)");
-    if (int e = set_smem(attn_bwd_dq_kernel<T>, dq_smem<T>())) return e;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(nwg), dim3(256), dq_smem<T>(), st, a);
-    MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dq)");
     return MTMP_OK;
 }
 
@@ -780,7 +772,6 @@ extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void
     MTMP_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv && delta_ws, "mtmp_attn_bwd: null pointer");
     MTMP_CHECK_ARG(attn_shape_ok(B, N, H, ld_qkv, ld_o) && attn_shape_ok(B, N, H, ld_do, ld_dqkv),
                    "mtmp_attn_bwd: bad shape B=%d N=%d H=%d", B, N, H);
-    MTMP_CHECK_ARG(H == 4, "mtmp_attn_bwd: the delta pass assumes 4 heads x 64 (d_model 256), got H=%d", H);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         return launch_bwd<float>(q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, B, N, H, ld_qkv, ld_o, ld_do,
