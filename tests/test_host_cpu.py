@@ -146,6 +146,33 @@ def test_flat_params_views_and_grads():
     assert float(flat.data[: 15].sum()) == pytest.approx(float(before["0.weight"].sum()) + 15, rel=1e-5)
 
 
+def test_sink_param_grads_writes_single_use_gradients_into_the_flat_buffer():
+    """ops.sink_param_grads: gradients of single-use parameters go straight into their FlatParams slices (and the
+    DDP ready callback fires); a slice that was already written this step, or a parameter outside the flat buffer,
+    falls back to returning the gradient to autograd."""
+    from medical_tri_modal_pilot_amd import ops
+    from medical_tri_modal_pilot_amd.optim import FlatParams
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    flat = FlatParams(lin.named_parameters())
+    flat.zero_grad()
+    ready = []
+    flat.ready_cb = ready.append
+    w, b = lin[0].weight, lin[0].bias
+    gw, gb = torch.randn(3, 5), torch.randn(3)
+    out = ops.sink_param_grads([w, b], [gw, gb])
+    assert out == [None, None]
+    assert torch.equal(w.grad, gw) and torch.equal(b.grad, gb)
+    assert sorted(ready) == sorted(flat.index_of[id(q)] for q in (w, b))
+    again = ops.sink_param_grads([w, b], [gw, gb])            # second writer in the same step: autograd must accumulate
+    assert again[0] is gw and again[1] is gb
+    flat.zero_grad()
+    assert ops.sink_param_grads([w, b], [gw, gb]) == [None, None]          # claim released by zero_grad
+    stray = torch.nn.Parameter(torch.zeros(4))
+    g = torch.ones(4)
+    assert ops.sink_param_grads([stray], [g])[0] is g
+    assert ops.sink_param_grads([w, stray], [gw, g])[1] is g
+
+
 DDP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["MTMP_ROOT"])
