@@ -736,6 +736,43 @@ def test_graph_replay_equals_eager_steps(ops):
     REPORT["graph_vs_eager[fp32].5_steps"] = {"rel_err": 0.0, "tol": 0.0}
 
 
+def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
+    """The data-parallel path on the one GPU of this box: RCCL process group of one rank, ddp.GradReducer attached to
+    FusedAdamW (bucketed all-reduce of the flat gradient on a side stream, ready callbacks from the kernels that write
+    gradients directly, the modality side streams joined before each bucket).  With one rank the all-reduce is the
+    identity, so losses and parameters must equal the plain run bit for bit -- eager (overlapped buckets) and graph."""
+    import torch.distributed as dist
+    from medical_tri_modal_pilot_amd.ddp import GradReducer
+    import medical_tri_modal_pilot_amd.optim as optim_mod
+    full = [[96, 96, 50, 7]] * 4
+    ref = {g: _loop(g, 0.0, "fp32", 4, full)[:2] for g in (0, 1)}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29677")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    orig_init = optim_mod.FusedAdamW.__init__
+    made = []
+
+    def init_with_reducer(self, *a, **k):
+        orig_init(self, *a, **k)
+        self.reducer = GradReducer(self.flat)
+        self.grad_scale = 1.0
+        made.append(self.reducer)
+
+    optim_mod.FusedAdamW.__init__ = init_with_reducer
+    try:
+        for g in (0, 1):
+            losses, flat, _ = _loop(g, 0.0, "fp32", 4, full)
+            assert losses == ref[g][0], (g, losses, ref[g][0])
+            assert torch.equal(flat, ref[g][1]), g
+        assert made and all(len(r.buckets) >= 1 for r in made)
+    finally:
+        optim_mod.FusedAdamW.__init__ = orig_init
+        for r in made:
+            r.remove()
+        dist.destroy_process_group()
+    REPORT["ddp_single_rank_vs_plain[fp32]"] = {"rel_err": 0.0, "tol": 0.0}
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_graph_full_size_training_tracks_eager(ops, overlap):
     """Bench-sized steps (B 64, T 1000, 6 layers, frozen Swin in train mode like 2_train.py:128) with the optimizer
