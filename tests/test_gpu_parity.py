@@ -736,6 +736,49 @@ def test_graph_replay_equals_eager_steps(ops):
     REPORT["graph_vs_eager[fp32].5_steps"] = {"rel_err": 0.0, "tol": 0.0}
 
 
+def test_cfg1_sample_data_windows_product_vs_oracle(ops):
+    """BASELINE configs[0] shape on the reference's own sample data: real TIE windows (the reference's `__getitem__`
+    goldens, tests/golden/tie_windows.npz), B 4, TIE-len 256, 2 layers, image and text missing (missing_num 3), fed as
+    a ragged PackedTieBatch -- HIP train step (fp32 build) against the CPU oracle's step on the padded batch."""
+    from medical_tri_modal_pilot_amd.builder.data import collate_packed
+    from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    g = G("tie_windows")
+    off = np.concatenate([[0], np.cumsum(g["seq_rows"])])
+    want = [c for c in range(len(g["case"])) if g["case"][c][0] == 1 and g["case"][c][1] == 1000 and 20 <= g["len"][c] <= 256]
+    pick = [want[0], want[len(want) // 3], want[2 * len(want) // 3], want[-1]]
+    B, T = 4, 256
+    samples = [(g["seq_cat"][off[c]:off[c] + int(g["len"][c])], g["static"][c], g["ttime"][c]) for c in pick]
+    pb = collate_packed(samples)
+    x_pad = pb.to_padded(T)
+    bt = dict(x=x_pad, age=pb.static[:, 1].clone(), gen=pb.static[:, 0].clone(), input_lengths=pb.input_lengths,
+              txt=torch.zeros(B, 128, 768), txt_lengths=torch.zeros(B, dtype=torch.long), img=torch.zeros(B, 1, 224, 224),
+              img_time=torch.full((B,), -1.0), txt_time=pb.txt_time.clone(), y=torch.tensor([0, 1, 1, 0]),
+              missing=torch.tensor([[0., 1., 1.]] * B))
+    args, model = _product_model(2, 0, "fp32", hip_graph=0)
+    args.TIE_len = T
+    sd = _model_sd(2)
+    model.train()
+    model.img_encoder.eval()
+    opt = FusedAdamW(model.hot_parameters(), lr=args.lr_init, weight_decay=args.weight_decay)
+    sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=args.t_0 * 10, cycle_mult=args.t_mult,
+                                          max_lr=args.lr_init * math.sqrt(args.batch_size), min_lr=1e-6,
+                                          warmup_steps=args.t_up * 10, gamma=args.gamma)
+    kw = dict(args=args, x=pb, static=pb.static, y=bt["y"], output_lengths=None, model=model, logger=_Logger(),
+              device=torch.device(DEV), scheduler=sched, optimizer=opt, criterion=torch.nn.BCEWithLogitsLoss(),
+              x_txt=bt["txt"], x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None,
+              missing=bt["missing"], reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+    _, loss1 = get_trainer(iteration=1, input_lengths=pb.input_lengths, txt_lengths=bt["txt_lengths"], flow_type="train", **kw)
+    _, loss2 = get_trainer(iteration=2, input_lengths=pb.input_lengths, txt_lengths=bt["txt_lengths"], flow_type="train", **kw)
+    tr = O.OracleTrainer(sd, O.Cfg(n_layers=2), lr_init=args.lr_init, batch_size=args.batch_size, iters_per_epoch=10)
+    ref1 = tr.step(bt, 1)
+    ref2 = tr.step(bt, 2)
+    REPORT["cfg1_sample_data.loss1"] = {"rel_err": abs(loss1 - ref1), "tol": 1e-4}
+    REPORT["cfg1_sample_data.loss2"] = {"rel_err": abs(loss2 - ref2), "tol": 1e-4}
+    assert abs(loss1 - ref1) < 1e-4 and abs(loss2 - ref2) < 1e-4, (loss1, ref1, loss2, ref2)
+
+
 def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
     """The data-parallel path on the one GPU of this box: RCCL process group of one rank, ddp.GradReducer attached to
     FusedAdamW (bucketed all-reduce of the flat gradient on a side stream, ready callbacks from the kernels that write
