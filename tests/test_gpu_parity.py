@@ -63,7 +63,8 @@ DT = [torch.float32, torch.bfloat16]
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("N,lens", [(54, None), (54, [54, 4, 30, 7]), (133, [133, 4, 5, 90]),
-                                    (261, [261, 200, 4, 64]), (40, [0, 17, 40, 1]), (1005, [1005, 700])])
+                                    (261, [261, 200, 4, 64]), (40, [0, 17, 40, 1]), (1005, [1005, 700]),
+                                    (2005, [2005, 1290])])        # configs[4]: TIE-len 2000
 def test_attention_fwd_bwd(ops, dt, N, lens):
     g = torch.Generator().manual_seed(7 + N)
     B = 4 if lens is None else len(lens)
