@@ -158,6 +158,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
     def forward(self, x, h, m, d, x_m, age, gen, input_lengths, txts, txt_lengths, img, missing, f_indices, img_time,
                 txt_time, flow_type, reports_tokens, reports_lengths):
         dt = self.compute_dtype
+        ops.mark("fwd.s")
         if isinstance(x, PackedTie):
             if self.args.vslt_type == "carryforward":
                 raise ValueError("a packed TIE batch needs --vslt-type TIE or QIE")
@@ -211,9 +212,11 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # the first bottleneck exchange, so the main stream goes on (TIE embedding, stream input, the vital-sign
         # stream's first layer) beside the encoder's small-M stages, which cannot fill the chip on their own.
         with on_side(0):
+            ops.mark("swin.s")
             with torch.no_grad():
                 feat = self.img_encoder(img)
             feat = self.flatten(feat)
+            ops.mark("swin.e")
         with on_side(0):
             img_embedding = (F.linear(feat, self.linear.weight.to(dt), self.linear.bias.to(dt)) if _TORCH_SMALL else
                              ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt))
@@ -249,6 +252,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         else:
             img_len = img_embedding.size(1)
         self.fusion_transformer.inputs_on_side_streams = side is not None
+        ops.mark("inputs.e")
         outputs, _ = self.fusion_transformer(
             enc_outputs=[vslt_embedding, img_embedding, txt_embedding],
             fixed_lengths=[vslt_embedding.size(1), img_embedding.size(1), txt_embedding.size(1)],
@@ -256,6 +260,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # ---- head (:248-255), fp32
         cls = self.fusion_transformer.last_cls             # outputs[0][:, 0, :] as a dedicated autograd output
         cls = (outputs[0][:, 0, :] if cls is None else cls).float()
+        ops.mark("stack.e")
         if fused_head:
             bn, ln, dm = self.fc_list[1], self.layer_norms_after_concat, self.ie_demo
             if bn.training and bn.track_running_stats:

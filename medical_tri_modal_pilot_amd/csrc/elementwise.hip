@@ -672,3 +672,14 @@ extern "C" int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, v
     MTMP_CHECK_LAUNCH("mtmp_bottleneck_exchange_bwd");
     return MTMP_OK;
 }
+
+// Diagnostic: one lane stores the 100 MHz wall clock into *slot.  Launched between the kernels of a step (also inside a
+// captured hipGraph, where HIP events cannot be timed) to get an un-profiled per-stream timeline (tools/dbg/timeline.py).
+__global__ void mark_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
+extern "C" int mtmp_debug_mark(unsigned long long* slot, void* stream) {
+    MTMP_CHECK_ARG(slot, "mtmp_debug_mark: null slot");
+    hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+    MTMP_CHECK_LAUNCH("mtmp_debug_mark");
+    return MTMP_OK;
+}

@@ -46,6 +46,32 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Diagnostic time stamps (tools/dbg/timeline.py): off unless marks_enable() was called.  mark(name) launches a one-lane kernel
+# on the current stream that stores the wall clock into the slot of `name`; inside a captured step the launches become graph
+# nodes, so every replay refreshes the slots.
+_marks: Optional[torch.Tensor] = None
+_mark_slots: dict = {}
+
+
+def marks_enable(device, n: int = 1024):
+    global _marks
+    _marks = torch.zeros(n, dtype=torch.int64, device=device)
+    _mark_slots.clear()
+
+
+def mark(name: str):
+    if _marks is None:
+        return
+    i = _mark_slots.setdefault(name, len(_mark_slots))
+    call("mtmp_debug_mark", _p(_marks, 8 * i), _stream())
+
+
+def marks_read() -> dict:
+    """{name: microseconds} of the last pass over every mark (100 MHz counter)."""
+    v = _marks.cpu().tolist()
+    return {k: v[i] / 100.0 for k, i in _mark_slots.items()}
+
+
 # Device-resident step word of the dropout masks.  The scalar `seed` arguments below are frozen into a captured
 # hipGraph; the kernels XOR them with the low 32 bits of this int64 word, which graph.GraphedTrainStep advances
 # inside the graph, so every replay draws fresh masks.  None (eager mode) = NULL pointer = plain scalar seeds.
@@ -670,11 +696,15 @@ class FusionStackFn(torch.autograd.Function):
                     s = streams[m - 1]
                     s.wait_event(ev)
                     with torch.cuda.stream(s):
+                        mark(f"f{li}.m{m}.s")
                         outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
                                                         cfg["seeds"][li][m])
+                        mark(f"f{li}.m{m}.e")
                 else:
+                    mark(f"f{li}.m{m}.s")
                     outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
                                                     cfg["seeds"][li][m])
+                    mark(f"f{li}.m{m}.e")
             if streams is not None and len(ms) > 1:
                 for s in streams:
                     cur.wait_stream(s)
@@ -735,9 +765,13 @@ class FusionStackFn(torch.autograd.Function):
                     s = streams[m - 1]
                     s.wait_event(ev)
                     with torch.cuda.stream(s):
+                        mark(f"b{li}.m{m}.s")
                         nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
+                        mark(f"b{li}.m{m}.e")
                 else:
+                    mark(f"b{li}.m{m}.s")
                     nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
+                    mark(f"b{li}.m{m}.e")
                 base = (li * 3 + m) * PARAMS_PER_LAYER
                 if g is not None:
                     for k in range(PARAMS_PER_LAYER):

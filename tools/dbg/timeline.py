@@ -1,0 +1,44 @@
+"""Un-profiled timeline of one replayed training step: wall-clock stamps (ops.mark -> mtmp_debug_mark, one-lane kernels that
+are captured into the hipGraph like any other launch) at the start/end of the frozen image encoder, of every fusion
+layer of every modality stream (forward and backward), around the graph replay and the AdamW kernel.
+
+    python tools/dbg/timeline.py [bench.py flags]
+"""
+import atexit, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from medical_tri_modal_pilot_amd import graph as G, optim as O, ops
+
+ops.marks_enable(torch.device("cuda", 0))
+_run, _step = G.GraphedTrainStep.run, O.FusedAdamW.step
+
+
+def run(self, inputs, fn, params=None):
+    ops.mark("step.s")
+    out = _run(self, inputs, fn, params)
+    ops.mark("graph.e")
+    return out
+
+
+def step(self, closure=None):
+    r = _step(self, closure)
+    ops.mark("adamw.e")
+    return r
+
+
+G.GraphedTrainStep.run, O.FusedAdamW.step = run, step
+
+
+@atexit.register
+def report():
+    torch.cuda.synchronize()
+    t = ops.marks_read()
+    t0 = t.get("step.s", min(t.values()))
+    for k, v in sorted(t.items(), key=lambda kv: kv[1]):
+        print("%9.1f us  %s" % (v - t0, k), file=sys.stderr)
+
+
+sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "20", "--warmup", "8", "--probe-steps", "0"] + sys.argv[1:]
+import runpy
+runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
