@@ -173,19 +173,6 @@ class TRI_MBT_VSLTCLS(nn.Module):
         if not fused_head:
             demographic = torch.stack([age, gen], dim=1)
             demo_embedding = self.ie_demo(demographic)                                        # [B,256] fp32
-        # ---- vital-sign / lab stream
-        if self.args.vslt_type == "carryforward":
-            vslt_embedding = self.vslt_enc(x).to(dt)
-        else:
-            tie_prm = (self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight, self.ie_vslt[1].bias,
-                       self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight, self.ie_time[1].bias,
-                       self.ie_feat.weight, dt)
-            if isinstance(x, PackedTie):      # ragged batch of builder/data (events, cu_seqlens, t_pad), SURVEY 8 f-1
-                vslt_embedding = ops.TieEmbedPacked.apply(x.events, x.cu_seqlens, x.t_pad, *tie_prm)
-            else:
-                vslt_embedding = ops.TieEmbed.apply(x, *tie_prm)                              # [B,T,256]
-            if self.args.vslt_type == "QIE":
-                vslt_embedding = vslt_embedding + demo_embedding.unsqueeze(1).to(dt)
         # The image and text input chains (projection, time embedding add, and -- inside the encoder -- the stream
         # input kernel) are issued on the encoder's two side HIP streams: autograd runs a node's backward on the
         # stream of its forward, so the three modalities' input-side backward tails (all small, latency-bound
@@ -220,6 +207,19 @@ class TRI_MBT_VSLTCLS(nn.Module):
         with on_side(0):
             img_embedding = (F.linear(feat, self.linear.weight.to(dt), self.linear.bias.to(dt)) if _TORCH_SMALL else
                              ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt))
+        # ---- vital-sign / lab stream
+        if self.args.vslt_type == "carryforward":
+            vslt_embedding = self.vslt_enc(x).to(dt)
+        else:
+            tie_prm = (self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight, self.ie_vslt[1].bias,
+                       self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight, self.ie_time[1].bias,
+                       self.ie_feat.weight, dt)
+            if isinstance(x, PackedTie):      # ragged batch of builder/data (events, cu_seqlens, t_pad), SURVEY 8 f-1
+                vslt_embedding = ops.TieEmbedPacked.apply(x.events, x.cu_seqlens, x.t_pad, *tie_prm)
+            else:
+                vslt_embedding = ops.TieEmbed.apply(x, *tie_prm)                              # [B,T,256]
+            if self.args.vslt_type == "QIE":
+                vslt_embedding = vslt_embedding + demo_embedding.unsqueeze(1).to(dt)
         img_time = img_time.reshape(-1).float()
         txt_time = txt_time.float()
         if self.args.imgtxt_time == 1:                                                        # (:216-224)

@@ -96,16 +96,22 @@ constexpr int LDO = BN + 8;
 // features each) -- the smaller tile is used when a launch would otherwise have fewer workgroups than ~2 per CU
 // (frozen-encoder stages 3-4, the image / text streams): such launches are bound by the latency chain of ONE
 // workgroup per CU, and more, smaller workgroups overlap their chains.
+#ifndef MTMP_NT_RT128
+#define MTMP_NT_RT128 1
+#endif
 template <int TM> struct NtGeom {
-    static constexpr int WR = TM / 32, WC = 4 / WR, NT = 4 / WC;     // row waves, column waves, 32-feature tiles per wave
+    // RT x NT 32x32 tiles per wave, WR x WC waves.  TM = 128: 4 x 1 waves of 32 tokens x 128 features (-DMTMP_NT_RT128=2:
+    // 2 x 2 waves of 64 x 64, one operand fragment fewer per 4 MFMAs -- measured 5-10 % SLOWER on every shape of
+    // tools/bench_kernels.py: 7 spilled VGPRs under the 128-register cap); TM = 64: 2 x 2 waves of 32 x 64.
+    static constexpr int RT = TM == 128 ? MTMP_NT_RT128 : 1;
+    static constexpr int WR = TM / (32 * RT), WC = 4 / WR, NT = 4 / WC;
 };
 
 template <typename T, bool RELU, int TM>
-MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::NT], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
+MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
     using G = NtGeom<TM>;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int wr = wave % G::WR, foff = (wave / G::WR) * 32 * G::NT;
-    const int row = min(m0 + 32 * wr + r, p.M - 1);
     const unsigned thr = dropout_threshold(p.drop_p);
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
     const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
@@ -125,23 +131,27 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::NT], const GemmArgs<T>& p
             rv[ps] = frag_load<T>(p.res + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.ldr + gcolc);
     }
 #pragma unroll
-    for (int nt = 0; nt < G::NT; ++nt) {
-        if (n0 + foff + 32 * nt >= p.N) continue;
+    for (int rt = 0; rt < G::RT; ++rt) {
+        const int rl = 32 * (G::RT * wr + rt) + r, row = min(m0 + rl, p.M - 1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cl = foff + 32 * nt + 8 * g + 4 * half, col = n0 + cl;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-            float v[4];
-            const unsigned keep = p.drop_p > 0.f ? dropout_keep4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
+        for (int nt = 0; nt < G::NT; ++nt) {
+            if (n0 + foff + 32 * nt >= p.N) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = acc[nt][4 * g + i] + bv[i];
-                if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
-                if (p.act == 2) v[i] = gelu<T>(v[i]);
-                if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const int cl = foff + 32 * nt + 8 * g + 4 * half, col = n0 + cl;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+                float v[4];
+                const unsigned keep = p.drop_p > 0.f ? dropout_keep4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[rt][nt][4 * g + i] + bv[i];
+                    if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
+                    if (p.act == 2) v[i] = gelu<T>(v[i]);
+                    if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
+                }
+                store4<T>(sOut + rl * LDO + cl, v[0], v[1], v[2], v[3]);
             }
-            store4<T>(sOut + (32 * wr + r) * LDO + cl, v[0], v[1], v[2], v[3]);
         }
     }
     __syncthreads();
@@ -374,16 +384,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) voi
     TileRegs<T> areg, wreg;
     tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, 0, tid, p.K);
     tile_fetch<T>(wreg, p.w, p.K, n0, p.N, 0, tid, p.K);
-    f32x16 acc[G::NT];
+    f32x16 acc[G::RT][G::NT];
 #pragma unroll
-    for (int nt = 0; nt < G::NT; ++nt) acc[nt] = f32x16{0};
+    for (int rt = 0; rt < G::RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < G::NT; ++nt) acc[rt][nt] = f32x16{0};
     auto multiply = [&]() {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const Frag<T> a = frag_load<T>(sA + (32 * wr + r) * LDW + 16 * c + 8 * half);
+            Frag<T> a[G::RT];
 #pragma unroll
-            for (int nt = 0; nt < G::NT; ++nt)
-                mma<T>(acc[nt], frag_load<T>(sW + (foff + 32 * nt + r) * LDW + 16 * c + 8 * half), a);
+            for (int rt = 0; rt < G::RT; ++rt) a[rt] = frag_load<T>(sA + (32 * (G::RT * wr + rt) + r) * LDW + 16 * c + 8 * half);
+#pragma unroll
+            for (int nt = 0; nt < G::NT; ++nt) {
+                const Frag<T> w = frag_load<T>(sW + (foff + 32 * nt + r) * LDW + 16 * c + 8 * half);
+#pragma unroll
+                for (int rt = 0; rt < G::RT; ++rt) mma<T>(acc[rt][nt], w, a[rt]);
+            }
         }
     };
     if constexpr (TM == 64 && sizeof(T) == 2) {
