@@ -172,6 +172,15 @@ int mtmp_swin_stem_fwd(int dtype, const float* img, const float* w, const float*
 int mtmp_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* y, long long rows, int C,
                         float eps, int merge, int H, int W, void* stream);
 
+/* MLP half of a Swin block in one launch (swin_transformer.py:428-449, torchvision MLP keys mlp.0 / mlp.3):
+ * y[M,C] = x + row_scale[row / rows_per_scale] * (gelu(LayerNorm(x; ln_w, ln_b, eps) W1^T + b1) W2^T + b2).
+ * Replaces mtmp_layernorm_rows + mtmp_gemm_nt(act = GELU) + mtmp_gemm_nt(residual, row_scale) for the narrow stages, whose
+ * 4C-wide hidden activation then never reaches HBM.  bf16 only (dtype 1), C = 96 or 192; w1 [4C,C], w2 [C,4C] bf16;
+ * ln_w, ln_b, b1, b2 fp32; row_scale (per-image StochasticDepth factor) may be NULL; y must not alias x. */
+int mtmp_swin_mlp(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                  const void* w2, const float* b2, const float* row_scale, int rows_per_scale, void* y, long long M, int C,
+                  float eps, void* stream);
+
 /* Shifted-window attention (swin_transformer.py:115-225, V1 branch) on the un-shifted NHWC map:
  * qkv [n,H,W,3C] -> out [n,H,W,C]; window 7x7, head_dim 32, H % 7 == W % 7 == 0.
  * table [4 window types][heads][64][64] in `dtype` = relative-position bias + shift mask

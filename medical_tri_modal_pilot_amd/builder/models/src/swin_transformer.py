@@ -16,6 +16,7 @@ the host and cached.  Feature maps whose side is not a multiple of 7 (e.g. --ima
 the reference's zero-padding of windows, which the window kernel does not implement: that case
 raises NotImplementedError.
 """
+import os
 from typing import List
 
 import torch
@@ -25,6 +26,9 @@ from medical_tri_modal_pilot_amd import ops
 
 WS = 7
 PAD_LOGIT = -30000.0
+
+_FUSED_MLP = os.environ.get("MTMP_SWIN_MLP", "1") != "0"     # A/B switch: mtmp_swin_mlp for the C = 96 / 192 blocks
+
 
 def _w(p: torch.Tensor, dtype) -> torch.Tensor:
     """Frozen-encoder weights in the compute dtype, converted once per (tensor, version).  The copy lives ON the
@@ -168,6 +172,13 @@ class SwinTransformerBlock(nn.Module):
         a = self.attn(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
         x2 = ops.gemm_nt(a.view(-1, C), _w(self.attn.proj.weight, dt), self.attn.proj.bias, res2d=x2,
                          row_scale=self.stochastic_depth.row_scale(n, x.device), rows_per_scale=hw)
+        if dt == torch.bfloat16 and C in ops.SWIN_MLP_WIDTHS and _FUSED_MLP:
+            # stages 1-2: norm2 -> fc1 -> GELU -> fc2 -> row scale -> residual in one launch; the 4C-wide hidden
+            # activation (154 MB per stage-1 block of 64 images) stays in registers
+            x2 = ops.swin_mlp(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps, _w(self.mlp[0].weight, dt),
+                              self.mlp[0].bias, _w(self.mlp[3].weight, dt), self.mlp[3].bias,
+                              self.stochastic_depth.row_scale(n, x.device), hw)
+            return x2.view(n, H, W, C)
         h = ops.layernorm_rows(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = ops.gemm_nt(h, _w(self.mlp[0].weight, dt), self.mlp[0].bias, act="gelu")
         x2 = ops.gemm_nt(h, _w(self.mlp[3].weight, dt), self.mlp[3].bias, res2d=x2,

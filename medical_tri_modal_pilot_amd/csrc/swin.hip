@@ -226,6 +226,186 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// MLP half of a Swin block (swin_transformer.py:428-449: x + stochastic_depth(mlp(norm2(x)))) in ONE kernel for the
+// narrow stages (C = 96 / 192, bf16), where the 4C-wide hidden activation is what the three-launch chain
+// (mtmp_layernorm_rows, mtmp_gemm_nt + GELU, mtmp_gemm_nt + residual) moves through HBM: 154 MB written and read
+// again per stage-1 block of 64 images against 38.5 MB of tokens.  Here it never leaves the registers:
+//   * a workgroup owns 128 tokens (32 per wave); each wave normalises its rows in registers (nn.LayerNorm: biased
+//     variance, eps inside the root) and keeps them as the KC = C/16 B-operand fragments of the first product;
+//   * the hidden units are walked in PANELS of HP: rows [j HP, (j+1) HP) of W1 and the matching columns of W2 are the
+//     only things staged in LDS (two buffers, one barrier per panel, next panel prefetched into registers);
+//   * H^T = W1_j xn^T comes out of the MFMA with hidden units on the accumulator ROWS; W1's rows are read through
+//     swz23() so that, after bias + GELU, accumulator registers 8s..8s+7 ARE the k-step-s operand fragment of the
+//     second product (common.cuh, "acc -> Frag") -- no LDS round trip between the two GEMMs;
+//   * out^T += W2[:, panel] H accumulates over the panels; the epilogue adds b2, rounds, applies the per-image
+//     StochasticDepth factor and the residual exactly like mtmp_gemm_nt's epilogue, through a wave-private LDS tile so
+//     that HBM sees 64-byte row pieces.
+template <int C, int HP> struct MlpGeom {
+    static constexpr int KC = C / 16, OG = C / 32, HG = HP / 32, NPAN = 4 * C / HP;
+    static constexpr int LD1 = C + 8, LD2 = HP + 8;               // LDS row strides (elements): 16 B pad, conflict-free b128 reads
+    static constexpr int P1 = HP * LD1, P2 = C * LD2;             // elements per W1 / W2 panel
+    static constexpr int CPR1 = C / 8, CPR2 = HP / 8;             // 16-byte chunks per panel row
+    static constexpr int L1 = HP * CPR1 / 256, L2 = C * CPR2 / 256;   // loads per thread (3 + 3 for both shapes)
+    static constexpr int FS = 40;                                 // staging row: 32 features + 16 B pad
+    static constexpr size_t lds_bytes = (size_t)(2 * (P1 + P2) + 4 * 32 * FS) * sizeof(bf16);
+    static_assert(HP * CPR1 % 256 == 0 && C * CPR2 % 256 == 0, "panel chunks must divide over 256 threads");
+};
+template <int C, int HP> struct MlpRegs { u32x4_t a[MlpGeom<C, HP>::L1], b[MlpGeom<C, HP>::L2]; };
+
+template <int C, int HP>
+MTMP_DEV void mlp_fetch(MlpRegs<C, HP>& g, const bf16* w1, const bf16* w2, int j, int tid) {
+    using G = MlpGeom<C, HP>;
+#pragma unroll
+    for (int i = 0; i < G::L1; ++i) {            // W1 panel: HP consecutive rows of [4C][C] = one contiguous block
+        const int id = i * 256 + tid;
+        g.a[i] = *reinterpret_cast<const u32x4_t*>(w1 + (size_t)j * HP * C + 8 * id);
+    }
+#pragma unroll
+    for (int i = 0; i < G::L2; ++i) {            // W2 panel: columns [j HP, (j+1) HP) of every row of [C][4C]
+        const int id = i * 256 + tid, row = id / G::CPR2, ch = id % G::CPR2;
+        g.b[i] = *reinterpret_cast<const u32x4_t*>(w2 + (size_t)row * 4 * C + j * HP + 8 * ch);
+    }
+}
+template <int C, int HP>
+MTMP_DEV void mlp_commit(bf16* s1, bf16* s2, const MlpRegs<C, HP>& g, int tid) {
+    using G = MlpGeom<C, HP>;
+#pragma unroll
+    for (int i = 0; i < G::L1; ++i) {
+        const int id = i * 256 + tid, row = id / G::CPR1, ch = id % G::CPR1;
+        *reinterpret_cast<u32x4_t*>(s1 + row * G::LD1 + 8 * ch) = g.a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < G::L2; ++i) {
+        const int id = i * 256 + tid, row = id / G::CPR2, ch = id % G::CPR2;
+        *reinterpret_cast<u32x4_t*>(s2 + row * G::LD2 + 8 * ch) = g.b[i];
+    }
+}
+
+template <int C, int HP>
+__global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const float* ln_w, const float* ln_b, const bf16* w1,
+                                                          const float* b1, const bf16* w2, const float* b2,
+                                                          const float* row_scale, int rows_per_scale, bf16* y, long long M,
+                                                          float eps) {
+    using G = MlpGeom<C, HP>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    bf16* sP = reinterpret_cast<bf16*>(smem_raw);                                  // [2][P1 + P2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    bf16* sS = sP + 2 * (G::P1 + G::P2) + wave * 32 * G::FS;                       // wave-private [32][FS]
+    const long long m_wave = (long long)blockIdx.x * 128 + wave * 32;
+    const long long row = min(m_wave + r, M - 1);
+    MlpRegs<C, HP> preg;
+    mlp_fetch<C, HP>(preg, w1, w2, 0, tid);
+    // ---- LayerNorm prologue in registers: lane (r, half) holds channels 16c + 8 half + j of token r
+    Frag<bf16> af[G::KC];
+    const bf16* xrow = x + row * C + 8 * half;
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < G::KC; ++c) {
+        af[c] = frag_load<bf16>(xrow + 16 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < G::KC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * (1.0f / C) + eps);
+#pragma unroll
+    for (int c = 0; c < G::KC; ++c) {
+        const int k = 16 * c + 8 * half;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_w + k), g1 = *reinterpret_cast<const f32x4*>(ln_w + k + 4);
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(ln_b + k), o1 = *reinterpret_cast<const f32x4*>(ln_b + k + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[c].v[i] = from_f32<bf16>(fmaf((to_f32(af[c].v[i]) - mean) * rstd, g0[i], o0[i]));
+            af[c].v[i + 4] = from_f32<bf16>(fmaf((to_f32(af[c].v[i + 4]) - mean) * rstd, g1[i], o1[i]));
+        }
+    }
+    mlp_commit<C, HP>(sP, sP + G::P1, preg, tid);
+    mlp_fetch<C, HP>(preg, w1, w2, 1, tid);
+    f32x16 acc2[G::OG];
+#pragma unroll
+    for (int o = 0; o < G::OG; ++o) acc2[o] = f32x16{0};
+    __syncthreads();
+    for (int j = 0; j < G::NPAN; ++j) {
+        const bf16* c1 = sP + (j & 1) * (G::P1 + G::P2);
+        const bf16* c2 = c1 + G::P1;
+        bf16* n1 = sP + ((j & 1) ^ 1) * (G::P1 + G::P2);
+#pragma unroll
+        for (int g = 0; g < G::HG; ++g) {
+            // accumulator register t of this lane = hidden unit j HP + 32 g + 16 (t >> 3) + 8 half + (t & 7)
+            const float* bp = b1 + j * HP + 32 * g + 8 * half;
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(bp), bb = *reinterpret_cast<const f32x4*>(bp + 4);
+            const f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 16), bd = *reinterpret_cast<const f32x4*>(bp + 20);
+            f32x16 h = {ba[0], ba[1], ba[2], ba[3], bb[0], bb[1], bb[2], bb[3], bc[0], bc[1], bc[2], bc[3], bd[0], bd[1], bd[2], bd[3]};
+            const bf16* wrow = c1 + (32 * g + swz23(r)) * G::LD1 + 8 * half;
+#pragma unroll
+            for (int c = 0; c < G::KC; ++c) mma<bf16>(h, frag_load<bf16>(wrow + 16 * c), af[c]);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) h[t] = gelu<bf16>(h[t]);
+            const Frag<bf16> h0 = frag_from_acc<bf16>(h, 0), h1 = frag_from_acc<bf16>(h, 1);
+#pragma unroll
+            for (int o = 0; o < G::OG; ++o) {
+                const bf16* vrow = c2 + (32 * o + r) * G::LD2 + 32 * g + 8 * half;
+                mma<bf16>(acc2[o], frag_load<bf16>(vrow), h0);
+                mma<bf16>(acc2[o], frag_load<bf16>(vrow + 16), h1);
+            }
+        }
+        mlp_commit<C, HP>(n1, n1 + G::P1, preg, tid);               // panel j+1 (or a harmless repeat of the last one)
+        mlp_fetch<C, HP>(preg, w1, w2, min(j + 2, G::NPAN - 1), tid);
+        __syncthreads();
+    }
+    // ---- epilogue: acc2[o] register t = output feature 32 o + acc_row(t, half) of token r
+    const int tok = lane >> 2, ch = lane & 3;
+#pragma unroll
+    for (int o = 0; o < G::OG; ++o) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 32 * o + 8 * i4 + 4 * half);
+            store4<bf16>(sS + r * G::FS + 8 * i4 + 4 * half, acc2[o][4 * i4] + bv[0], acc2[o][4 * i4 + 1] + bv[1],
+                         acc2[o][4 * i4 + 2] + bv[2], acc2[o][4 * i4 + 3] + bv[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int t = tok + 16 * ps;
+            const long long grow = min(m_wave + t, M - 1);
+            const Frag<bf16> v = frag_load<bf16>(sS + t * G::FS + 8 * ch);
+            const Frag<bf16> res = frag_load<bf16>(x + grow * C + 32 * o + 8 * ch);
+            const float rsv = row_scale ? row_scale[grow / rows_per_scale] : 1.0f;
+            Frag<bf16> out;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float f = to_f32(v.v[i]);
+                if (row_scale) f *= rsv;
+                out.v[i] = from_f32<bf16>(round_as<bf16>(f) + to_f32(res.v[i]));
+            }
+            frag_store<bf16>(y + grow * C + 32 * o + 8 * ch, out);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <int C, int HP>
+int launch_swin_mlp(const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1, const void* w2,
+                    const float* b2, const float* row_scale, int rows_per_scale, void* y, long long M, float eps,
+                    hipStream_t st) {
+    using G = MlpGeom<C, HP>;
+    const void* fn = (const void*)swin_mlp_kernel<C, HP>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes) != hipSuccess) {
+        mtmp_set_error("mtmp_swin_mlp: cannot raise dynamic LDS to %zu", G::lds_bytes);
+        return MTMP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((swin_mlp_kernel<C, HP>), dim3((unsigned)((M + 127) / 128)), dim3(256), G::lds_bytes, st, (const bf16*)x,
+                       ln_w, ln_b, (const bf16*)w1, b1, (const bf16*)w2, b2, row_scale, rows_per_scale, (bf16*)y, M, eps);
+    return MTMP_OK;
+}
 }  // namespace
 
 // y[rows,C] = LayerNorm(x rows; w, b, eps) in `dtype`; w,b fp32.  merge != 0: x is an NHWC map
@@ -264,5 +444,23 @@ extern "C" int mtmp_swin_window_attn(int dtype, const void* qkv, const void* tab
                            (const bf16*)table, (bf16*)out, n_img, H, W, C, heads, shift, scale);
     else { mtmp_set_error("mtmp_swin_window_attn: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_swin_window_attn");
+    return MTMP_OK;
+}
+
+// y[M,C] = x + row_scale[row / rows_per_scale] * (gelu(LN(x; ln_w, ln_b, eps) W1^T + b1) W2^T + b2): the MLP half of a
+// Swin block (swin_transformer.py:428-449; torchvision MLP keys mlp.0 / mlp.3) in one launch.  bf16 only (dtype 1),
+// C = 96 or 192 (stages 1-2; wider stages use mtmp_layernorm_rows + mtmp_gemm_nt); w1 [4C,C], w2 [C,4C] bf16;
+// ln_w, ln_b, b1, b2 fp32; row_scale (per-image StochasticDepth factor) may be NULL; y must not alias x.
+extern "C" int mtmp_swin_mlp(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                             const void* w2, const float* b2, const float* row_scale, int rows_per_scale, void* y,
+                             long long M, int C, float eps, void* stream) {
+    MTMP_CHECK_ARG(x && ln_w && ln_b && w1 && b1 && w2 && b2 && y && x != y, "mtmp_swin_mlp: null / aliased pointer");
+    MTMP_CHECK_ARG(dtype == 1 && (C == 96 || C == 192) && M > 0 && (!row_scale || rows_per_scale > 0),
+                   "mtmp_swin_mlp: bf16 with C = 96 or 192 only (dtype=%d C=%d M=%lld)", dtype, C, M);
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = C == 96 ? launch_swin_mlp<96, 64>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, st)
+                           : launch_swin_mlp<192, 32>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, st);
+    if (rc) return rc;
+    MTMP_CHECK_LAUNCH("mtmp_swin_mlp");
     return MTMP_OK;
 }

@@ -141,6 +141,21 @@ def layernorm_rows(x, w, b, eps=1e-5, merge_hw=None):
     return y
 
 
+SWIN_MLP_WIDTHS = (96, 192)
+
+
+def swin_mlp(x2d, ln_w, ln_b, eps, w1, b1, w2, b2, row_scale=None, rows_per_scale=1):
+    """x2d [M,C] bf16 -> x2d + row_scale[row // rows_per_scale] * (gelu(LN(x2d) w1^T + b1) w2^T + b2) in one launch
+    (mtmp_swin_mlp; C in SWIN_MLP_WIDTHS, w1 [4C,C] / w2 [C,4C] bf16, the rest fp32)."""
+    _gpu(x2d)
+    x2d = _c(x2d)
+    M, C = x2d.shape
+    y = torch.empty_like(x2d)
+    call("mtmp_swin_mlp", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w1)), _p(b1), _p(_c(w2)), _p(b2), _p(row_scale),
+         int(rows_per_scale), _p(y), M, C, float(eps), _stream())
+    return y
+
+
 def swin_window_attn(qkv, table, heads, shift):
     """qkv [n,H,W,3C] -> [n,H,W,C]; table [4][heads][64][64] (bias + shift mask, -30000 on pad keys)."""
     _gpu(qkv)

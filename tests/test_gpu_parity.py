@@ -473,6 +473,38 @@ def test_swin_window_attention_and_layernorm(ops, dt, H, C, heads, shift):
               1e-5 if dt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("C,rows,hw", [(96, 3 * 3136, 3136), (192, 5 * 784 - 7, 784), (96, 130, 64)])
+def test_swin_mlp_fused_vs_chain_and_torch(ops, C, rows, hw):
+    """mtmp_swin_mlp (LN -> fc1 -> GELU -> fc2 -> row scale -> residual, one launch) against the three-launch chain
+    it replaces (same roundings; only fp32 summation order differs) and against the fp32 torch modules
+    (swin_transformer.py:428-449); ragged row count = clamped last rows."""
+    g = torch.Generator().manual_seed(C + rows)
+    bf = torch.bfloat16
+    x = torch.randn(rows, C, generator=g).to(bf)
+    lw, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w1, b1 = (torch.randn(4 * C, C, generator=g) * C ** -0.5).to(bf), 0.1 * torch.randn(4 * C, generator=g)
+    w2, b2 = (torch.randn(C, 4 * C, generator=g) * (4 * C) ** -0.5).to(bf), 0.1 * torch.randn(C, generator=g)
+    n_img = (rows + hw - 1) // hw
+    rs = torch.tensor([0.0, 1.25, 1.0, 1.25, 1.25][:n_img])
+    d = lambda t: t.to(DEV)
+    for scale in (None, rs):
+        y = ops.swin_mlp(d(x), d(lw), d(lb), 1e-5, d(w1), d(b1), d(w2), d(b2), None if scale is None else d(scale), hw)
+        h = ops.layernorm_rows(d(x), d(lw), d(lb), 1e-5)
+        h = ops.gemm_nt(h, d(w1), d(b1), act="gelu")
+        chain = ops.gemm_nt(h, d(w2), d(b2), res2d=d(x), row_scale=None if scale is None else d(scale), rows_per_scale=hw)
+        xf = x.float()
+        hid = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xf, (C,), lw, lb, 1e-5) @ w1.float().t() + b1)
+        ref = hid @ w2.float().t() + b2
+        if scale is not None:
+            ref = ref * scale.repeat_interleave(hw)[:rows, None]
+        ref = xf + ref
+        t = f"swin_mlp[C={C},rows={rows},scale={scale is not None}]"
+        check(t + ".vs_chain", y.float(), chain.float(), 2e-2)
+        check(t + ".vs_torch_fp32", y.float(), ref, 3e-2)
+        frac = (y != chain).float().mean().item()
+        assert frac < 0.10, f"{t}: {frac:.3f} of the outputs differ from the chain by a bf16 ulp or more"
+
+
 def test_fused_adamw_matches_torch(ops):
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     g = torch.Generator().manual_seed(2)

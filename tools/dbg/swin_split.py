@@ -28,7 +28,7 @@ def run(parts):
     return torch.cat(outs) if parts > 1 else outs[0]
 
 
-for parts in (1, 2, 4, 1, 2, 4):
+for parts in [int(v) for v in os.environ.get("PARTS", "1,2,4,1,2,4").split(",")]:
     for _ in range(2):
         run(parts)
     torch.cuda.synchronize()
