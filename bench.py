@@ -167,6 +167,33 @@ def main():
 
     ops.attn_fwd = timed_attn_fwd
 
+    # the same for the two other heavy kernels of the vital-sign stream (reported under "roofline_more"):
+    # attention backward (dQ + dK/dV launches of one call) and the weight-gradient GEMMs
+    more = {"attn_bwd": [], "gemm_tn": []}
+    raw_attn_bwd, raw_gemm_tn = ops.attn_bwd, ops.gemm_tn
+
+    def timed_attn_bwd(qkv, *rest):
+        if record["on"] and qkv.shape[1] == TIE_LEN + 5:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_attn_bwd(qkv, *rest)
+            e1.record()
+            more["attn_bwd"].append((e0, e1, 10.0 * qkv.shape[0] * 4 * qkv.shape[1] * qkv.shape[1] * 64))
+            return out
+        return raw_attn_bwd(qkv, *rest)
+
+    def timed_gemm_tn(dy2d, x2d, *rest, **kws):
+        if record["on"] and dy2d.shape[0] >= B_PER_GPU * TIE_LEN:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_gemm_tn(dy2d, x2d, *rest, **kws)
+            e1.record()
+            more["gemm_tn"].append((e0, e1, 2.0 * dy2d.shape[0] * dy2d.shape[1] * x2d.shape[1]))
+            return out
+        return raw_gemm_tn(dy2d, x2d, *rest, **kws)
+
+    ops.attn_bwd, ops.gemm_tn = timed_attn_bwd, timed_gemm_tn
+
     # host-side enqueue time: from step start until the trainer blocks in loss.item()
     enq = {"t0": 0.0, "sum": 0.0, "n": 0}
     raw_item = torch.Tensor.item
@@ -208,6 +235,8 @@ def main():
         # events cannot time one kernel inside a replayed graph: time the same kernel on the same workload in
         # eager steps right after the timed region (its rocprofv3 average covers both kinds of launch)
         events.clear()
+        more["attn_bwd"].clear()
+        more["gemm_tn"].clear()
         args.hip_graph = 0
         record["on"] = True
         for i in range(a.probe_steps):
@@ -255,6 +284,17 @@ def main():
                          "launches_timed": len(events), "avg_launch_ms": k_ms, "flops_per_launch": flops,
                          "timed_in": "eager probe steps after the graph-replay region" if graphed else "timed steps"},
         }
+        names = {"attn_bwd": "attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (vslt stream; algorithmic flops = 2.5 x forward)",
+                 "gemm_tn": "gemm_tn_tr_kernel + tn_reduce_kernel (vslt-stream weight gradients)"}
+        out["roofline_more"] = []
+        for key, evs in more.items():
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
+            fl = sum(f for _, _, f in evs)
+            if evs and ms > 0:
+                tf = fl / (ms * 1e-3) / 1e12
+                out["roofline_more"].append({"bound": "mfma", "kernel": names[key], "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "launches_timed": len(evs),
+                                             "avg_launch_ms": ms / len(evs), "flops_per_launch": fl / len(evs)})
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -172,6 +172,12 @@ int mtmp_swin_stem_fwd(int dtype, const float* img, const float* w, const float*
 int mtmp_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* y, long long rows, int C,
                         float eps, int merge, int H, int W, void* stream);
 
+/* y[M,N] = LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias: norm1 + the qkv projection of a Swin block in one launch
+ * (swin_transformer.py:428-449 + :115-225; replaces mtmp_layernorm_rows + mtmp_gemm_nt for the narrow stages).
+ * bf16 only (dtype 1), C = 96 or 192, N % 32 == 0; W bf16; ln_w, ln_b, bias fp32 (bias may be NULL). */
+int mtmp_swin_ln_linear(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias,
+                        void* y, long long M, int C, int N, float eps, void* stream);
+
 /* MLP half of a Swin block in one launch (swin_transformer.py:428-449, torchvision MLP keys mlp.0 / mlp.3):
  * y[M,C] = x + row_scale[row / rows_per_scale] * (gelu(LayerNorm(x; ln_w, ln_b, eps) W1^T + b1) W2^T + b2).
  * Replaces mtmp_layernorm_rows + mtmp_gemm_nt(act = GELU) + mtmp_gemm_nt(residual, row_scale) for the narrow stages, whose

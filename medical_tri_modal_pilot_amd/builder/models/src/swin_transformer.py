@@ -140,13 +140,18 @@ class ShiftedWindowAttention(nn.Module):
             self._tab, self._tab_key = tab.to(dtype).contiguous(), key
         return self._tab
 
-    def forward(self, xn: torch.Tensor) -> torch.Tensor:
-        """xn [n,H,W,C] (already normalised) -> attention output [n,H,W,C] BEFORE the projection."""
+    def forward(self, xn: torch.Tensor, norm: nn.LayerNorm = None) -> torch.Tensor:
+        """xn [n,H,W,C] (already normalised, or raw with `norm` = the block's norm1 to be fused into the qkv
+        projection) -> attention output [n,H,W,C] BEFORE the output projection."""
         n, H, W, C = xn.shape
         if H % WS or W % WS:
             raise NotImplementedError("feature maps must be multiples of the 7x7 window (use --image-size 224)")
         shift = 0 if WS >= H else self.shift_size[0]
-        qkv = ops.gemm_nt(xn.view(-1, C), _w(self.qkv.weight, xn.dtype), self.qkv.bias).view(n, H, W, 3 * C)
+        if norm is not None:          # xn is the un-normalised map: norm1 + qkv in one launch (mtmp_swin_ln_linear)
+            qkv = ops.swin_ln_linear(xn.view(-1, C), norm.weight, norm.bias, norm.eps, _w(self.qkv.weight, xn.dtype),
+                                     self.qkv.bias).view(n, H, W, 3 * C)
+        else:
+            qkv = ops.gemm_nt(xn.view(-1, C), _w(self.qkv.weight, xn.dtype), self.qkv.bias).view(n, H, W, 3 * C)
         return ops.swin_window_attn(qkv, self.additive_table(shift, xn.dtype, xn.device), self.num_heads, shift)
 
 
@@ -169,7 +174,10 @@ class SwinTransformerBlock(nn.Module):
         n, H, W, C = x.shape
         dt, hw = x.dtype, H * W
         x2 = x.view(-1, C)
-        a = self.attn(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        if dt == torch.bfloat16 and C in ops.SWIN_MLP_WIDTHS and _FUSED_MLP:
+            a = self.attn(x, norm=self.norm1)
+        else:
+            a = self.attn(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
         x2 = ops.gemm_nt(a.view(-1, C), _w(self.attn.proj.weight, dt), self.attn.proj.bias, res2d=x2,
                          row_scale=self.stochastic_depth.row_scale(n, x.device), rows_per_scale=hw)
         if dt == torch.bfloat16 and C in ops.SWIN_MLP_WIDTHS and _FUSED_MLP:

@@ -406,6 +406,89 @@ int launch_swin_mlp(const void* x, const float* ln_w, const float* ln_b, const v
                        ln_w, ln_b, (const bf16*)w1, b1, (const bf16*)w2, b2, row_scale, rows_per_scale, (bf16*)y, M, eps);
     return MTMP_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// y[M,N] = LayerNorm(x[M,C]) W[N,C]^T + bias for the narrow stages (C = 96 / 192, bf16): norm1 -> qkv of a Swin block
+// (swin_transformer.py:428-449 + :115-225) in one launch.  At K = C the projection is bound by writing its 3C-wide
+// output, and the separate LayerNorm pass reads and writes the token map once more for nothing.  Every wave is on its
+// own: it normalises 32 tokens in registers (the KC = C/16 B-operand fragments), then walks the output features in
+// groups of 32, reading the weight fragments straight from global memory -- W is 55 / 221 KB and stays in L2, there is
+// nothing to share through LDS and no barrier -- and stores each 32 x 32 tile through a wave-private LDS tile as
+// 64-byte row pieces.  The next group's weight fragments are requested before the current group's stores.
+template <int C>
+__global__ __launch_bounds__(256, 3) void swin_ln_linear_kernel(const bf16* x, const float* ln_w, const float* ln_b, const bf16* w,
+                                                                const float* bias, bf16* y, long long M, int N, float eps) {
+    constexpr int KC = C / 16, FS = 40;
+    __shared__ __attribute__((aligned(16))) bf16 stage[4 * 32 * FS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    bf16* sS = stage + wave * 32 * FS;
+    const long long m_wave = (long long)blockIdx.x * 128 + wave * 32;
+    if (m_wave >= M) return;                                     // whole wave out of range (no barriers in this kernel)
+    const long long row = min(m_wave + r, M - 1);
+    const int ngroups = N / 32;
+    Frag<bf16> wf[KC];
+    const bf16* wlane = w + (size_t)r * C + 8 * half;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) wf[c] = frag_load<bf16>(wlane + 16 * c);
+    Frag<bf16> af[KC];
+    const bf16* xrow = x + row * C + 8 * half;
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        af[c] = frag_load<bf16>(xrow + 16 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * (1.0f / C) + eps);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const int k = 16 * c + 8 * half;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_w + k), g1 = *reinterpret_cast<const f32x4*>(ln_w + k + 4);
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(ln_b + k), o1 = *reinterpret_cast<const f32x4*>(ln_b + k + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[c].v[i] = from_f32<bf16>(fmaf((to_f32(af[c].v[i]) - mean) * rstd, g0[i], o0[i]));
+            af[c].v[i + 4] = from_f32<bf16>(fmaf((to_f32(af[c].v[i + 4]) - mean) * rstd, g1[i], o1[i]));
+        }
+    }
+    const int tok = lane >> 2, ch = lane & 3;
+    for (int g = 0; g < ngroups; ++g) {
+        // accumulator register t = output feature 32 g + acc_row(t, half) of token r; start from the bias
+        f32x16 acc;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 32 * g + 8 * i4 + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * i4 + i] = bv[i];
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) mma<bf16>(acc, wf[c], af[c]);
+        const bf16* wnext = wlane + (size_t)32 * min(g + 1, ngroups - 1) * C;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) wf[c] = frag_load<bf16>(wnext + 16 * c);
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+            store4<bf16>(sS + r * FS + 8 * i4 + 4 * half, acc[4 * i4], acc[4 * i4 + 1], acc[4 * i4 + 2], acc[4 * i4 + 3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int t = tok + 16 * ps;
+            const long long grow = min(m_wave + t, M - 1);
+            const u32x4_t d = *reinterpret_cast<const u32x4_t*>(sS + t * FS + 8 * ch);
+            *reinterpret_cast<u32x4_t*>(y + grow * N + 32 * g + 8 * ch) = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
 }  // namespace
 
 // y[rows,C] = LayerNorm(x rows; w, b, eps) in `dtype`; w,b fp32.  merge != 0: x is an NHWC map
@@ -462,5 +545,25 @@ extern "C" int mtmp_swin_mlp(int dtype, const void* x, const float* ln_w, const 
                            : launch_swin_mlp<192, 32>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, st);
     if (rc) return rc;
     MTMP_CHECK_LAUNCH("mtmp_swin_mlp");
+    return MTMP_OK;
+}
+
+// y[M,N] = LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias: norm1 + the qkv projection of a Swin block
+// (swin_transformer.py:428-449, :115-225) in one launch.  bf16 only (dtype 1), C = 96 or 192, N % 32 == 0; W bf16,
+// ln_w / ln_b / bias fp32 (bias may be NULL).
+extern "C" int mtmp_swin_ln_linear(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w,
+                                   const float* bias, void* y, long long M, int C, int N, float eps, void* stream) {
+    MTMP_CHECK_ARG(x && ln_w && ln_b && w && y, "mtmp_swin_ln_linear: null pointer");
+    MTMP_CHECK_ARG(dtype == 1 && (C == 96 || C == 192) && M > 0 && N > 0 && N % 32 == 0,
+                   "mtmp_swin_ln_linear: bf16 with C = 96 or 192 and N %% 32 == 0 only (dtype=%d C=%d N=%d M=%lld)", dtype, C, N, M);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((M + 127) / 128));
+    if (C == 96)
+        hipLaunchKernelGGL(swin_ln_linear_kernel<96>, grid, dim3(256), 0, st, (const bf16*)x, ln_w, ln_b, (const bf16*)w, bias,
+                           (bf16*)y, M, N, eps);
+    else
+        hipLaunchKernelGGL(swin_ln_linear_kernel<192>, grid, dim3(256), 0, st, (const bf16*)x, ln_w, ln_b, (const bf16*)w, bias,
+                           (bf16*)y, M, N, eps);
+    MTMP_CHECK_LAUNCH("mtmp_swin_ln_linear");
     return MTMP_OK;
 }

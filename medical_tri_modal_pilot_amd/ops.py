@@ -156,6 +156,17 @@ def swin_mlp(x2d, ln_w, ln_b, eps, w1, b1, w2, b2, row_scale=None, rows_per_scal
     return y
 
 
+def swin_ln_linear(x2d, ln_w, ln_b, eps, w, bias):
+    """x2d [M,C] bf16 -> LayerNorm(x2d) w^T + bias [M,N] in one launch (mtmp_swin_ln_linear; C in SWIN_MLP_WIDTHS)."""
+    _gpu(x2d)
+    x2d = _c(x2d)
+    M, C = x2d.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
+    call("mtmp_swin_ln_linear", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), _stream())
+    return y
+
+
 def swin_window_attn(qkv, table, heads, shift):
     """qkv [n,H,W,3C] -> [n,H,W,C]; table [4][heads][64][64] (bias + shift mask, -30000 on pad keys)."""
     _gpu(qkv)

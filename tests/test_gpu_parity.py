@@ -505,6 +505,25 @@ def test_swin_mlp_fused_vs_chain_and_torch(ops, C, rows, hw):
         assert frac < 0.10, f"{t}: {frac:.3f} of the outputs differ from the chain by a bf16 ulp or more"
 
 
+@pytest.mark.parametrize("C,rows", [(96, 3 * 3136), (192, 5 * 784 - 7), (96, 33)])
+def test_swin_ln_linear_fused_vs_chain_and_torch(ops, C, rows):
+    """mtmp_swin_ln_linear (norm1 + qkv projection, one launch) against mtmp_layernorm_rows + mtmp_gemm_nt and against
+    fp32 torch; ragged row counts exercise the clamped last rows / the early exit of whole waves."""
+    g = torch.Generator().manual_seed(C + rows)
+    bf = torch.bfloat16
+    x = torch.randn(rows, C, generator=g).to(bf)
+    lw, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w, b = (torch.randn(3 * C, C, generator=g) * C ** -0.5).to(bf), 0.1 * torch.randn(3 * C, generator=g)
+    d = lambda t: t.to(DEV)
+    for bias in (b, None):
+        y = ops.swin_ln_linear(d(x), d(lw), d(lb), 1e-5, d(w), None if bias is None else d(bias))
+        chain = ops.gemm_nt(ops.layernorm_rows(d(x), d(lw), d(lb), 1e-5), d(w), None if bias is None else d(bias))
+        ref = torch.nn.functional.layer_norm(x.float(), (C,), lw, lb, 1e-5) @ w.float().t() + (0 if bias is None else bias)
+        t = f"swin_ln_linear[C={C},rows={rows},bias={bias is not None}]"
+        check(t + ".vs_chain", y.float(), chain.float(), 1e-2)
+        check(t + ".vs_torch_fp32", y.float(), ref, 2e-2)
+
+
 def test_fused_adamw_matches_torch(ops):
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     g = torch.Generator().manual_seed(2)
