@@ -174,7 +174,7 @@ class SwinTransformerBlock(nn.Module):
         n, H, W, C = x.shape
         dt, hw = x.dtype, H * W
         x2 = x.view(-1, C)
-        if dt == torch.bfloat16 and C in ops.SWIN_MLP_WIDTHS and _FUSED_MLP:
+        if dt == torch.bfloat16 and C in ops.SWIN_LN_LINEAR_WIDTHS and _FUSED_MLP:
             a = self.attn(x, norm=self.norm1)
         else:
             a = self.attn(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
