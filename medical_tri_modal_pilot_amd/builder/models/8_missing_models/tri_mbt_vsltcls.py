@@ -198,12 +198,22 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # The frozen encoder itself runs on the image side stream: nothing of the vital-sign stream depends on it before
         # the first bottleneck exchange, so the main stream goes on (TIE embedding, stream input, the vital-sign
         # stream's first layer) beside the encoder's small-M stages, which cannot fill the chip on their own.
-        with on_side(0):
-            ops.mark("swin.s")
+        if side is not None:
+            # stages 1-2 on a third stream, stages 3-4 as two half batches on the two side streams (result valid on side[0])
+            if getattr(self, "_swin_stream", None) is None or self._swin_stream.device != img.device:
+                self._swin_stream = torch.cuda.Stream(device=img.device)
+            self._swin_stream.wait_stream(cur)
+            with torch.cuda.stream(self._swin_stream), torch.no_grad():
+                ops.mark("swin.s")
+                feat = self.img_encoder(img, tail_streams=(side[0], side[1]))
+            side[0].wait_stream(self._swin_stream)        # (already implied when the encoder split its tail)
+            with on_side(0):
+                feat = self.flatten(feat)
+                ops.mark("swin.e")
+        else:
             with torch.no_grad():
                 feat = self.img_encoder(img)
             feat = self.flatten(feat)
-            ops.mark("swin.e")
         with on_side(0):
             img_embedding = (F.linear(feat, self.linear.weight.to(dt), self.linear.bias.to(dt)) if _TORCH_SMALL else
                              ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt))
@@ -257,6 +267,8 @@ class TRI_MBT_VSLTCLS(nn.Module):
             enc_outputs=[vslt_embedding, img_embedding, txt_embedding],
             fixed_lengths=[vslt_embedding.size(1), img_embedding.size(1), txt_embedding.size(1)],
             varying_lengths=[input_lengths, img_len, txt_lengths + 2], fusion_idx=None, missing=missing)
+        if side is not None:
+            cur.wait_stream(self._swin_stream)            # joins the encoder's stream to the caller's (its work ended long ago)
         # ---- head (:248-255), fp32
         cls = self.fusion_transformer.last_cls             # outputs[0][:, 0, :] as a dedicated autograd output
         cls = (outputs[0][:, 0, :] if cls is None else cls).float()

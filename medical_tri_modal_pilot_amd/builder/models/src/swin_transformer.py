@@ -27,6 +27,7 @@ from medical_tri_modal_pilot_amd import ops
 WS = 7
 PAD_LOGIT = -30000.0
 
+_SPLIT_TAIL = os.environ.get("MTMP_SWIN_SPLIT_TAIL", "1") != "0"   # A/B switch: stages 3-4 as two half batches on two streams
 _FUSED_MLP = os.environ.get("MTMP_SWIN_MLP", "1") != "0"     # A/B switch: mtmp_swin_mlp for the C = 96 / 192 blocks
 
 
@@ -170,27 +171,31 @@ class SwinTransformerBlock(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.normal_(m.bias, std=1e-6)
 
-    def forward(self, x):
+    def draw_scales(self, n: int, device):
+        """(attention-branch, MLP-branch) StochasticDepth factors of one forward, float32[n] each or None."""
+        return self.stochastic_depth.row_scale(n, device), self.stochastic_depth.row_scale(n, device)
+
+    def forward(self, x, scales=None):
+        """x [n,H,W,C]; scales: this call's slice of draw_scales() when the batch is processed in parts (None = draw)."""
         n, H, W, C = x.shape
         dt, hw = x.dtype, H * W
         x2 = x.view(-1, C)
+        s_attn, s_mlp = self.draw_scales(n, x.device) if scales is None else scales
         if dt == torch.bfloat16 and C in ops.SWIN_LN_LINEAR_WIDTHS and _FUSED_MLP:
             a = self.attn(x, norm=self.norm1)
         else:
             a = self.attn(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
         x2 = ops.gemm_nt(a.view(-1, C), _w(self.attn.proj.weight, dt), self.attn.proj.bias, res2d=x2,
-                         row_scale=self.stochastic_depth.row_scale(n, x.device), rows_per_scale=hw)
+                         row_scale=s_attn, rows_per_scale=hw)
         if dt == torch.bfloat16 and C in ops.SWIN_MLP_WIDTHS and _FUSED_MLP:
             # stages 1-2: norm2 -> fc1 -> GELU -> fc2 -> row scale -> residual in one launch; the 4C-wide hidden
             # activation (154 MB per stage-1 block of 64 images) stays in registers
             x2 = ops.swin_mlp(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps, _w(self.mlp[0].weight, dt),
-                              self.mlp[0].bias, _w(self.mlp[3].weight, dt), self.mlp[3].bias,
-                              self.stochastic_depth.row_scale(n, x.device), hw)
+                              self.mlp[0].bias, _w(self.mlp[3].weight, dt), self.mlp[3].bias, s_mlp, hw)
             return x2.view(n, H, W, C)
         h = ops.layernorm_rows(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = ops.gemm_nt(h, _w(self.mlp[0].weight, dt), self.mlp[0].bias, act="gelu")
-        x2 = ops.gemm_nt(h, _w(self.mlp[3].weight, dt), self.mlp[3].bias, res2d=x2,
-                         row_scale=self.stochastic_depth.row_scale(n, x.device), rows_per_scale=hw)
+        x2 = ops.gemm_nt(h, _w(self.mlp[3].weight, dt), self.mlp[3].bias, res2d=x2, row_scale=s_mlp, rows_per_scale=hw)
         return x2.view(n, H, W, C)
 
 
@@ -243,13 +248,44 @@ class SwinTransformer(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
-    def forward(self, x):
-        """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] in the compute dtype."""
+    def forward(self, x, tail_streams=None):
+        """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] in the compute dtype.
+
+        tail_streams=(s0, s1): two HIP streams OTHER than the caller's.  Stages 3-4 (12.5 k / 3.1 k tokens for 64 images:
+        launches of 15-35 us that cannot fill 256 CUs and are bound by one workgroup's latency chain) then run as two half
+        batches side by side on s0 and s1, s0 joins s1, and the result is valid ON s0: the caller goes on there.  (The
+        halves cannot come back to the caller's stream: under hipGraph capture this ROCm crashes in hipStreamEndCapture
+        when a forked non-origin stream is joined by the stream that forked it -- tools/dbg/capture_topology.py.)"""
         stem = self.features[0]
-        draw_row_scales(self, x.shape[0], x.device)
+        n = x.shape[0]
+        draw_row_scales(self, n, x.device)
         x = ops.swin_stem(x, stem[0].weight, stem[0].bias, stem[2].weight, stem[2].bias, self.compute_dtype)
-        for layer in list(self.features)[1:]:
+        layers = list(self.features)[1:]
+        split = tail_streams is not None and _SPLIT_TAIL and n >= 16 and n % 2 == 0 and len(layers) == 7
+        for layer in layers[:4] if split else layers:
             x = layer(x)
+        if split:
+            tail = []                 # (module, per-block scale pairs) in execution order; all draws happen once, here
+            for layer in layers[4:]:
+                if isinstance(layer, nn.Sequential):
+                    tail += [(blk, blk.draw_scales(n, x.device)) for blk in layer]
+                else:
+                    tail.append((layer, None))
+            head = torch.cuda.current_stream()
+            s0, s1 = tail_streams
+            s0.wait_stream(head)
+            s1.wait_stream(head)
+            with torch.cuda.stream(s0):       # s0 owns the result: nothing allocated on s1 is read by another stream
+                out = torch.empty(n, x.shape[1] // 2, x.shape[2] // 2, 2 * x.shape[3], dtype=x.dtype, device=x.device)   # one merge left
+            for k, st in enumerate((s0, s1)):
+                lo, hi = k * n // 2, (k + 1) * n // 2
+                with torch.cuda.stream(st):
+                    y = x[lo:hi]
+                    for mod, sc in tail:
+                        y = mod(y) if sc is None else mod(y, tuple(None if v is None else v[lo:hi] for v in sc))
+                    ops.layernorm_rows(y, self.norm.weight, self.norm.bias, self.norm.eps, out=out[lo:hi])
+            s0.wait_stream(s1)
+            return out
         return ops.layernorm_rows(x, self.norm.weight, self.norm.bias, self.norm.eps)
 
 

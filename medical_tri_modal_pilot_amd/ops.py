@@ -123,14 +123,17 @@ def gemm_nt(a2d, w, bias=None, res2d=None, act=None, drop_p=0.0, seed=0, gate=No
     return y
 
 
-def layernorm_rows(x, w, b, eps=1e-5, merge_hw=None):
+def layernorm_rows(x, w, b, eps=1e-5, merge_hw=None, out=None):
     """nn.LayerNorm over the last dim of x (any leading dims) -> same shape; merge_hw=(H,W): x is [n,H,W,Cs] and
-    the result is the LayerNorm of the 2x2 patch-merging concat, [n,H/2,W/2,4Cs]."""
+    the result is the LayerNorm of the 2x2 patch-merging concat, [n,H/2,W/2,4Cs].  out: contiguous destination of
+    x's shape and dtype (plain mode only)."""
     _gpu(x)
     x = _c(x)
     if merge_hw is None:
         C = x.shape[-1]
-        y = torch.empty_like(x)
+        if out is not None and (out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous()):
+            raise ValueError("layernorm_rows: out must be contiguous with x's shape and dtype")
+        y = torch.empty_like(x) if out is None else out
         call("mtmp_layernorm_rows", _dt(x), _p(x), _p(w), _p(b), _p(y), x.numel() // C, C, float(eps), 0, 0, 0, _stream())
         return y
     H, W = merge_hw

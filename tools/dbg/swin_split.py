@@ -22,8 +22,8 @@ def run(parts):
         s = streams[k]
         s.wait_stream(cur)
         with torch.cuda.stream(s), torch.no_grad():
-            outs.append(enc(ch))
-    for s in streams[:parts]:
+            outs.append(enc(ch, tail_streams=(streams[2], streams[3])) if os.environ.get('AUX') and parts == 1 else enc(ch))
+    for s in streams:
         cur.wait_stream(s)
     return torch.cat(outs) if parts > 1 else outs[0]
 
