@@ -25,12 +25,15 @@ def main():
     ap.add_argument("--seq", action="store_true", help="print the main-stream launch sequence of one step")
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--json", default="")
+    ap.add_argument("--skip-last", type=int, default=0, help="ignore the last K steps (bench.py's eager probe steps)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.csv)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     big = max(int(r["Grid_Size_X"]) for r in rows if "attn_fwd" in r["Kernel_Name"])
     fw = [r for r in rows if "attn_fwd" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == big]
     starts = [int(fw[a.layers * k]["Start_Timestamp"]) for k in range(len(fw) // a.layers)]
+    if a.skip_last:
+        starts = starts[:-a.skip_last]
     lo, hi = starts[len(starts) // 2], starts[-1]
     n = len(starts) - 1 - len(starts) // 2
     sel = [r for r in rows if lo <= int(r["Start_Timestamp"]) < hi]
