@@ -524,6 +524,29 @@ def test_swin_ln_linear_fused_vs_chain_and_torch(ops, C, rows):
         check(t + ".vs_torch_fp32", y.float(), ref, 2e-2)
 
 
+def test_swin_tail_split_equals_single_stream(ops):
+    """Stages 3-4 as two half batches on two HIP streams (SwinTransformer.forward(tail_streams=...)) against the
+    one-stream forward, train mode (StochasticDepth active, same draws): the per-image arithmetic is the same."""
+    _, model = _product_model(2, 0, "bf16")
+    enc = model.img_encoder.train()
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(16, 1, 224, 224, generator=g).to(DEV)
+    s0, s1, head = (torch.cuda.Stream(device=DEV) for _ in range(3))
+    with torch.no_grad():
+        torch.manual_seed(11)
+        ref = enc(img)
+        torch.cuda.synchronize()
+        torch.manual_seed(11)
+        head.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(head):
+            out = enc(img, tail_streams=(s0, s1))
+        torch.cuda.current_stream().wait_stream(s0)
+        torch.cuda.current_stream().wait_stream(head)
+        torch.cuda.synchronize()
+    assert out.shape == ref.shape == (16, 7, 7, 768)
+    check("swin.tail_split_vs_single", out.float(), ref.float(), 1e-6)
+
+
 def test_fused_adamw_matches_torch(ops):
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     g = torch.Generator().manual_seed(2)
