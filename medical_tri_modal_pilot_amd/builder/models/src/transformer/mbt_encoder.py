@@ -10,6 +10,7 @@ how the work reaches the GPU:
   * the caller's length tensors are NOT mutated (the reference does ``varying_lengths[n] += 1``
     in place, :704 -- nothing downstream reads them again).
 """
+import os
 import contextlib
 from typing import List, Optional
 
@@ -60,7 +61,7 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
     def _side_streams(self, dev):
         """Two extra HIP streams: the image (54-token) and text (133-token) streams of a layer cannot fill
         256 CUs on their own, so they run beside the 1005-token vital-sign stream."""
-        if not getattr(self, "overlap_streams", True) or dev.type != "cuda":
+        if not getattr(self, "overlap_streams", True) or dev.type != "cuda" or os.environ.get("MTMP_NO_OVERLAP"):   # (A/B switch)
             return None
         key = (dev.type, dev.index)
         if getattr(self, "_streams_key", None) != key:
