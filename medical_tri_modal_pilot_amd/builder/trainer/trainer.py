@@ -36,6 +36,14 @@ def missing_to_num(missing: torch.Tensor, fullmodal_definition: str = "txt1_img1
     elif fullmodal_definition == "img1":
         missing = missing[:, :2]
     missing = missing.detach().clone().float().cpu()
+    # Fast path (same result): when every row IS one of the template rows -- first flag 0, the others 0/1 -- the sorted
+    # unique rows are exactly the template, so a row's index is its binary value.  Any other row (it would become a new
+    # unique row and shift the indices, as in the reference) takes the unique-based path below.
+    if missing.shape[1] in (2, 3) and missing.shape[0] > 0:
+        rest = missing[:, 1:]
+        if bool(((missing[:, :1] == 0) & ((rest == 0) | (rest == 1))).all()):
+            idx = rest[:, 0] if rest.shape[1] == 1 else 2 * rest[:, 0] + rest[:, 1]
+            return idx.type(torch.LongTensor), missing
     tmpl = torch.tensor(_TEMPLATE[missing.shape[1]])
     _, inverse = torch.unique(torch.cat([tmpl, missing], dim=0), dim=0, sorted=True, return_inverse=True)
     return inverse[tmpl.shape[0]:].type(torch.LongTensor), missing

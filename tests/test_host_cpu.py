@@ -91,9 +91,24 @@ def test_missing_num_bit_exact():
     bt = filler.make_batch(int(G["seed"]), int(G["B"]), int(G["T"]))
     mn, _ = missing_to_num(bt["missing"])
     assert torch.equal(mn, torch.from_numpy(G["missing_num"]))
-    for rows in ([[0, 1, 1], [0, 0, 0]], [[0, 0, 1]] * 5, [[0, 1, 0], [0, 1, 1], [0, 0, 1], [0, 0, 0]]):
+    # template rows only (the product's closed-form fast path) and rows outside the template (vital signs missing,
+    # values other than 0/1: they become new unique rows and shift the indices, as in the reference) -- all against
+    # the oracle's unique-based restatement of trainer.py:53-77
+    for rows in ([[0, 1, 1], [0, 0, 0]], [[0, 0, 1]] * 5, [[0, 1, 0], [0, 1, 1], [0, 0, 1], [0, 0, 0]],
+                 [[1, 0, 0], [0, 1, 1]], [[0, 2, 0], [0, 0, 1], [0, 1, 0]], [[0, 0.5, 1], [0, 1, 1]], [[1, 1, 1]] * 3):
         m = torch.tensor(rows, dtype=torch.float32)
+        assert torch.equal(missing_to_num(m)[0], O.missing_to_num(m)), rows
+    g = torch.Generator().manual_seed(3)
+    for _ in range(20):
+        m = torch.randint(0, 2, (17, 3), generator=g).float()
+        m[:, 0] = 0
         assert torch.equal(missing_to_num(m)[0], O.missing_to_num(m))
+        for fd in ("txt1", "img1"):
+            got = missing_to_num(m, fd)[0]
+            sub = torch.stack([m[:, 0], m[:, 2]]).permute(1, 0) if fd == "txt1" else m[:, :2]
+            tmpl = torch.tensor([[0., 0.], [0., 1.]])                              # trainer.py:57-66
+            want = torch.unique(torch.cat([tmpl, sub], 0), dim=0, sorted=True, return_inverse=True)[1][2:]
+            assert torch.equal(got, want)
 
 
 def test_key_lengths_bit_exact():

@@ -14,8 +14,12 @@ ops.marks_enable(torch.device("cuda", 0))
 _run, _step = G.GraphedTrainStep.run, O.FusedAdamW.step
 
 
+count = {"k": 0}
+
+
 def run(self, inputs, fn, params=None):
     ops.mark("step.s")
+    ops.mark("step.s%d" % (count["k"] % 2))          # per-parity copies: the idle time between two steps
     out = _run(self, inputs, fn, params)
     ops.mark("graph.e")
     return out
@@ -24,6 +28,8 @@ def run(self, inputs, fn, params=None):
 def step(self, closure=None):
     r = _step(self, closure)
     ops.mark("adamw.e")
+    ops.mark("adamw.e%d" % (count["k"] % 2))
+    count["k"] += 1
     return r
 
 
@@ -34,6 +40,10 @@ G.GraphedTrainStep.run, O.FusedAdamW.step = run, step
 def report():
     torch.cuda.synchronize()
     t = ops.marks_read()
+    last = (count["k"] - 1) % 2
+    if "step.s%d" % last in t and "adamw.e%d" % (1 - last) in t:
+        print("GPU idle between the previous step's AdamW and this step's first launch: %.1f us"
+              % (t["step.s%d" % last] - t["adamw.e%d" % (1 - last)]), file=sys.stderr)
     t0 = t.get("step.s", min(t.values()))
     for k, v in sorted(t.items(), key=lambda kv: kv[1]):
         print("%9.1f us  %s" % (v - t0, k), file=sys.stderr)
