@@ -252,7 +252,11 @@ MTMP_DEV void bias_fetch(f32x4 (&b)[Panel<T>::G][4], const float* bias, const T*
 }
 // LDS traffic of ONE wave to its private staging tile needs no barrier (a wave's LDS instructions execute in
 // order); this only stops the compiler from moving memory operations across the hand-over point.
+#ifdef MTMP_HANDOVER_WAIT      // (A/B builds: the explicit wait of the first version)
 MTMP_DEV void wave_lds_handover() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+MTMP_DEV void wave_lds_handover() { asm volatile("" ::: "memory"); }
+#endif
 
 template <typename T, bool RELU>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(GemmArgs<T> p) {
