@@ -220,6 +220,18 @@ MTMP_DEV unsigned dropout_keep4(unsigned seed, unsigned g, unsigned thr) {
            ((y >> 16) >= thr ? 8u : 0u);
 }
 
+// The same four decisions as 16-bit fields (element 4g+i is kept iff f[i] >= thr): a caller that compares the fields itself
+// feeds the compare result straight into its select instead of building the 4-bit mask and testing it again
+// (4 instructions per element less in the GEMM epilogues).
+MTMP_DEV void dropout_fields4(unsigned seed, unsigned g, unsigned (&f)[4]) {
+    unsigned x = (g * 0x9E3779B1u) ^ seed;
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    unsigned y = x * 0x27D4EB2Fu; y ^= y >> 15;
+    f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
+}
+// ReLU as ONE v_med3_f32 (fmaxf() on an MFMA output costs an extra canonicalising v_max)
+MTMP_DEV float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8)
 // get a contiguous chunk of the work list, so neighbours share that XCD's L2.
 MTMP_DEV int xcd_remap(int bid, int nwg) {

@@ -107,7 +107,7 @@ template <int TM> struct NtGeom {
     static constexpr int WR = TM / (32 * RT), WC = 4 / WR, NT = 4 / WC;
 };
 
-template <typename T, bool RELU, int TM>
+template <typename T, bool RELU, int TM, bool DROP>
 MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
     using G = NtGeom<TM>;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
@@ -142,13 +142,21 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], cons
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
                 float v[4];
-                const unsigned keep = p.drop_p > 0.f ? dropout_keep4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
+                unsigned fld[4];
+                if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[rt][nt][4 * g + i] + bv[i];
-                    if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
-                    if (p.act == 2) v[i] = gelu<T>(v[i]);
-                    if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
+                for (int i = 0; i < 4; ++i) v[i] = acc[rt][nt][4 * g + i] + bv[i];
+                if (RELU || p.act == 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = relu1(v[i]);
+                }
+                if (p.act == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = gelu<T>(v[i]);
+                }
+                if (DROP) {                      // (template parameter: no per-element selects when dropout is off)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
                 }
                 store4<T>(sOut + rl * LDO + cl, v[0], v[1], v[2], v[3]);
             }
@@ -258,7 +266,7 @@ MTMP_DEV void wave_lds_handover() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "mem
 MTMP_DEV void wave_lds_handover() { asm volatile("" ::: "memory"); }
 #endif
 
-template <typename T, bool RELU>
+template <typename T, bool RELU, bool DROP>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(GemmArgs<T> p) {
     using P = Panel<T>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -344,13 +352,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
                 const int col = n0 + 32 * g + 8 * i4 + 4 * half;
-                const unsigned keep = p.drop_p > 0.f ? dropout_keep4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, thr) : 15u;
+                unsigned fld[4];
+                if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
                 float v[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     v[i] = acc[g][4 * i4 + i];
-                    if (RELU || p.act == 1) v[i] = fmaxf(v[i], 0.f);
-                    if (p.drop_p > 0.f) v[i] = (keep >> i) & 1u ? v[i] * keep_scale : 0.f;
+                    if (RELU) v[i] = relu1(v[i]);
+                    if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
                 }
                 store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
             }
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 // each (as in gemm_tn_tr_kernel) was measured and rejected: it needs 256 VGPRs and 74 KiB of LDS, i.e. two
 // workgroups per CU instead of three, and every large launch got 20-30 % slower (dH 93 -> 120 us, FFN2 76 -> 97 us);
 // only launches with < 1 workgroup per CU gained.  Occupancy hides this loop's latency better than depth.
-template <typename T, bool RELU, int TM>
+template <typename T, bool RELU, int TM, bool DROP>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) void gemm_nt_kernel(GemmArgs<T> p) {
     using G = NtGeom<TM>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -446,7 +455,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) voi
         }
     }
     __syncthreads();                          // every wave is done with sA / sW: reuse them as the staging tile
-    epilogue<T, RELU, TM>(acc, p, sA, m0, n0, tid);
+    epilogue<T, RELU, TM, DROP>(acc, p, sA, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -764,7 +773,9 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
         return MTMP_ERR_ARG;
     }
     if (sm > 48 * 1024) {
-        const void* f = relu ? (const void*)ln_gemm_kernel<T, true> : (const void*)ln_gemm_kernel<T, false>;
+        const void* fs[4] = {(const void*)ln_gemm_kernel<T, false, false>, (const void*)ln_gemm_kernel<T, false, true>,
+                             (const void*)ln_gemm_kernel<T, true, false>, (const void*)ln_gemm_kernel<T, true, true>};
+        const void* f = fs[(relu ? 2 : 0) + (a.drop_p > 0.f ? 1 : 0)];
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
             mtmp_set_error("mtmp_ln_gemm: cannot raise dynamic LDS to %zu", sm);
             return MTMP_ERR_LAUNCH;
@@ -776,8 +787,11 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
     int nsplit = 512 / mtiles;
     nsplit = nsplit < 1 ? 1 : (nsplit > npanels ? npanels : nsplit);
     dim3 grid(mtiles, nsplit);
-    if (relu) hipLaunchKernelGGL((ln_gemm_kernel<T, true>), grid, dim3(256), sm, st, a);
-    else      hipLaunchKernelGGL((ln_gemm_kernel<T, false>), grid, dim3(256), sm, st, a);
+    const bool drop = a.drop_p > 0.f;         // (RELU, DROP) are template parameters: no per-element selects in the epilogue
+    if (relu && drop)       hipLaunchKernelGGL((ln_gemm_kernel<T, true, true>), grid, dim3(256), sm, st, a);
+    else if (relu)          hipLaunchKernelGGL((ln_gemm_kernel<T, true, false>), grid, dim3(256), sm, st, a);
+    else if (drop)          hipLaunchKernelGGL((ln_gemm_kernel<T, false, true>), grid, dim3(256), sm, st, a);
+    else                    hipLaunchKernelGGL((ln_gemm_kernel<T, false, false>), grid, dim3(256), sm, st, a);
     MTMP_CHECK_LAUNCH("mtmp_ln_gemm");
     return MTMP_OK;
 }
@@ -787,15 +801,20 @@ int launch_gemm_nt_tm(GemmArgs<T> a, int relu, hipStream_t st) {
     const size_t stage = (size_t)TM * LDO * sizeof(T);
     if (sm < stage) sm = stage;
     if (sm > 48 * 1024) {
-        const void* f = relu ? (const void*)gemm_nt_kernel<T, true, TM> : (const void*)gemm_nt_kernel<T, false, TM>;
+        const void* fs[4] = {(const void*)gemm_nt_kernel<T, false, TM, false>, (const void*)gemm_nt_kernel<T, false, TM, true>,
+                             (const void*)gemm_nt_kernel<T, true, TM, false>, (const void*)gemm_nt_kernel<T, true, TM, true>};
+        const void* f = fs[(relu ? 2 : 0) + (a.drop_p > 0.f ? 1 : 0)];
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
             mtmp_set_error("mtmp_gemm_nt: cannot raise dynamic LDS to %zu", sm);
             return MTMP_ERR_LAUNCH;
         }
     }
     dim3 grid(((a.M + TM - 1) / TM) * ((a.N + BN - 1) / BN));
-    if (relu) hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM>), grid, dim3(256), sm, st, a);
-    else      hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM>), grid, dim3(256), sm, st, a);
+    const bool drop = a.drop_p > 0.f;
+    if (relu && drop)       hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM, true>), grid, dim3(256), sm, st, a);
+    else if (relu)          hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM, false>), grid, dim3(256), sm, st, a);
+    else if (drop)          hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM, true>), grid, dim3(256), sm, st, a);
+    else                    hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM, false>), grid, dim3(256), sm, st, a);
     MTMP_CHECK_LAUNCH("mtmp_gemm_nt");
     return MTMP_OK;
 }
