@@ -229,8 +229,9 @@ MTMP_DEV void dropout_fields4(unsigned seed, unsigned g, unsigned (&f)[4]) {
     unsigned y = x * 0x27D4EB2Fu; y ^= y >> 15;
     f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
 }
-// ReLU as ONE v_med3_f32 (fmaxf() on an MFMA output costs an extra canonicalising v_max)
-MTMP_DEV float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff()); }
+// ReLU as ONE integer max (fmaxf() / fmed3 on an MFMA output cost an extra canonicalising v_max each): negative floats
+// (and -0.0) are negative integers, everything else passes unchanged (NaNs with the sign bit clear stay NaNs).
+MTMP_DEV float relu1(float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0)); }
 
 // XCD-aware bijective remap of a 1-D block id: blocks that share an XCD (id % 8)
 // get a contiguous chunk of the work list, so neighbours share that XCD's L2.

@@ -241,22 +241,27 @@ template <typename T> MTMP_DEV void panel_commit(T* dst, const PanelRegs& w, int
         *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst + row * P::LDP) + 16 * ch) = w.q[i];
     }
 }
-// bias of one panel in accumulator order (lane half h: features 32g + 8*i4 + 4h .. +3); a null bias reads zeros
-// from a constant so that the load count per iteration stays static
+// bias of one panel in accumulator order (lane half h: features 32g + 8*i4 + 4h .. +3), loaded straight into the
+// register block that the panel's FIRST MFMA takes as its C operand (no accumulator-initialising moves).  A null bias
+// reads the first N*4 bytes of W instead -- both are kernel-argument, i.e. global, pointers; a select between the bias and
+// a __device__ constant would turn these into FLAT loads, whose out-of-order counters force s_waitcnt 0 everywhere -- and
+// the caller zeroes the block behind a uniform branch (bias_or_zero), so the load count per iteration stays static.
 template <typename T>
-MTMP_DEV void bias_fetch(f32x4 (&b)[Panel<T>::G][4], const float* bias, const T* w, int n0, int half) {
-    // (a select between the bias and a __device__ constant would turn these into FLAT loads, whose
-    //  out-of-order counters force s_waitcnt 0 everywhere; with no bias, the first N*4 bytes of W are read
-    //  and masked to zero instead -- both are kernel-argument, i.e. global, pointers)
+MTMP_DEV void bias_fetch(f32x16 (&b)[Panel<T>::G], const float* bias, const T* w, int n0, int half) {
     const float* src = bias ? bias : reinterpret_cast<const float*>(w);
-    const unsigned m = bias ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int g = 0; g < Panel<T>::G; ++g)
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + n0 + 32 * g + 8 * i4 + 4 * half);
-            b[g][i4] = __builtin_bit_cast(f32x4, v & u32x4_t{m, m, m, m});
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + n0 + 32 * g + 8 * i4 + 4 * half);
+            b[g][4 * i4] = v[0]; b[g][4 * i4 + 1] = v[1]; b[g][4 * i4 + 2] = v[2]; b[g][4 * i4 + 3] = v[3];
         }
+}
+template <typename T> MTMP_DEV void bias_or_zero(f32x16 (&b)[Panel<T>::G], const float* bias) {
+    if (!bias) {
+#pragma unroll
+        for (int g = 0; g < Panel<T>::G; ++g) b[g] = f32x16{0};
+    }
 }
 // LDS traffic of ONE wave to its private staging tile needs no barrier (a wave's LDS instructions execute in
 // order); this only stops the compiler from moving memory operations across the hand-over point.
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
         }
     }
     panel_commit<T>(sP, wreg, tid);
-    f32x4 binit[P::G][4];
+    f32x16 binit[P::G];
     bias_fetch<T>(binit, p.bias, p.w, j0 * P::NP, half);
     panel_fetch<T>(wreg, p.w, min(j0 + 1, j1 - 1) * P::NP, p.N, tid);
     __syncthreads();                                             // panel j0 visible; sG dead (sS may be written)
@@ -334,13 +339,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
         const int n0 = j * P::NP;
         T* cur = sP + ((j - j0) & 1) * P::NP * P::LDP;
         T* nxt = sP + (((j - j0) & 1) ^ 1) * P::NP * P::LDP;
-        f32x16 acc[P::G];                                        // accumulators start from the bias
+        f32x16 acc[P::G];                                        // the first MFMA takes the bias block as its C operand
+        bias_or_zero<T>(binit, p.bias);
 #pragma unroll
         for (int g = 0; g < P::G; ++g)
+            acc[g] = mma_c<T>(frag_load<T>(cur + (32 * g + r) * P::LDP + 8 * half), af[0], binit[g]);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) acc[g][t] = binit[g][t >> 2][t & 3];
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
+        for (int c = 1; c < 16; ++c)
 #pragma unroll
             for (int g = 0; g < P::G; ++g)
                 mma<T>(acc[g], frag_load<T>(cur + (32 * g + r) * P::LDP + 16 * c + 8 * half), af[c]);
