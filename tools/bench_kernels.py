@@ -72,6 +72,9 @@ def main():
         r = R(m, n)
         rec(name, timeit(lambda: ops.gemm_nt(x, w, b, res2d=r), a.rounds), 2.0 * m * n * k)
         rec(name + ".blas", timeit(lambda: torch.addmm(r, x, w.t()), a.rounds), 2.0 * m * n * k)
+    if want("gemm_nt"):             # dH = dY W2 gated by the saved hidden activation (FFN backward)
+        dy, w2t, h = R(M, 256), R(1024, 256) * 0.05, R(M, 1024)
+        rec("gemm_nt.dH_gated[M,1024,256]", timeit(lambda: ops.gemm_nt(dy, w2t, gate=h, gate_scale=1.0 / 0.9), a.rounds), 2.0 * M * 1024 * 256)
     # ---- LN-fused GEMMs
     if want("ln_gemm"):
         x = R(M, 256)
