@@ -77,6 +77,11 @@ MTMP_DEV void tile_fetch(TileRegs<T>& t, const T* src, int ld, int row0, int lim
     }
 }
 template <typename T, int ROWS = 128> MTMP_DEV void tile_commit(T* dst, const TileRegs<T>& t, int tid) {
+    if (wave_all(t.ok == (1u << (ROWS / 32)) - 1u)) {      // no K tail in this chunk (every chunk when K % 64 == 0): no masking
+#pragma unroll
+        for (int ps = 0; ps < ROWS / 32; ++ps) frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, t.f[ps]);
+        return;
+    }
 #pragma unroll
     for (int ps = 0; ps < ROWS / 32; ++ps)
         frag_store<T>(dst + ((tid >> 3) + 32 * ps) * LDW + (tid & 7) * 8, frag_keep(t.f[ps], (t.ok >> ps) & 1u));
