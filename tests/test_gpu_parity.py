@@ -176,6 +176,35 @@ def test_ln_bwd(ops, dt, golden_dir):
     check(t + ".dbeta", db, bet.grad, 1e-4 if dt == torch.float32 else 1e-2)
 
 
+def test_ln_gemm_dropout_statistics(ops):
+    """Dropout inside mtmp_ln_gemm (module.py:77-79 after the ReLU): kept elements are the no-dropout values / (1-p), the keep
+    fraction is 1-p overall, per row and per column, a different seed gives a different mask, the same seed the same one."""
+    g = torch.Generator().manual_seed(7)
+    M, N, p = 1536, 1024, 0.1
+    x = torch.randn(M, 256, generator=g).to(DEV)
+    gm, bt = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+    w = (torch.randn(N, 256, generator=g) / 16).to(DEV)
+    b = torch.full((N,), 3.0, device=DEV)            # large bias: nearly every pre-dropout value is positive
+    y0, _, _ = ops.ln_gemm(x, gm, bt, w, b, N)
+    y1, _, _ = ops.ln_gemm(x, gm, bt, w, b, N, drop_p=p, seed=4242)
+    pos = y0 > 0
+    kept = (y1 != 0) & pos
+    frac = float(kept.sum()) / float(pos.sum())
+    REPORT["ln_gemm.dropout.keep_fraction"] = {"rel_err": abs(frac - (1 - p)), "tol": 0.005}
+    assert abs(frac - (1 - p)) < 0.005, frac
+    assert torch.allclose(y1[kept], y0[kept] / (1 - p), rtol=1e-5, atol=1e-6)
+    rows, cols = kept.float().mean(1), kept.float().mean(0)
+    assert float((rows - (1 - p)).abs().max()) < 0.06 and float((cols - (1 - p)).abs().max()) < 0.06
+    # no structure along the feature axis: neighbouring decisions are uncorrelated
+    k = kept.float() - kept.float().mean()
+    for lag in (1, 2, 4, 8, 32, 64):
+        c = float((k[:, :-lag] * k[:, lag:]).mean() / k.var())
+        assert abs(c) < 0.01, (lag, c)
+    y2, _, _ = ops.ln_gemm(x, gm, bt, w, b, N, drop_p=p, seed=4242)
+    y3, _, _ = ops.ln_gemm(x, gm, bt, w, b, N, drop_p=p, seed=4243)
+    assert torch.equal(y1, y2) and not torch.equal(y1 != 0, y3 != 0)
+
+
 def test_dropout_mask_consistency(ops):
     g = torch.Generator().manual_seed(1)
     M, p, seed = 512, 0.1, 1234567
