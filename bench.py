@@ -1,61 +1,92 @@
-"""Headline benchmark: tri-modal training samples/s (BASELINE.json metric) on N MI355X.
+"""Headline benchmark: tri-modal training samples/s (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full optimisation step of TRI_MBT_VSLTCLS through the reference's trainer
-contract (zero_grad, forward, BCE, backward, AdamW, scheduler) on one synthetic batch that is
-already resident in HBM.  Workload = BASELINE.json configs[1]: vslt_img_txt, 6 layers, d_model
-256, per-GPU batch 64, TIE-len 1000 (full-length events -> N_v = 1005), one 224x224 CXR, 128
-text tokens, bf16 MFMA build, dropout 0.1 (the reference default), random-init weights.
-Weak scaling: every rank runs its own batch of 64; gradients are all-reduced over RCCL.
+N > 1 without a launcher (WORLD_SIZE unset): this process starts ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`` as a CHILD before it makes any GPU call, relays
+rank 0's JSON line and exits with the child's status.  Launched by the driver under torch.distributed.run (RANK /
+LOCAL_RANK / WORLD_SIZE set), it is one rank.
+
+One "step" = one full optimisation step of TRI_MBT_VSLTCLS through the reference's trainer contract (zero_grad,
+forward, BCE, backward, AdamW, scheduler, loss.item()) on one synthetic batch that is already resident in HBM.
+Workload = BASELINE.json configs[1]: vslt_img_txt, 6 layers, d_model 256, per-GPU batch 64, TIE-len 1000 (full-length
+events -> N_v = 1005), one 224x224 CXR, 128 text tokens, bf16 MFMA build, dropout 0.1 (the reference default),
+random-init weights.  Weak scaling: every rank runs its own batch of 64; gradients are all-reduced over RCCL
+(ddp.GradReducer; under hipGraph replay the step is cut into 3 graphs and the buckets of one go out beside the next).
+
+Timing: W warm-up steps, then K steps bracketed by barrier + torch.cuda.synchronize(); every step ends in the
+reference's loss.item(), so per-step host times are exact step times.  ms_per_step is the MEDIAN of the K steps
+(MAX over ranks), value = global batch / that; the mean over the bracketed region is reported beside it.
 
 The JSON line also carries
-  roofline     -- the dominant kernel (key-masked attention forward, vslt stream): algorithmic
-                  FLOPs 4*B*H*N^2*64 per launch / average launch time measured with HIP events
-                  on the launch stream inside the timed steps, against the 2.5 PFLOP/s dense bf16 peak;
-  cpu_baseline -- the CPU oracle (fp32 PyTorch restatement of the reference, golden-pinned) timed
-                  on this host's cores on a bounded sample (rank 0, N=1 only).
+  roofline      -- the dominant kernel (key-masked attention forward, vslt stream): algorithmic FLOPs 4*B*H*N^2*64 per
+                   launch / launch duration, against the 2.5 PFLOP/s dense bf16 peak.  The duration is measured AFTER
+                   the timed region on the step's REAL layer-0 tensors (captured from one eager step): K back-to-back
+                   launches between ONE pair of HIP events on an otherwise idle device, so host enqueue latency cannot
+                   leak into it (round 1 bracketed single Python-side launches inside host-bound eager steps and read
+                   2.3x too long).  The rocprofv3 average of the same kernel inside the replayed steps is committed
+                   under profiles/ and quoted as rocprof_avg_us.
+  roofline_more -- the same probe for the attention backward and the weight-gradient GEMM of the vslt stream.
+  cpu_baseline  -- the CPU oracle (fp32 PyTorch restatement of the reference, golden-pinned) timed on this host's
+                   cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-import torch  # noqa: E402
+import torch  # noqa: E402  (importing torch makes no GPU call)
 import torch.distributed as dist  # noqa: E402
 
-B_PER_GPU, TIE_LEN, LAYERS = 64, 1000, 6
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
+WORKLOADS = {
+    # name: (per-GPU batch, TIE-len, layers, multiimages, n_images, ragged, missing mode, description)
+    "full": (64, 1000, 6, 0, 1, False, "none",
+             "BASELINE configs[1]: vslt_img_txt tri_mbt_vsltcls, 6 layers, d_model 256, batch 64/GPU, TIE-len 1000 "
+             "(N_v=1005), 224x224 CXR, 128-tok text"),
+    "ragged": (64, 1000, 6, 0, 1, True, "mixed",
+               "BASELINE configs[3] shape: configs[1] with len ~ U{3..1000} and mixed missing modalities; roofline flops "
+               "still count the dense N^2"),
+    "cfg5": (128, 2000, 12, 1, 4, False, "none",
+             "BASELINE configs[4]: multiimages with 4 images per sample (N_i=201), TIE-len 2000 (N_v=2005), 12 layers, "
+             "batch 128/GPU"),
+}
 
-def make_args(dtype: str, dropout: float, hip_graph: int = 1):
+
+def make_args(wl, dtype: str, dropout: float, hip_graph: int, graph_stages: int, ddp: bool):
     from medical_tri_modal_pilot_amd.control.config import parse_args
+    B, T, L, multi, K = WORKLOADS[wl][:5]
     return parse_args(["--input-types", "vslt_img_txt", "--model", "tri_mbt_vsltcls", "--modality-inclusion",
                        "train-missing_test-missing", "--lr-init", "1e-5", "--output-type", "intubation",
-                       "--batch-size", str(B_PER_GPU), "--transformer-num-layers", str(LAYERS), "--vslt-type", "TIE",
-                       "--model-types", "detection", "--imgtxt-time", "1", "--mbt-only-vslt", "1", "--multiimages", "0",
-                       "--dropout", str(dropout), "--compute-dtype", dtype, "--hip-graph", str(hip_graph)])
+                       "--batch-size", str(B), "--transformer-num-layers", str(L), "--vslt-type", "TIE", "--TIE-len", str(T),
+                       "--model-types", "detection", "--imgtxt-time", "1", "--mbt-only-vslt", "1", "--multiimages", str(multi),
+                       "--n-images", str(max(K, 1)), "--dropout", str(dropout), "--compute-dtype", dtype,
+                       "--hip-graph", str(hip_graph), "--graph-stages", str(graph_stages), "--ddp", str(int(ddp)),
+                       "--synthetic", "1"])
 
 
-def cpu_baseline(sample_b: int = 8, timed: int = 2):
+def cpu_baseline(wl, shapes, sample_b: int = 8, timed: int = 2):
     """Oracle (port of the reference's CPU path) on a bounded sample of the same workload."""
-    import filler
+    from medical_tri_modal_pilot_amd import synthetic
     from oracle import tri_mbt_oracle as O
-    from tests.state_shapes import reference_state_shapes
+    _, T, L, multi, K = WORKLOADS[wl][:5]
+    if wl == "cfg5":
+        sample_b = 2
     torch.manual_seed(0)
-    sd = {}
-    for k, s in reference_state_shapes(LAYERS).items():
-        sd[k] = filler.fill_tensor(k, torch.zeros(s))
+    sd = {k: synthetic.fill_tensor(k, torch.zeros(s)) for k, s in shapes.items()}
     sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
-    bt = filler.make_batch(1234, sample_b, TIE_LEN, ragged=False, missing_mode="none")
-    tr = O.OracleTrainer(sd, O.Cfg(n_layers=LAYERS, dropout=0.1), lr_init=1e-5, batch_size=sample_b, iters_per_epoch=100)
+    bt = synthetic.make_batch(1234, sample_b, T, ragged=False, missing_mode="none", multiimages=multi, n_images=K)
+    tr = O.OracleTrainer(sd, O.Cfg(n_layers=L, dropout=0.1, multiimages=multi), lr_init=1e-5, batch_size=sample_b,
+                         iters_per_epoch=100)
     tr.step(bt, 1)                                   # warm-up
     ts = []
     for i in range(timed):
@@ -64,11 +95,11 @@ def cpu_baseline(sample_b: int = 8, timed: int = 2):
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
     return {"value": sample_b / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle full train step (fwd+BCE+bwd+AdamW), fp32, B={sample_b} of the config-2 batch "
-                      f"(T={TIE_LEN}, L={LAYERS}), 1 warm-up + {timed} timed, median {t:.2f} s/step"}
+            "sample": f"oracle full train step (fwd+BCE+bwd+AdamW), fp32, B={sample_b} of the workload's batch "
+                      f"(T={T}, L={L}), 1 warm-up + {timed} timed, median {t:.2f} s/step"}
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -77,66 +108,76 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hip-graph", type=int, default=1, choices=[0, 1])
-    ap.add_argument("--workload", default="full", choices=["full", "ragged"],
-                    help="full = BASELINE configs[1] (every series at TIE-len, all modalities; the headline number); "
-                         "ragged = configs[3] shape: len ~ U{3..T}, mixed missing modalities (SURVEY 8d)")
+    ap.add_argument("--graph-stages", type=int, default=0, help="0 = auto (3 with more than one rank, else 1)")
+    ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS),
+                    help="full = BASELINE configs[1] (the headline number); ragged = configs[3] shape; "
+                         "cfg5 = configs[4] (K = 4 images, B 128, TIE-len 2000, 12 layers)")
     ap.add_argument("--packed", type=int, default=0, choices=[0, 1],
                     help="feed the vital-sign events as the ragged PackedTieBatch of builder/data (SURVEY 8 f-1)")
-    ap.add_argument("--probe-steps", type=int, default=5, help="eager steps after the timed region that time "
-                    "the roofline kernel with HIP events (only when the timed region replays a hipGraph)")
-    a = ap.parse_args()
+    ap.add_argument("--probe-launches", type=int, default=30,
+                    help="back-to-back launches per kernel of the roofline probe after the timed region (0 = no probe)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="run the RCCL reducer even with one rank (exercises the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--print-loss", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check without a GPU: every rank joins a gloo group, barriers, and rank 0 "
+                         "prints a JSON line")
+    return ap.parse_args()
+
+
+def self_launch(a) -> int:
+    """--gpus N > 1 and no launcher environment: run N ranks as children of this (GPU-free) process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    # MTMP_FORCE_DDP=1: run the RCCL reducer even with one rank (exercises the N>1 code path on a 1-GPU box)
-    ddp = world > 1 or bool(os.environ.get("MTMP_FORCE_DDP"))
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    ddp = world > 1 or a.force_ddp
     if ddp and "MASTER_ADDR" not in os.environ:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    if a.dry_run:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(), "max_rank": int(t)}))
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if ddp:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import filler
-    from medical_tri_modal_pilot_amd import ops
-    from medical_tri_modal_pilot_amd.builder.models import get_model
+    from medical_tri_modal_pilot_amd import ops, synthetic
     from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
     from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
-    from medical_tri_modal_pilot_amd.optim import FusedAdamW
-    from medical_tri_modal_pilot_amd.ddp import GradReducer, broadcast_module_state
+    from medical_tri_modal_pilot_amd.train import _Logger, build_training
 
-    args = make_args(a.dtype, a.dropout, a.hip_graph)
-    args.device = dev
+    B_PER_GPU, TIE_LEN, LAYERS, multi, n_img, ragged, miss_mode, wl_text = WORKLOADS[a.workload]
+    args = make_args(a.workload, a.dtype, a.dropout, a.hip_graph, a.graph_stages, ddp)
     torch.manual_seed(412)
-    model = get_model(args)(args).to(dev)
-    if ddp:
-        broadcast_module_state(model, 0)
+    model, opt, crit = build_training(args, dev, ddp)
     model.train()
-    if os.environ.get("MTMP_NO_OVERLAP"):            # experiment switch: all three modality streams on one HIP stream
-        model.fusion_transformer.overlap_streams = False
-    opt = FusedAdamW(model.hot_parameters(), lr=args.lr_init, weight_decay=args.weight_decay)
-    if ddp:
-        opt.reducer = GradReducer(opt.flat)
-        opt.grad_scale = 1.0 / world
     sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=args.t_0 * 100, cycle_mult=args.t_mult,
                                           max_lr=args.lr_init * math.sqrt(args.batch_size), min_lr=1e-6,
                                           warmup_steps=args.t_up * 100, gamma=args.gamma)
-    crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
 
-    class Log:
-        class Ev:
-            def add_batch(self, *_):
-                pass
-        evaluator = Ev()
-
-        def log_lr(self, *_):
-            pass
-
-    ragged = a.workload == "ragged"
-    bt = filler.make_batch(1234 + rank, B_PER_GPU, TIE_LEN, ragged=ragged, missing_mode="mixed" if ragged else "none")
+    bt = synthetic.make_batch(1234 + rank, B_PER_GPU, TIE_LEN, ragged=ragged, missing_mode=miss_mode, multiimages=multi,
+                              n_images=n_img)
     d = {k: v.to(dev) for k, v in bt.items() if k != "missing"}
     static = torch.stack([d["gen"], d["age"]], 1)
     x_in = d["x"]
@@ -144,62 +185,18 @@ def main():
         from medical_tri_modal_pilot_amd.builder.data import collate_packed
         x_in = collate_packed([(bt["x"][b, :int(n)].numpy(), static[b].cpu().numpy(), float(bt["txt_time"][b]))
                                for b, n in enumerate(bt["input_lengths"])])
-    kw = dict(args=args, x=x_in, static=static, y=d["y"], output_lengths=None, model=model, logger=Log(),
+    kw = dict(args=args, x=x_in, static=static, y=d["y"], output_lengths=None, model=model, logger=_Logger(),
               device=dev, scheduler=sched, optimizer=opt, criterion=crit, x_txt=d["txt"], x_img=d["img"],
               imgtxt_time=(d["img_time"], d["txt_time"]), scaler=None, missing=bt["missing"], flow_type="train",
               reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
     in_len_host = bt["input_lengths"]            # lengths stay on the host like the reference loader's
 
-    # HIP-event instrumentation of the dominant kernel (vslt-stream attention forward)
-    events = []
-    raw_attn_fwd = ops.attn_fwd
-    record = {"on": False}
-
-    def timed_attn_fwd(qkv, kv_len, res=None):
-        if record["on"] and qkv.shape[1] == TIE_LEN + 5:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = raw_attn_fwd(qkv, kv_len, res)
-            e1.record()
-            events.append((e0, e1))
-            return out
-        return raw_attn_fwd(qkv, kv_len, res)
-
-    ops.attn_fwd = timed_attn_fwd
-
-    # the same for the two other heavy kernels of the vital-sign stream (reported under "roofline_more"):
-    # attention backward (dQ + dK/dV launches of one call) and the weight-gradient GEMMs
-    more = {"attn_bwd": [], "gemm_tn": []}
-    raw_attn_bwd, raw_gemm_tn = ops.attn_bwd, ops.gemm_tn
-
-    def timed_attn_bwd(qkv, *rest):
-        if record["on"] and qkv.shape[1] == TIE_LEN + 5:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = raw_attn_bwd(qkv, *rest)
-            e1.record()
-            more["attn_bwd"].append((e0, e1, 10.0 * qkv.shape[0] * 4 * qkv.shape[1] * qkv.shape[1] * 64))
-            return out
-        return raw_attn_bwd(qkv, *rest)
-
-    def timed_gemm_tn(dy2d, x2d, *rest, **kws):
-        if record["on"] and dy2d.shape[0] >= B_PER_GPU * TIE_LEN:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = raw_gemm_tn(dy2d, x2d, *rest, **kws)
-            e1.record()
-            more["gemm_tn"].append((e0, e1, 2.0 * dy2d.shape[0] * dy2d.shape[1] * x2d.shape[1]))
-            return out
-        return raw_gemm_tn(dy2d, x2d, *rest, **kws)
-
-    ops.attn_bwd, ops.gemm_tn = timed_attn_bwd, timed_gemm_tn
-
     # host-side enqueue time: from step start until the trainer blocks in loss.item()
-    enq = {"t0": 0.0, "sum": 0.0, "n": 0}
+    enq = {"t0": 0.0, "sum": 0.0, "n": 0, "on": False}
     raw_item = torch.Tensor.item
 
     def timed_item(self):
-        if record["on"] and enq["t0"] > 0:
+        if enq["on"] and enq["t0"] > 0:
             enq["sum"] += time.perf_counter() - enq["t0"]
             enq["n"] += 1
             enq["t0"] = 0.0
@@ -213,91 +210,123 @@ def main():
 
     for i in range(a.warmup):
         step(i + 1)
-    record["on"] = True
+    enq["on"] = True
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loss = 0.0
+    loss, per_step = 0.0, []
     for i in range(a.steps):
-        loss = step(a.warmup + i + 1)
-        if os.environ.get("MTMP_PRINT_LOSS"):
+        ts = time.perf_counter()
+        loss = step(a.warmup + i + 1)            # ends in loss.item(): the step's device work is complete
+        per_step.append(time.perf_counter() - ts)
+        if a.print_loss:
             print(f"step {a.warmup + i + 1} loss {loss:.6f}", file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    record["on"] = False
+    enq["on"] = False
+    torch.Tensor.item = raw_item
     host_ms = 1e3 * enq["sum"] / max(1, enq["n"])
+    med = statistics.median(per_step)
     gs = getattr(model, "_mtmp_graph_step", None)
-    graphed = gs is not None and gs.replays >= a.steps
-    if graphed and rank == 0:
-        # events cannot time one kernel inside a replayed graph: time the same kernel on the same workload in
-        # eager steps right after the timed region (its rocprofv3 average covers both kinds of launch)
-        events.clear()
-        more["attn_bwd"].clear()
-        more["gemm_tn"].clear()
-        args.hip_graph = 0
-        record["on"] = True
-        for i in range(a.probe_steps):
-            step(a.warmup + a.steps + i + 1)
-        torch.cuda.synchronize()
-        record["on"] = False
-        args.hip_graph = a.hip_graph
+    graphed = gs is not None and gs.replays >= a.steps and not gs.disabled
+    n_graphs = 0 if not graphed else max(len(e.get("graphs", [])) for e in gs.entries.values())
     if world > 1:
-        t = torch.tensor([dt], device=dev)
+        t = torch.tensor([dt, med], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt, med = float(t[0]), float(t[1])
     if not math.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")
 
+    # ---- roofline probe: the heavy vslt-stream kernels on the step's real tensors, back to back on an idle device
+    n_tok = TIE_LEN + 5
+    probe = {}
+    if a.probe_launches > 0:
+        grabbed = {}
+        raw = {"attn_fwd": ops.attn_fwd, "attn_bwd": ops.attn_bwd, "gemm_tn": ops.gemm_tn}
+
+        def grab(name, pred):
+            def wrapper(*args_, **kws):
+                if name not in grabbed and pred(*args_):
+                    grabbed[name] = (args_, kws)
+                return raw[name](*args_, **kws)
+            return wrapper
+
+        ops.attn_fwd = grab("attn_fwd", lambda qkv, *_: qkv.shape[1] == n_tok)
+        ops.attn_bwd = grab("attn_bwd", lambda qkv, *_: qkv.shape[1] == n_tok)
+        ops.gemm_tn = grab("gemm_tn", lambda dy, x, *_: dy.shape[0] >= B_PER_GPU * TIE_LEN and dy.shape[1] == 768)
+        args.hip_graph = 0
+        step(a.warmup + a.steps + 1)              # one eager step (every rank: it contains the collective)
+        args.hip_graph = a.hip_graph
+        ops.attn_fwd, ops.attn_bwd, ops.gemm_tn = raw["attn_fwd"], raw["attn_bwd"], raw["gemm_tn"]
+        torch.cuda.synchronize()
+        flops = {"attn_fwd": 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
+                 "attn_bwd": 10.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
+                 "gemm_tn": 2.0 * B_PER_GPU * n_tok * 768 * 256}
+        for name, (args_, kws) in grabbed.items():
+            for _ in range(3):
+                raw[name](*args_, **kws)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.probe_launches):
+                raw[name](*args_, **kws)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.probe_launches
+            probe[name] = (ms, flops[name])
+        if world > 1:
+            dist.barrier()
+
     if rank == 0:
-        n_tok = TIE_LEN + 5
-        k_ms = sum(e0.elapsed_time(e1) for e0, e1 in events) / max(1, len(events))
-        flops = 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64
-        achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        # HBM traffic of the same kernel from the PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate rocprofv3
-        # runs of this script -- counters cannot be read from inside it); committed under profiles/ with its method
-        traffic, traffic_src = None, None
+        k_ms, fl = probe.get("attn_fwd", (0.0, 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64))
+        achieved = fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # HBM traffic and the in-step rocprofv3 average of the same kernel come from separate rocprofv3 runs of this
+        # script (counters / traces cannot be read from inside it); committed under profiles/ with their method
+        traffic = traffic_src = rocprof_us = rocprof_src = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if a.dtype == "bf16" and os.path.exists(tpath):
+        if a.dtype == "bf16" and a.workload == "full" and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/roofline_traffic.json ({tj.get('round')})"
+            rocprof_us, rocprof_src = tj.get("rocprof_avg_us"), tj.get("rocprof_source")
         out = {
-            "metric": "tri-modal training samples/s (fwd+bwd+AdamW step, per-GPU batch 64)",
-            "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-            "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "higher_is_better": True, "scaling": "weak",
+            "metric": "tri-modal training samples/s (fwd+bwd+AdamW step, per-GPU batch %d)" % B_PER_GPU,
+            "value": world * B_PER_GPU / med, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * med, "ms_per_step_mean": 1e3 * dt / a.steps,
+            "value_from_mean": world * B_PER_GPU * a.steps / dt,
+            "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "graphs_per_step": n_graphs,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
-            "config": {"workload": ("BASELINE configs[1]: vslt_img_txt tri_mbt_vsltcls, 6 layers, d_model 256, "
-                                    "batch 64/GPU, TIE-len 1000 (N_v=1005), 224x224 CXR, 128-tok text, "
-                                    f"dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1")
-                                   + (" -- RAGGED variant (configs[3] shape): len ~ U{3..1000}, mixed missing modalities;"
-                                      " roofline flops still count the dense N^2" if ragged else "")
+            "rccl_ranks": dist.get_world_size() if ddp else 1,
+            "config": {"workload": wl_text + f", dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1"
                                    + (" -- events fed as PackedTieBatch" if a.packed else ""),
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "attn_fwd_kernel<bf16> (vslt stream, N=1005)" if a.dtype == "bf16"
-                         else "attn_fwd_kernel<float>", "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
-                         "launches_timed": len(events), "avg_launch_ms": k_ms, "flops_per_launch": flops,
-                         "timed_in": "eager probe steps after the graph-replay region" if graphed else "timed steps"},
+            "roofline": {"bound": "mfma", "kernel": f"attn_fwd_kernel<{'bf16' if a.dtype == 'bf16' else 'float'}> "
+                                                    f"(vslt stream, N={n_tok})",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "launches_timed": a.probe_launches if k_ms > 0 else 0, "avg_launch_ms": k_ms,
+                         "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_src, "flops_per_launch": fl,
+                         "timed_in": "back-to-back launches on the step's layer-0 tensors between one HIP event pair, "
+                                     "idle device, after the timed region"},
         }
         names = {"attn_bwd": "attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (vslt stream; algorithmic flops = 2.5 x forward)",
-                 "gemm_tn": "gemm_tn_tr_kernel + tn_reduce_kernel (vslt-stream weight gradients)"}
+                 "gemm_tn": "gemm_tn_tr_kernel + tn_reduce_kernel (vslt-stream QKV weight gradient, M x 768 x 256)"}
         out["roofline_more"] = []
-        for key, evs in more.items():
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs)
-            fl = sum(f for _, _, f in evs)
-            if evs and ms > 0:
-                tf = fl / (ms * 1e-3) / 1e12
+        for key in ("attn_bwd", "gemm_tn"):
+            if key in probe and probe[key][0] > 0:
+                ms, f = probe[key]
+                tf = f / (ms * 1e-3) / 1e12
                 out["roofline_more"].append({"bound": "mfma", "kernel": names[key], "achieved": tf, "peak": PEAK_BF16_TFLOPS,
-                                             "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "launches_timed": len(evs),
-                                             "avg_launch_ms": ms / len(evs), "flops_per_launch": fl / len(evs)})
+                                             "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
+                                             "launches_timed": a.probe_launches, "avg_launch_ms": ms, "flops_per_launch": f})
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+            shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.is_floating_point()}
+            out["cpu_baseline"] = cpu_baseline(a.workload, shapes)
+        print(json.dumps(out), flush=True)
     if ddp:
         dist.destroy_process_group()
 

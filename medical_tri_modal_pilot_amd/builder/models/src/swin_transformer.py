@@ -16,7 +16,6 @@ the host and cached.  Feature maps whose side is not a multiple of 7 (e.g. --ima
 the reference's zero-padding of windows, which the window kernel does not implement: that case
 raises NotImplementedError.
 """
-import os
 from typing import List
 
 import torch
@@ -27,8 +26,9 @@ from medical_tri_modal_pilot_amd import ops
 WS = 7
 PAD_LOGIT = -30000.0
 
-_SPLIT_TAIL = os.environ.get("MTMP_SWIN_SPLIT_TAIL", "1") != "0"   # A/B switch: stages 3-4 as two half batches on two streams
-_FUSED_MLP = os.environ.get("MTMP_SWIN_MLP", "1") != "0"     # A/B switch: mtmp_swin_mlp for the C = 96 / 192 blocks
+# Both on in the product; tools/dbg A/B scripts flip these module attributes (no environment switches in the package).
+_SPLIT_TAIL = True     # stages 3-4 as two half batches on two streams
+_FUSED_MLP = True      # mtmp_swin_ln_linear / mtmp_swin_mlp for the C = 96 / 192 blocks
 
 
 def _w(p: torch.Tensor, dtype) -> torch.Tensor:

@@ -10,7 +10,6 @@ how the work reaches the GPU:
   * the caller's length tensors are NOT mutated (the reference does ``varying_lengths[n] += 1``
     in place, :704 -- nothing downstream reads them again).
 """
-import os
 import contextlib
 from typing import List, Optional
 
@@ -61,7 +60,7 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
     def _side_streams(self, dev):
         """Two extra HIP streams: the image (54-token) and text (133-token) streams of a layer cannot fill
         256 CUs on their own, so they run beside the 1005-token vital-sign stream."""
-        if not getattr(self, "overlap_streams", True) or dev.type != "cuda" or os.environ.get("MTMP_NO_OVERLAP"):   # (A/B switch)
+        if not getattr(self, "overlap_streams", True) or dev.type != "cuda":
             return None
         key = (dev.type, dev.index)
         if getattr(self, "_streams_key", None) != key:
@@ -133,23 +132,38 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         # fusion layers: one explicit-buffer autograd node (ops.FusionStackFn); the streams carry the
         # bottleneck tokens in rows 0..3 of their own buffer: [bottleneck | CLS | tokens] (:745)
         fl = list(self.layer_stacks)[n_pre:]
-        params, fused, seeds, p = [], [], [], 0.0
         all_fused = iter(type(fl[0][0]).fused_weights_of([layer for layers in fl for layer in layers], dt))
-        for layers in fl:
-            frow, srow = [], []
-            for layer in layers:
-                params += layer.param_list()
-                frow.append(next(all_fused))
-                p, sd = layer.dropout_args()
-                srow.append(sd)
-            fused.append(frow)
-            seeds.append(srow)
-        sinks = [[layer.grad_sink() for layer in layers] for layers in fl] if torch.is_grad_enabled() else None
-        cfg = dict(n_layers=len(fl), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
-                   prebuilt=fused_in,
-                   missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev))
-        out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(streams[0], streams[1], streams[2], self.bottlenecks,
-                                                             *params, cfg)
+        # graph_segments (set by the trainer for staged hipGraph + DDP steps): cut the fusion layers into chained
+        # ops.FusionStackFn nodes at these layer counts; segment_boundaries then holds the three stream buffers
+        # between consecutive nodes (the tensors the staged backward is cut at).
+        cuts = [c for c in (getattr(self, "graph_segments", None) or []) if 0 < c < len(fl)]
+        if cuts and (not fused_in or self.resbottle or not torch.is_grad_enabled()):
+            cuts = []
+        bounds = [0] + sorted(set(cuts)) + [len(fl)]
+        self.segment_boundaries = []
+        zs = (streams[0], streams[1], streams[2])
+        cls_v = None
+        for si in range(len(bounds) - 1):
+            seg = fl[bounds[si]:bounds[si + 1]]
+            final = si == len(bounds) - 2
+            params, fused, seeds, p = [], [], [], 0.0
+            for layers in seg:
+                frow, srow = [], []
+                for layer in layers:
+                    params += layer.param_list()
+                    frow.append(next(all_fused))
+                    p, sd = layer.dropout_args()
+                    srow.append(sd)
+                fused.append(frow)
+                seeds.append(srow)
+            sinks = [[layer.grad_sink() for layer in layers] for layers in seg] if torch.is_grad_enabled() else None
+            cfg = dict(n_layers=len(seg), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
+                       prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True,
+                       missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev))
+            out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(zs[0], zs[1], zs[2], self.bottlenecks, *params, cfg)
+            zs = (out_v, out_i, out_t)
+            if not final:
+                self.segment_boundaries.append(zs)
         nb = self.bottlenecks_n
         self.last_cls = cls_v               # = outs[0][:, 0, :] as its own autograd output (cheap backward)
         if self.vsltonly == 1:

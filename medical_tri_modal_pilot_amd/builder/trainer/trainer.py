@@ -54,6 +54,59 @@ def _use_graph(args, flow_type, device, optimizer, scaler) -> bool:
             and hasattr(optimizer, "flat") and scaler is None)
 
 
+def _stage_bounds(args, enc, ddp: bool):
+    """Layer counts (relative to the first fusion layer) at which the captured step is cut: [0, c1, ..., n_fusion].
+    --graph-stages 0 (default) = 3 stages under DDP, 1 otherwise."""
+    want = int(getattr(args, "graph_stages", 0))
+    if want <= 0:
+        want = 3 if ddp else 1
+    if enc is None or want <= 1 or enc.resbottle or getattr(args, "vslt_type", "TIE") == "QIE":
+        return [0, 0]
+    n_fl = enc.n_layers - min(max(enc.fusion_idx, 0), enc.n_layers)
+    want = min(want, n_fl)
+    if want <= 1:
+        return [0, n_fl]
+    return sorted(set([0, n_fl] + [round(n_fl * k / want) for k in range(1, want)]))
+
+
+def _staged_step(model, enc, optimizer, criterion, run_model, bounds):
+    """The stage callables of graph.GraphedTrainStep for a step cut at ``bounds``: stage 0 = zero_grad, forward, loss
+    and the backward of the head and the LAST group of fusion layers, down to the stream buffers in front of that
+    group (mbt_encoder.py segment_boundaries); stage k = the backward of the next group down; the last stage also
+    runs the input-side backward (stream inputs, projections, TIE embedding)."""
+    n_pre = min(max(enc.fusion_idx, 0), enc.n_layers)
+    n_stage = len(bounds) - 1
+
+    def stage0(t, carry):
+        optimizer.zero_grad()
+        step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
+        carry["loss"] = step_loss.detach()
+        bnds = carry["bnds"] = list(enc.segment_boundaries)
+        if len(bnds) != n_stage - 1:          # the encoder did not cut (torch input chain, resbottle, ...): one backward
+            carry["bnds"] = []
+            step_loss.backward()
+            return
+        prm = model.backward_stage_params(n_pre + bounds[-2], n_pre + bounds[-1], head=True)
+        torch.autograd.backward(step_loss, inputs=list(bnds[-1]) + prm, retain_graph=True)
+
+    def later(k):
+        def stage(t, carry):
+            bnds = carry["bnds"]
+            if not bnds:
+                return
+            j = len(bnds) - k                  # gradients sit on bnds[j]; this stage carries them down to bnds[j-1]
+            src = [z for z in bnds[j] if z.grad is not None]
+            grads = [z.grad for z in src]
+            if j == 0:
+                torch.autograd.backward(src, grads)
+            else:
+                prm = model.backward_stage_params(n_pre + bounds[j], n_pre + bounds[j + 1], head=False)
+                torch.autograd.backward(src, grads, inputs=list(bnds[j - 1]) + prm, retain_graph=True)
+        return stage
+
+    return [stage0] + [later(k) for k in range(1, n_stage)]
+
+
 def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, model, logger, device,
                     scheduler=None, optimizer=None, criterion=None, scaler=None, flow_type=None, output_lengths=None,
                     seq_lengths=None, x_img=None, x_txt=None, txt_lengths=None, imgtxt_time=None, missing=None,
@@ -90,6 +143,9 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
     elif args.input_types == "vslt_img":
         missing_num[missing_num == 1] = 0
         missing_num[missing_num == 3] = 1
+    if missing_num.numel() and (int(missing_num.max()) > 3 or int(missing_num.min()) < 0):
+        # the reference gathers all_bottleneck_stack[missing, idx_order] from FOUR candidates (mbt_encoder.py:768-776)
+        raise IndexError(f"modality pattern id {int(missing_num.max())} is out of bounds for the 4 bottleneck candidates")
     missing_num = missing_num.to(device, non_blocking=True)
     static_x = static_x.permute(1, 0)
     age = static_x[1].float().to(device, non_blocking=True)
@@ -124,24 +180,37 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         from medical_tri_modal_pilot_amd.graph import GraphedTrainStep
         gs = getattr(model, "_mtmp_graph_step", None)
         if gs is None or gs.device != data.device:
-            gs = model._mtmp_graph_step = GraphedTrainStep(data.device)
-
-        if getattr(optimizer, "reducer", None) is not None:
-            optimizer.reducer.overlap = False      # no collective inside the graph: buckets go out in optimizer.step()
-
-        def fwd_bwd(t):
-            optimizer.zero_grad()
-            step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
-            step_loss.backward()
-            return step_loss.detach()
-
-        loss = gs.run(dict(data=data, age=age, gender=gender, input_lengths=input_lengths, x_txt=x_txt,
-                           txt_lengths=txt_lengths, x_img=x_img, missing_num=missing_num, img_time=img_time,
-                           txt_time=txt_time, final_target=final_target, **packed_extra), fwd_bwd, optimizer.flat.params)
+            gs = model._mtmp_graph_step = GraphedTrainStep(data.device,
+                                                           fallback=bool(int(getattr(args, "hip_graph_fallback", 0))))
+        # Data-parallel steps are captured as a few graphs cut at layer boundaries: the all-reduce of the gradient
+        # buckets a stage completed starts right behind its replay and overlaps the next stage (ddp.py, staged mode).
+        enc = getattr(model, "fusion_transformer", None)
+        bounds = _stage_bounds(args, enc, red is not None)
+        if red is not None:
+            red.staged = True
+        if enc is not None:
+            enc.graph_segments = bounds[1:-1]
+        inputs = dict(data=data, age=age, gender=gender, input_lengths=input_lengths, x_txt=x_txt,
+                      txt_lengths=txt_lengths, x_img=x_img, missing_num=missing_num, img_time=img_time,
+                      txt_time=txt_time, final_target=final_target, **packed_extra)
+        if len(bounds) <= 2:
+            def fwd_bwd(t):
+                optimizer.zero_grad()
+                step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
+                step_loss.backward()
+                return step_loss.detach()
+            loss = gs.run(inputs, fwd_bwd, optimizer.flat.params, reducer=red)
+        else:
+            loss = gs.run(inputs, _staged_step(model, enc, optimizer, criterion, run_model, bounds),
+                          optimizer.flat.params, reducer=red)
         optimizer.step()
         scheduler.step(iteration)
         logger.log_lr(scheduler.get_lr()[0], iteration)
     elif flow_type == "train":
+        if red is not None:
+            red.staged = False
+        if getattr(model, "fusion_transformer", None) is not None:
+            model.fusion_transformer.graph_segments = None
         optimizer.zero_grad()
         output = run_model()
         loss = ops.bce_with_logits(criterion, output, final_target)

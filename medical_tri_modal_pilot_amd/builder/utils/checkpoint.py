@@ -7,35 +7,28 @@
 ``model`` needs nothing special -- TRI_MBT_VSLTCLS keeps the reference's 313 keys and shapes.  ``optimizer`` is the
 state_dict of ``torch.optim.AdamW(model.parameters())`` (2_train.py:110): moments indexed by a parameter's position
 in ``model.parameters()``.  ``optim.FusedAdamW`` keeps its moments in flat buffers over ``model.hot_parameters()``
-(a subset, in another order), so the two helpers below translate in both directions; a reference-trained checkpoint
-resumes on the MI355X path and vice versa.
+(a subset, in another order), so FusedAdamW.state_dict() / load_state_dict() translate in both directions when the optimizer knows
+``model.parameters()`` (``reference_params``); the helpers below supply it.  A reference-trained checkpoint resumes on the
+MI355X path and vice versa.
 """
 from typing import Optional
 
 import torch
 
-_ADAMW_GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
-                             fused=None)
+def _with_reference_layout(model, optimizer, fn):
+    old = optimizer.reference_params
+    optimizer.reference_params = list(model.parameters())
+    try:
+        return fn()
+    finally:
+        optimizer.reference_params = old
 
 
 def optimizer_state_as_reference(model: torch.nn.Module, optimizer) -> dict:
     """``optimizer.state_dict()`` in the layout of ``torch.optim.AdamW(model.parameters())``."""
     if not hasattr(optimizer, "flat"):
         return optimizer.state_dict()
-    params = list(model.parameters())
-    pos = {id(p): i for i, p in enumerate(params)}
-    flat, state = optimizer.flat, {}
-    if optimizer.step_count > 0:
-        for j, p in enumerate(flat.params):
-            lo, hi = flat.slice_of(j)
-            state[pos[id(p)]] = {"step": torch.tensor(float(optimizer.step_count)),
-                                 "exp_avg": optimizer.exp_avg[lo:hi].view_as(p).clone(),
-                                 "exp_avg_sq": optimizer.exp_avg_sq[lo:hi].view_as(p).clone()}
-    group = {k: v for k, v in optimizer.param_groups[0].items() if k != "params"}
-    for k, v in _ADAMW_GROUP_DEFAULTS.items():
-        group.setdefault(k, v)
-    group["params"] = list(range(len(params)))
-    return {"state": state, "param_groups": [group]}
+    return _with_reference_layout(model, optimizer, optimizer.state_dict)
 
 
 def load_reference_optimizer_state(model: torch.nn.Module, optimizer, state_dict: dict) -> None:
@@ -44,28 +37,9 @@ def load_reference_optimizer_state(model: torch.nn.Module, optimizer, state_dict
     if not hasattr(optimizer, "flat"):
         optimizer.load_state_dict(state_dict)
         return
-    params = list(model.parameters())
-    flat, steps = optimizer.flat, set()
-    with torch.no_grad():
-        optimizer.exp_avg.zero_()
-        optimizer.exp_avg_sq.zero_()
-        for idx, st in state_dict["state"].items():
-            p = params[int(idx)]
-            j = flat.index_of.get(id(p))
-            if j is None:
-                continue                  # a parameter the hot path never trains (frozen Swin, unused heads)
-            lo, hi = flat.slice_of(j)
-            optimizer.exp_avg[lo:hi].copy_(st["exp_avg"].reshape(-1))
-            optimizer.exp_avg_sq[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
-            steps.add(int(float(st["step"])))
-    if len(steps) > 1:
-        raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): the fused AdamW "
-                         "keeps one step count for its flat buffer")
-    optimizer.step_count = steps.pop() if steps else 0
-    g = state_dict["param_groups"][0]
-    for k in ("lr", "betas", "eps", "weight_decay"):
-        if k in g:
-            optimizer.param_groups[0][k] = g[k]
+    sd = dict(state_dict)
+    sd["mtmp_layout"] = "reference"
+    _with_reference_layout(model, optimizer, lambda: optimizer.load_state_dict(sd))
 
 
 def make_checkpoint(model, optimizer, step, epoch, score, last=None) -> dict:

@@ -126,6 +126,12 @@ _BUILD_FLAGS = [
     (("--hip-graph",), dict(type=int, default=1, choices=[0, 1],
                             help="replay zero_grad+forward+backward of the training step from a captured hipGraph "
                                  "(pays off when the host cannot enqueue ~770 launches per step fast enough)")),
+    (("--hip-graph-fallback",), dict(type=int, default=0, choices=[0, 1],
+                                     help="1: a failed hipGraph capture falls back to eager launches with a warning "
+                                          "(default: it raises -- the eager step is host-bound)")),
+    (("--graph-stages",), dict(type=int, default=0,
+                               help="number of hipGraphs the captured step is cut into at fusion-layer boundaries "
+                                    "(0 = auto: 3 under --ddp 1 so that the gradient all-reduce overlaps backward, else 1)")),
     (("--n-images",), dict(type=int, default=3, help="images per sample when --multiimages 1 (reference: 3)")),
     (("--synthetic",), dict(type=int, default=0, choices=[0, 1], help="train on synthetic batches (SURVEY.md §8d)")),
 ]

@@ -598,7 +598,9 @@ template <typename T> struct ExchangeArgs {
 
 template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel(ExchangeArgs<T> p) {
     const int b = blockIdx.x >> 2, r = blockIdx.x & 3, f = threadIdx.x;
-    const long long pat = p.missing[b];
+    // ids outside 0..3 raise IndexError on the host (trainer.py, like the reference's gather); clamped here so that a
+    // caller that skipped the check still cannot read outside the table
+    const long long pat = min(max(p.missing[b], 0LL), 3LL);
     const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
     float v = __fmul_rn(to_f32(p.z[0][b * p.bstride[0] + o]), kExchangeW[pat][0]);
     v = __fadd_rn(v, __fmul_rn(to_f32(p.z[1][b * p.bstride[1] + o]), kExchangeW[pat][1]));
@@ -615,7 +617,7 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel
 // rows 0..3 of z[m] become d_new * w[m] = gradient w.r.t. stream m's own bottleneck outputs.
 template <typename T> __global__ __launch_bounds__(256) void exchange_bwd_kernel(ExchangeArgs<T> p) {
     const int b = blockIdx.x >> 2, r = blockIdx.x & 3, f = threadIdx.x;
-    const long long pat = p.missing[b];
+    const long long pat = min(max(p.missing[b], 0LL), 3LL);
     const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
     float d = to_f32(p.z[0][b * p.bstride[0] + o]);
     d = __fadd_rn(d, to_f32(p.z[1][b * p.bstride[1] + o]));

@@ -5,13 +5,28 @@ collective is the gradient all-reduce -- 12,121,601 fp32 values (48.5 MB) at 6 l
 Design for xGMI (point-to-point links, ring collectives are per-link bound): few large
 contiguous buckets cut from the flat gradient buffer of optim.FlatParams in REVERSE parameter
 order (head -> last layer ... first layer -> embeddings = the order backward produces them).
-A bucket's all-reduce is launched as soon as every parameter in it has accumulated its gradient
-(post-accumulate-grad hooks), on a side HIP stream that waits on an event recorded on the
-compute stream, so RCCL traffic overlaps the rest of backward; ``wait()`` (called by
-FusedAdamW.step) joins the side stream.  Sums are left un-averaged: the 1/world factor is folded
-into the AdamW kernel's ``grad_scale``.  BatchNorm statistics stay per-rank (standard DDP).
+A bucket's all-reduce runs on a side HIP stream, beside the rest of the backward; ``wait()``
+(called by FusedAdamW.step) joins the side stream.  Sums are left un-averaged: the 1/world factor
+is folded into the AdamW kernel's ``grad_scale``.  BatchNorm statistics stay per-rank (standard DDP).
+
+Two ways a bucket gets launched:
+  * hook mode (eager steps): as soon as every parameter of the bucket has its gradient
+    (post-accumulate-grad hooks, or optim.FlatParams.mark_ready for gradients the backward kernels
+    write straight into the flat buffer).  The side stream then waits for EVERYTHING enqueued so far
+    on the stream the hook fired on, on the step's main compute stream and on the model's modality
+    side streams: a bucket is completed by its last slice, but its other slices may have been
+    written from another stream.
+  * staged mode (hipGraph replays: no Python runs inside a replay): the step is captured as a few
+    graphs cut at layer boundaries (graph.GraphedTrainStep stages); while a stage is captured (or
+    run eagerly) the hooks only LOG which buckets became complete, and the trainer calls
+    ``launch(ids, after=stream)`` right after enqueuing that stage's replay -- the all-reduce of the
+    finished buckets then overlaps the next stage's backward.
+
+Gradient accumulation: wrap every backward but the last of a step in ``no_sync()``; a gradient that
+arrives for a bucket already reduced raises instead of being silently left un-reduced.
 """
-from typing import List, Optional
+import contextlib
+from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -27,14 +42,14 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
 
 
 class GradReducer:
-    def __init__(self, flat: FlatParams, bucket_bytes: int = 12 << 20, group=None, overlap: bool = True):
+    def __init__(self, flat: FlatParams, bucket_bytes: int = 8 << 20, group=None, overlap: bool = True):
         self.flat, self.group, self.overlap = flat, group, overlap
         self.world = dist.get_world_size(group)
         self.cuda = flat.grad.is_cuda
         self.side = torch.cuda.Stream(device=flat.grad.device) if self.cuda else None
-        # other streams gradients are produced on (the encoder's modality side streams): a bucket's all-reduce waits
-        # for everything enqueued on them too -- the slice that completed the bucket says nothing about its
-        # neighbours written from another stream
+        self.staged = False                      # staged mode (see module docstring): hooks log, launch() launches
+        self.main_stream: Optional["torch.cuda.Stream"] = None     # the step's compute stream (set by begin_step)
+        # other streams gradients are produced on (the encoder's modality side streams)
         self.extra_streams: List["torch.cuda.Stream"] = []
         # buckets: contiguous [lo, hi) element ranges, built from the END of the flat buffer
         self.buckets: List[List[int]] = []       # [lo, hi, n_params]
@@ -48,39 +63,85 @@ class GradReducer:
             if (hi - cur_lo) * 4 >= bucket_bytes or i == 0:
                 self.buckets.append([cur_lo, hi, cur_n])
                 hi, cur_n = cur_lo, 0
-        self.pending = [b[2] for b in self.buckets]
-        self.launched = [False] * len(self.buckets)
         self.works = []
+        self._sync = True
+        self._reset()
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
         flat.ready_cb = self._ready          # gradients written straight into the flat buffer (ops.GradSink)
+        flat.zero_cb = self.begin_step       # zero_grad() opens a step
+
+    def _reset(self):
+        self.pending = [b[2] for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.ready_log: List[int] = []           # buckets in the order they became complete this step
+
+    def begin_step(self):
+        """Called by FlatParams.zero_grad(): a new accumulation starts; the stream it is called on is the
+        step's main compute stream."""
+        if any(self.launched) or self.works:
+            raise RuntimeError("GradReducer: zero_grad() while all-reduces of the previous step are in flight "
+                               "(optimizer.step() / reducer.wait() was not called)")
+        self._reset()
+        if self.cuda:
+            self.main_stream = torch.cuda.current_stream(self.flat.grad.device)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backwards inside this context neither count towards bucket completion nor
+        launch anything (DistributedDataParallel.no_sync semantics); the LAST backward of the step runs outside."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
 
     def _ready(self, i: int):
+        if not self._sync:
+            return
         b = self.bucket_of[i]
+        if self.launched[b]:
+            raise RuntimeError(f"GradReducer: a gradient for '{self.flat.names[i]}' arrived after its bucket was "
+                               "all-reduced -- with gradient accumulation wrap every backward but the last in no_sync()")
         self.pending[b] -= 1
-        if self.pending[b] == 0 and self.overlap:
-            self._launch(b)
+        if self.pending[b] == 0:
+            self.ready_log.append(b)
+            if self.overlap and not self.staged:
+                self._launch(b)
 
     def _make_hook(self, i: int):
         def hook(_param):
             self._ready(i)
         return hook
 
-    def _launch(self, b: int):
+    def take_ready(self) -> List[int]:
+        """Buckets that became complete since the last call (staged mode: the trainer asks after each stage)."""
+        out, self.ready_log = self.ready_log, []
+        return out
+
+    def _launch(self, b: int, after: Optional[Iterable["torch.cuda.Stream"]] = None):
         if self.launched[b]:
             return
         self.launched[b] = True
         lo, hi, _ = self.buckets[b]
         buf = self.flat.grad[lo:hi]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.side.wait_event(ev)
-            for s in self.extra_streams:
-                self.side.wait_stream(s)
+            dev = self.flat.grad.device
+            seen = set()
+            for s in ([torch.cuda.current_stream(dev), self.main_stream] + list(self.extra_streams) + list(after or [])):
+                if s is not None and s.cuda_stream not in seen:
+                    seen.add(s.cuda_stream)
+                    self.side.wait_stream(s)
             with torch.cuda.stream(self.side):
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def launch(self, bucket_ids: Iterable[int], after=None):
+        """Staged mode: all-reduce these buckets now, behind everything enqueued on the stream(s) ``after``."""
+        if after is not None and not isinstance(after, (list, tuple)):
+            after = [after]
+        for b in bucket_ids:
+            self._launch(b, after)
 
     def wait(self):
         """Launch whatever has not been launched (parameters without a gradient this step keep their
@@ -90,11 +151,12 @@ class GradReducer:
         for w in self.works:
             w.wait()
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.side)
+            torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.side)
         self.works = []
-        self.pending = [b[2] for b in self.buckets]
-        self.launched = [False] * len(self.buckets)
+        self._reset()
 
     def remove(self):
         for h in self._hooks:
             h.remove()
+        self.flat.ready_cb = None
+        self.flat.zero_cb = None

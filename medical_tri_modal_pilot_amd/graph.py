@@ -16,30 +16,37 @@ scalars that change every step), the scheduler, and loss.item().
 Anything that would make a replay differ from an eager step is keyed or refused:
   * one graph per input signature (names, shapes, dtypes); at most ``max_graphs`` live (LRU);
   * the first ``warmup`` calls of a signature run eagerly (lazy initialisation must not be captured);
-  * a failed capture disables graphs for this object and the step runs eagerly (never silently wrong:
-    capture either succeeds completely or the eager path is used).
+  * a failed capture RAISES (the eager step is host-bound: 12 ms of enqueue for 10 ms of GPU work at config 2, so
+    silently reporting it as the product would be wrong); ``fallback=True`` (--hip-graph-fallback 1) turns the failure
+    into a warning and eager launches, and ``self.disabled`` / ``self.captures`` / ``self.replays`` say which ran.
+
+Staged steps (data-parallel training): ``fn`` may be a LIST of stage callables ``stage(inputs, carry)``.  Each stage is
+captured in its own graph (one shared memory pool, always replayed in order); ``carry`` hands tensors from one stage to
+the next at capture time (stage 0 = zero_grad + forward + loss + backward of the last layers, stage k = backward of the
+next group of layers down from the tensors stage k-1 left gradients on).  After a stage's replay has been enqueued,
+``reducer.launch()`` starts the all-reduce of the gradient buckets that stage completed (recorded while the stage was
+captured) on RCCL's side stream, beside the next stage's kernels -- no collective inside any graph.
 """
-import os
 import warnings
 from collections import OrderedDict
-from typing import Callable, Dict
+from typing import Callable, Dict, List, Union
 
 import torch
 
 from . import ops
 
 _GOLDEN = 0x9E3779B1          # odd increment of the step word
-_SYNC_AFTER_REPLAY = os.environ.get("MTMP_GRAPH_SYNC", "") != ""        # diagnostics: host-wait after every replay
 
 
 class GraphedTrainStep:
-    def __init__(self, device: torch.device, max_graphs: int = 8, warmup: int = 1):
+    def __init__(self, device: torch.device, max_graphs: int = 8, warmup: int = 1, fallback: bool = False):
         if device.type != "cuda":
             raise RuntimeError("hipGraph capture needs a GPU device")
         self.device = device
-        self.max_graphs, self.warmup = max_graphs, warmup
+        self.max_graphs, self.warmup, self.fallback = max_graphs, warmup, fallback
         self.entries: "OrderedDict[tuple, dict]" = OrderedDict()
         self.disabled = False
+        self.sync_after_replay = False       # diagnostics (tools/dbg): host-wait after every replay
         self.seed_word = torch.full((1,), torch.initial_seed() & 0x7FFFFFFF, dtype=torch.int64, device=device)
         ops.set_seed_word(self.seed_word)
         # Warm-up steps and the capture run on ONE dedicated stream: autograd's AccumulateGrad nodes remember the
@@ -57,58 +64,79 @@ class GraphedTrainStep:
         """Drop every captured graph (call after load_state_dict / any change of module structure or flags)."""
         self.entries.clear()
 
-    def _capture(self, ent: dict, inputs: Dict[str, torch.Tensor], fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
-                 params):
+    @staticmethod
+    def _stages(fn) -> List[Callable]:
+        if isinstance(fn, (list, tuple)):
+            return list(fn)
+        return [lambda inputs, carry: carry.__setitem__("loss", fn(inputs))]
+
+    def _capture(self, ent: dict, inputs: Dict[str, torch.Tensor], stages: List[Callable], reducer):
         static = {k: v.detach().clone() for k, v in inputs.items()}
         ops.bump_fused_epoch()      # per-layer derived weights (W2^T, casts) must be re-made INSIDE the graph
-        g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(self.device)
-        # thread_local: other threads (autograd workers, the RCCL watchdog) may keep making HIP calls during capture
-        with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
-            self.seed_word.add_(_GOLDEN)
-            loss = fn(static)
-        if self.pool is None:
-            self.pool = g.pool()
-        ent.update(graph=g, static=static, loss=loss, fresh=True)
+        graphs, ready, carry = [], [], {}
+        for i, stage in enumerate(stages):
+            g = torch.cuda.CUDAGraph()
+            # thread_local: other threads (autograd workers, the RCCL watchdog) may keep making HIP calls during capture
+            with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
+                if i == 0:
+                    self.seed_word.add_(_GOLDEN)
+                stage(static, carry)
+            if self.pool is None:
+                self.pool = g.pool()
+            graphs.append(g)
+            # which gradient buckets this stage completed (the hooks ran while its Python was captured)
+            ready.append(reducer.take_ready() if reducer is not None else [])
+        ent.update(graphs=graphs, ready=ready, static=static, loss=carry["loss"], fresh=True)
         self.captures += 1
 
-    def _eager_on_side_stream(self, inputs, fn):
+    def _eager_on_side_stream(self, inputs, stages, reducer):
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        carry = {}
         with torch.cuda.stream(self.stream):
             self.seed_word.add_(_GOLDEN)
-            loss = fn(inputs)
+            for stage in stages:
+                stage(inputs, carry)
+                if reducer is not None and reducer.staged:
+                    reducer.launch(reducer.take_ready(), after=self.stream)
         cur.wait_stream(self.stream)
         for v in inputs.values():
             v.record_stream(self.stream)
-        return loss
+        return carry["loss"]
 
-    def run(self, inputs: Dict[str, torch.Tensor], fn: Callable[[Dict[str, torch.Tensor]], torch.Tensor],
-            params=None) -> torch.Tensor:
-        """fn(inputs) -> scalar loss tensor; must do zero_grad + forward + backward with no host sync.
-        Returns the loss tensor of this step (a static buffer when replayed)."""
+    def run(self, inputs: Dict[str, torch.Tensor], fn: Union[Callable, List[Callable]], params=None,
+            reducer=None) -> torch.Tensor:
+        """fn(inputs) -> scalar loss tensor (zero_grad + forward + backward with no host sync), or a list of stage
+        callables stage(inputs, carry) of which one stores carry["loss"] (see the module docstring).
+        reducer: ddp.GradReducer in staged mode, or None.  Returns the loss tensor of this step (a static buffer when
+        replayed)."""
+        stages = self._stages(fn)
         if self.disabled:
-            return fn(inputs)
-        key = self.signature(inputs)
+            return self._eager_on_side_stream(inputs, stages, reducer)
+        key = self.signature(inputs) + (len(stages),)
         ent = self.entries.get(key)
         if ent is None:
             ent = self.entries[key] = {"seen": 0}
             while len(self.entries) > self.max_graphs:
                 self.entries.popitem(last=False)
         self.entries.move_to_end(key)
-        if "graph" not in ent:
+        if "graphs" not in ent:
             if ent["seen"] < self.warmup:
                 ent["seen"] += 1
-                return self._eager_on_side_stream(inputs, fn)
+                return self._eager_on_side_stream(inputs, stages, reducer)
             try:
-                self._capture(ent, inputs, fn, params)
-            except Exception as e:                      # noqa: BLE001 -- any capture failure -> eager
-                self.disabled = True
+                self._capture(ent, inputs, stages, reducer)
+            except Exception as e:                      # noqa: BLE001
                 self.entries.clear()
                 torch.cuda.synchronize(self.device)
+                if not self.fallback:
+                    raise RuntimeError("hipGraph capture of the training step failed; run with --hip-graph 0 (eager "
+                                       "launches, host-bound) or --hip-graph-fallback 1 to continue eagerly") from e
+                self.disabled = True
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
-                              "continuing with eager launches")
-                return fn(inputs)
+                              "continuing with eager launches (--hip-graph-fallback 1)")
+                return self._eager_on_side_stream(inputs, stages, reducer)
         cur = torch.cuda.current_stream(self.device)
         fresh = ent.pop("fresh", False)
         self.stream.wait_stream(cur)
@@ -127,15 +155,18 @@ class GraphedTrainStep:
                     v.record_stream(self.stream)
                 if dst:
                     torch._foreach_copy_(dst, src)
-            ent["graph"].replay()
+            for g, ids in zip(ent["graphs"], ent["ready"]):
+                g.replay()
+                if reducer is not None and ids:
+                    reducer.launch(ids, after=self.stream)     # this stage's finished buckets, beside the next stage
         cur.wait_stream(self.stream)
         # Why not simply graph.replay() on the caller's stream: measured on ROCm 7.2 / torch 2.10 (bench.py, one-stream
         # graph, --warmup 10), a graph launched on the DEFAULT stream let work enqueued on that stream right after
         # hipGraphLaunch (the AdamW kernel) overtake the graph's tail -- the loss went NaN within ~15 steps.  Launched
         # on the capture stream and joined by events as above, 60 replayed steps are bit-identical to eager ones in
-        # every stream configuration.  MTMP_GRAPH_SYNC=1 additionally host-waits for each replay (diagnostics; costs
+        # every stream configuration.  sync_after_replay additionally host-waits for each replay (diagnostics; costs
         # ~0.7 ms/step because the next step's host work no longer overlaps the GPU).
-        if _SYNC_AFTER_REPLAY:
+        if self.sync_after_replay:
             self.stream.synchronize()
         self.replays += 1
         return ent["loss"]

@@ -690,6 +690,14 @@ class FusionStackFn(torch.autograd.Function):
     apply(xv, xi, xt, bottlenecks, *layer_params, cfg) -> (out_v, out_i, out_t, cls_v); cfg is a dict:
       n_layers, vsltonly, resbottle, kv (list of int32[B] | None per stream, bottleneck prefix
       included), missing (int64[B]), drop_p, seeds[l][m], fused[l][m], dtype, side_streams
+      final (default True): this node holds the LAST fusion layers.  The stack may be cut into several chained nodes
+        (mbt_encoder.py ``graph_segments``; needs prebuilt inputs and resbottle off): a non-final node ends with a
+        bottleneck exchange like every inner layer, returns no CLS vector, and its three output buffers are the next
+        node's prebuilt inputs -- the trainer captures the backward of each node in its own hipGraph so that the
+        gradient all-reduce of the later layers overlaps the backward of the earlier ones (ddp.GradReducer, staged mode).
+      bott_rows_unused: the caller never reads rows 0..3 of the outputs (mbt_encoder.py slices them off), so with
+        vsltonly == 0 and no gradient for the image / text outputs the last layer's image / text blocks get no
+        backward at all (in the reference their gradient is None, not zero).
     """
 
     @staticmethod
@@ -697,6 +705,9 @@ class FusionStackFn(torch.autograd.Function):
         cfg = rest[-1]
         params = rest[:-1]
         L, dt = cfg["n_layers"], cfg["dtype"]
+        final = cfg.get("final", True)
+        if not final and (not cfg.get("prebuilt") or cfg["resbottle"]):
+            raise ValueError("a non-final FusionStackFn segment needs prebuilt inputs and resbottle off")
         xs = [xv, xi, xt]
         _gpu(xv)
         B, dev = xv.shape[0], xv.device
@@ -717,7 +728,7 @@ class FusionStackFn(torch.autograd.Function):
         saved, active = [], []
         prev_bott = bott.expand(B, -1, -1).float().contiguous() if cfg["resbottle"] else None
         for li in range(L):
-            last = cfg["vsltonly"] == 1 and li == L - 1
+            last = final and cfg["vsltonly"] == 1 and li == L - 1
             ms = [0] if last else [0, 1, 2]
             outs = [None, None, None]
             row = [None, None, None]
@@ -760,7 +771,7 @@ class FusionStackFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         outs_full = [z[m] if z[m] is not None else torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) for m in range(3)]
         ctx.mark_non_differentiable(*[o for m, o in enumerate(outs_full) if z[m] is None])
-        cls_v = outs_full[0][:, NB, :].clone()
+        cls_v = outs_full[0][:, NB, :].clone() if final else None
         return outs_full[0], outs_full[1], outs_full[2], cls_v
 
     @staticmethod
@@ -772,6 +783,16 @@ class FusionStackFn(torch.autograd.Function):
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
         n_run = len(saved)
+        final = cfg.get("final", True)
+        # vsltonly == 0: the last layer ran all three streams, but when nothing downstream read the image / text outputs
+        # (and nobody reads the exchanged bottleneck rows) their blocks have no gradient: run the backward of the last
+        # layer like the vslt-only one (the reference's autograd never reaches those blocks either)
+        if (final and cfg["vsltonly"] != 1 and d_i is None and d_t is None and cfg.get("bott_rows_unused")
+                and not cfg["resbottle"] and len(active[-1]) == 3):
+            active = active[:-1] + [[0]]
+            skip_last_exchange = True
+        else:
+            skip_last_exchange = False
         # gradient w.r.t. the last executed layer's outputs
         dz = [None, None, None]
         for m, g in enumerate((d_v, d_i, d_t)):
@@ -783,7 +804,7 @@ class FusionStackFn(torch.autograd.Function):
         d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
         for li in range(n_run - 1, -1, -1):
             ms = active[li]
-            if not (cfg["vsltonly"] == 1 and li == L - 1):
+            if not ((final and cfg["vsltonly"] == 1 and li == L - 1) or (skip_last_exchange and li == n_run - 1)):
                 # this layer's outputs went through an exchange before feeding layer li+1: rows 0..3 of the three
                 # gradient buffers are summed and redistributed by the exchange weights, in place (one kernel)
                 d_out_prev = torch.empty(B, NB, D_MODEL, dtype=torch.float32, device=dev) if cfg["resbottle"] else None

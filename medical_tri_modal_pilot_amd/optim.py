@@ -37,7 +37,9 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.index_of = {id(p): i for i, p in enumerate(self.params)}
         self.written = set()          # parameter indices whose gradient slice was written directly since zero_grad
+        self.accumulated = set()      # parameter indices autograd has accumulated into since zero_grad
         self.ready_cb = None          # ddp.GradReducer: called with an index when a slice was written directly
+        self.zero_cb = None           # ddp.GradReducer: called by zero_grad() (a new accumulation starts)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.data[o:o + p.numel()].view_as(p)
@@ -45,6 +47,14 @@ class FlatParams:
                 p.data = view
                 p._mtmp_flat = self
         self.attach_grads()
+        # a kernel may only OVERWRITE a gradient slice nothing has been accumulated into since zero_grad() (claim)
+        self._acc_hooks = [p.register_post_accumulate_grad_hook(self._note_accumulated(i))
+                           for i, p in enumerate(self.params)]
+
+    def _note_accumulated(self, i: int):
+        def hook(_param):
+            self.accumulated.add(i)
+        return hook
 
     def attach_grads(self):
         """(Re)point every p.grad at its slice of the flat gradient buffer."""
@@ -54,8 +64,11 @@ class FlatParams:
                 p.grad = g
 
     def zero_grad(self):
+        if self.zero_cb is not None:
+            self.zero_cb()
         self.grad.zero_()
         self.written.clear()
+        self.accumulated.clear()
         self.attach_grads()
 
     # ---- direct writes by the backward kernels (ops.GradSink) ----
@@ -64,7 +77,8 @@ class FlatParams:
         still the flat view (then a kernel may overwrite them); False -> caller returns gradients normally."""
         for i in idx:
             p = self.params[i]
-            if i in self.written or p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[i]:
+            if (i in self.written or i in self.accumulated or p.grad is None
+                    or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[i]):
                 return False
         self.written.update(idx)
         return True
@@ -126,7 +140,10 @@ class FusedAdamW(torch.optim.Optimizer):
     over FlatParams, one HIP launch per step.  ``lr`` is read from ``param_groups[0]['lr']`` so the
     reference's CosineAnnealingWarmupRestarts drives it unchanged."""
 
-    def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, named_params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, reference_params=None):
+        """reference_params: ``list(model.parameters())`` -- when given, state_dict() / load_state_dict() speak the
+        layout of ``torch.optim.AdamW(model.parameters())`` (2_train.py:110), so the reference's unchanged
+        ``Logger.save`` / resume code (logger.py:167, 2_train.py:98) round-trips the moments."""
         named_params = list(named_params)
         if named_params and not isinstance(named_params[0], (tuple, list)):
             named_params = [(f"p{i}", p) for i, p in enumerate(named_params)]
@@ -138,6 +155,67 @@ class FusedAdamW(torch.optim.Optimizer):
         self.step_count = 0
         self.reducer = None            # ddp.GradReducer, attached by the training script
         self.grad_scale = 1.0
+        self.reference_params = None if reference_params is None else list(reference_params)
+
+    # ---- checkpoints (logger.py:166-177 calls optimizer.state_dict(); 2_train.py:98 optimizer.load_state_dict()) ----
+    def _positions(self, layout: str):
+        """(position of every flat parameter in the state_dict's numbering, number of entries)."""
+        if layout == "reference":
+            if self.reference_params is None:
+                raise ValueError("this optimizer state is indexed by model.parameters(): construct FusedAdamW with "
+                                 "reference_params=list(model.parameters()) to load it")
+            pos = {id(p): i for i, p in enumerate(self.reference_params)}
+            return [pos[id(p)] for p in self.flat.params], len(self.reference_params)
+        return list(range(len(self.flat.params))), len(self.flat.params)
+
+    def state_dict(self):
+        """The moments and the step count in torch.optim.AdamW's state_dict format: indexed like
+        ``torch.optim.AdamW(model.parameters())`` when ``reference_params`` was given (parameters the hot path never
+        trains have no entry, like parameters that never received a gradient in the reference), else by flat order."""
+        layout = "reference" if self.reference_params is not None else "flat"
+        posn, n = self._positions(layout)
+        state = {}
+        if self.step_count > 0:
+            for j, p in enumerate(self.flat.params):
+                lo, hi = self.flat.slice_of(j)
+                state[posn[j]] = {"step": torch.tensor(float(self.step_count)),
+                                  "exp_avg": self.exp_avg[lo:hi].view_as(p).clone(),
+                                  "exp_avg_sq": self.exp_avg_sq[lo:hi].view_as(p).clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        for k, v in dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                         fused=None).items():
+            group.setdefault(k, v)
+        group["params"] = list(range(n))
+        return {"state": state, "param_groups": [group], "mtmp_layout": layout}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        layout = state_dict.get("mtmp_layout")
+        if layout is None:         # written by torch.optim.AdamW itself (a reference-trained checkpoint)
+            layout = "reference" if self.reference_params is not None else "flat"
+        posn, n = self._positions(layout)
+        g = state_dict["param_groups"][0]
+        if len(g["params"]) != n:
+            raise ValueError(f"optimizer state has {len(g['params'])} parameters, expected {n} ({layout} layout)")
+        where = {q: j for j, q in enumerate(posn)}
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for idx, st in state_dict["state"].items():
+            j = where.get(int(idx))
+            if j is None:
+                continue               # a parameter the hot path never trains (frozen Swin, unused heads)
+            lo, hi = self.flat.slice_of(j)
+            self.exp_avg[lo:hi].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): the fused AdamW "
+                             "keeps one step count for its flat buffer")
+        self.step_count = steps.pop() if steps else 0
+        for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+            if k in g:
+                self.param_groups[0][k] = g[k]
 
     def zero_grad(self, set_to_none: bool = True):
         self.flat.zero_grad()

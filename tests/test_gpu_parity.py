@@ -800,12 +800,12 @@ def test_full_training_step_bf16_tolerance(ops):
 
 
 # ------------------------------------------------------------------ hipGraph replay of the step
-def _loop(hip_graph, dropout, dtype, n_steps, lens_per_step, L=2, B=4, T=96):
+def _loop(hip_graph, dropout, dtype, n_steps, lens_per_step, L=2, B=4, T=96, **over):
     from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
     from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     torch.manual_seed(7)
-    args, model = _product_model(L, 0, dtype, hip_graph=hip_graph, dropout=dropout)
+    args, model = _product_model(L, 0, dtype, hip_graph=hip_graph, dropout=dropout, **over)
     model.train()
     model.img_encoder.eval()
     opt = FusedAdamW(model.hot_parameters(), lr=1e-4, weight_decay=args.weight_decay)
@@ -838,6 +838,72 @@ def test_graph_replay_equals_eager_steps(ops):
     assert le == lg, (le, lg)
     assert torch.equal(pe, pg)
     REPORT["graph_vs_eager[fp32].5_steps"] = {"rel_err": 0.0, "tol": 0.0}
+
+
+@pytest.mark.parametrize("vsltonly", [0, 1])
+def test_staged_graphs_equal_single_graph(ops, vsltonly):
+    """--graph-stages 3 (what data-parallel steps use so that bucket all-reduces overlap the backward): the fusion
+    stack is cut into three chained autograd nodes and the step into three hipGraphs replayed back to back.  Same
+    kernels, same order -> losses and parameters bit-identical to the one-graph step, and to eager."""
+    full = [[96, 96, 50, 7]] * 5
+    le, pe, _ = _loop(0, 0.0, "fp32", 5, full, L=4, mbt_only_vslt=vsltonly)
+    l1, p1, g1 = _loop(1, 0.0, "fp32", 5, full, L=4, mbt_only_vslt=vsltonly, graph_stages=1)
+    l3, p3, g3 = _loop(1, 0.0, "fp32", 5, full, L=4, mbt_only_vslt=vsltonly, graph_stages=3)
+    assert g3.captures == 1 and g3.replays == 4 and not g3.disabled
+    assert [len(e["graphs"]) for e in g3.entries.values()] == [3] and [len(e["graphs"]) for e in g1.entries.values()] == [1]
+    assert le == l1 == l3, (le, l1, l3)
+    assert torch.equal(pe, p1) and torch.equal(p1, p3)
+    REPORT[f"staged_graphs_vs_single[fp32,vsltonly={vsltonly}].5_steps"] = {"rel_err": 0.0, "tol": 0.0}
+
+
+def test_vsltonly0_training_step_vs_oracle(ops):
+    """--mbt-only-vslt 0 (the flag's default): the last layer's image / text blocks run forward but nothing reads their
+    outputs (tri_mbt_vsltcls.py:248), so the reference leaves their gradient None.  The product gives them no backward
+    and keeps them out of AdamW; loss, second-step loss and every other gradient follow the CPU oracle."""
+    from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    L = 2
+    args, model = _product_model(L, 0, "fp32", hip_graph=0, mbt_only_vslt=0)
+    model.train()
+    model.img_encoder.eval()
+    hot = dict(model.hot_parameters())
+    assert not any(n.startswith((f"fusion_transformer.layer_stacks.{L - 1}.1.", f"fusion_transformer.layer_stacks.{L - 1}.2."))
+                   for n in hot)
+    opt = FusedAdamW(list(hot.items()), lr=args.lr_init, weight_decay=args.weight_decay)
+    sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=args.t_0 * 10, cycle_mult=args.t_mult,
+                                          max_lr=args.lr_init * math.sqrt(args.batch_size), min_lr=1e-6,
+                                          warmup_steps=args.t_up * 10, gamma=args.gamma)
+    bt = filler.make_batch(4321, 4, 40)
+    static = torch.stack([bt["gen"], bt["age"]], 1)
+    kw = dict(args=args, x=bt["x"], static=static, y=bt["y"], output_lengths=None, model=model, logger=_Logger(),
+              device=torch.device(DEV), scheduler=sched, optimizer=opt, criterion=torch.nn.BCEWithLogitsLoss(),
+              x_txt=bt["txt"], x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None,
+              missing=bt["missing"], reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    _, loss1 = get_trainer(iteration=1, input_lengths=bt["input_lengths"].clone(), txt_lengths=bt["txt_lengths"].clone(),
+                           flow_type="train", **kw)
+    grads = {n: p.grad.detach().clone() for n, p in hot.items()}
+    _, loss2 = get_trainer(iteration=2, input_lengths=bt["input_lengths"].clone(), txt_lengths=bt["txt_lengths"].clone(),
+                           flow_type="train", **kw)
+    tr = O.OracleTrainer(_model_sd(L), O.Cfg(n_layers=L, vsltonly=0), lr_init=args.lr_init, batch_size=args.batch_size,
+                         iters_per_epoch=10)
+    ref1 = tr.step(bt, 1)
+    ref_grads = {k: v.clone() for k, v in tr.grads.items()}
+    ref2 = tr.step(bt, 2)
+    assert abs(loss1 - ref1) < 1e-4 and abs(loss2 - ref2) < 1e-4, (loss1, ref1, loss2, ref2)
+    assert sorted(ref_grads) == sorted(hot), set(ref_grads) ^ set(hot)        # the oracle's autograd reaches the same set
+    med = float(np.median([float(v.norm()) for v in ref_grads.values()]))
+    worst = 0.0
+    for n, g in ref_grads.items():
+        if float(g.norm()) < 1e-4 * med:
+            continue
+        worst = max(worst, _rel(grads[n], g))
+    REPORT["vsltonly0_step[fp32].worst_grad"] = {"rel_err": worst, "tol": 1e-4}
+    assert worst < 1e-4
+    for n, p in model.named_parameters():          # untouched: the skipped blocks (no weight decay either) and the frozen Swin
+        if n not in hot:
+            assert torch.equal(p.detach(), before[n]), n
 
 
 def test_cfg1_sample_data_windows_product_vs_oracle(ops):

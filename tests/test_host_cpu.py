@@ -225,9 +225,116 @@ for step in range(2):
 gathered = [torch.zeros_like(flat.grad) for _ in range(world)]
 dist.all_gather(gathered, flat.grad)
 assert all(torch.equal(gathered[0], t) for t in gathered)       # every rank holds the same reduced buffer
+
+# ---- staged mode (what hipGraph replays use): hooks only LOG, launch() is called between the stages of a step that
+# is cut at an activation (here: after the first Linear), and the result equals the hook-mode result
+def expected():
+    exp = [torch.zeros_like(p) for p in ref]
+    for r in range(world):
+        m = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8), torch.nn.Linear(8, 1))
+        with torch.no_grad():
+            for q, s in zip(m.parameters(), ref):
+                q.copy_(s)
+        m(xs[r]).pow(2).mean().backward()
+        for e, q in zip(exp, m.parameters()):
+            e += q.grad
+    return exp
+with torch.no_grad():
+    for q, s in zip(net.parameters(), ref):
+        q.copy_(s)
+red.remove()
+flat = FlatParams(net.named_parameters())            # only parameters that do get gradients (the product's hot set)
+red = GradReducer(flat, bucket_bytes=1024)
+red.staged = True
+flat.zero_grad()
+h = net[1](net[0](xs[rank]))
+loss = net[3](net[2](h)).pow(2).mean()
+later = [p for n, p in net.named_parameters() if n.startswith(("2.", "3."))]
+torch.autograd.backward(loss, inputs=[h] + later, retain_graph=True)          # stage 0: down to h
+assert not red.works                                                            # nothing went out by itself
+first = red.take_ready()
+assert first and all(red.buckets[b][0] >= flat.offsets[flat.index_of[id(net[2].weight)]] for b in first)
+red.launch(first)
+torch.autograd.backward([h], [h.grad])                                          # stage 1: the rest
+red.launch(red.take_ready())
+red.wait()
+for p, e in zip(net.parameters(), expected()):
+    assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6), rank
+red.staged = False
+
+# ---- gradient accumulation: no_sync() for every backward but the last; a late gradient raises
+flat.zero_grad()
+with red.no_sync():
+    net(xs[rank]).pow(2).mean().backward()
+net(xs[rank]).pow(2).mean().backward()
+red.wait()
+for p, e in zip(net.parameters(), expected()):
+    assert torch.allclose(p.grad, 2 * e, rtol=1e-5, atol=1e-6), rank
+flat.zero_grad()
+net(xs[rank]).pow(2).mean().backward()
+try:
+    net(xs[rank]).pow(2).mean().backward()          # second backward without no_sync: its buckets are already in flight
+    raise SystemExit("late gradient was accepted")
+except RuntimeError as e:
+    assert "no_sync" in str(e), e
+red.wait()
 dist.destroy_process_group()
 print("OK", rank)
 """
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts two ranks as children of a GPU-free parent
+    (torch.distributed.run on 127.0.0.1) and relays rank 0's JSON line; --dry-run stops before the first GPU call."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d == {"dry_run": True, "n_gpus": 2, "rccl_ranks": 2, "max_rank": 1}
+
+
+def test_flat_params_claim_refuses_slices_autograd_accumulated_into():
+    """A backward kernel may overwrite a gradient slice only if nothing was accumulated into it since zero_grad()."""
+    from medical_tri_modal_pilot_amd.optim import FlatParams
+    lin = torch.nn.Linear(5, 3)
+    flat = FlatParams(lin.named_parameters())
+    flat.zero_grad()
+    idx = [flat.index_of[id(lin.weight)]]
+    lin(torch.randn(2, 5)).sum().backward()          # autograd accumulates into the flat views
+    assert flat.accumulated and not flat.claim(idx)
+    flat.zero_grad()
+    assert flat.claim(idx) and not flat.claim(idx)   # free after zero_grad, once
+
+
+def test_fused_adamw_state_dict_speaks_the_reference_layout():
+    """optimizer.state_dict() / load_state_dict() as the reference's Logger.save / resume code calls them
+    (logger.py:167, 2_train.py:98): moments indexed like torch.optim.AdamW(model.parameters())."""
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.Linear(2, 1))
+    hot = [(n, p) for n, p in net.named_parameters() if not n.startswith("1.")]      # a subset, in another order
+    hot = hot[2:] + hot[:2]
+    opt = FusedAdamW(hot, lr=1e-3, reference_params=list(net.parameters()))
+    assert opt.state_dict()["state"] == {}                    # nothing stepped yet
+    opt.exp_avg.copy_(torch.arange(opt.exp_avg.numel()).float())
+    opt.exp_avg_sq.copy_(torch.arange(opt.exp_avg_sq.numel()).float() * 2)
+    opt.step_count = 7
+    sd = opt.state_dict()
+    ref = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    assert len(sd["param_groups"][0]["params"]) == len(list(net.parameters()))
+    assert sorted(sd["state"]) == [0, 1, 4, 5]                # positions in model.parameters(); Linear 1 is not trained
+    ref.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})           # torch accepts it as is
+    assert float(ref.state[net[2].weight]["step"]) == 7
+    j = opt.flat.index_of[id(net[2].weight)]
+    lo, hi = opt.flat.slice_of(j)
+    assert torch.equal(ref.state[net[2].weight]["exp_avg"].reshape(-1), opt.exp_avg[lo:hi])
+    opt2 = FusedAdamW(hot, lr=1e-3, reference_params=list(net.parameters()))
+    opt2.load_state_dict(ref.state_dict())                   # a checkpoint written by the reference's own AdamW
+    assert opt2.step_count == 7
+    for j in range(len(opt.flat.params)):                    # (alignment padding between slices belongs to nobody)
+        lo, hi = opt.flat.slice_of(j)
+        assert torch.equal(opt2.exp_avg[lo:hi], opt.exp_avg[lo:hi]) and torch.equal(opt2.exp_avg_sq[lo:hi], opt.exp_avg_sq[lo:hi])
 
 
 def test_grad_reducer_two_ranks_gloo(tmp_path):

@@ -2,7 +2,7 @@
 # Diagnostic: build ablated variants of the attention forward and time them (results are WRONG by design).
 cd "$(dirname "$0")/../medical_tri_modal_pilot_amd/csrc"
 F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -shared"
-S="attention.hip gemm.hip elementwise.hip stem.hip swin.hip error.cpp"
+S="attention.hip gemm.hip elementwise.hip stem.hip swin.hip head.hip error.cpp"
 /opt/rocm/bin/hipcc $F -DMTMP_ABLATE_FETCH -o ../libmtmp_ab_fetch.so $S
 /opt/rocm/bin/hipcc $F -DMTMP_ABLATE_EXP -o ../libmtmp_ab_exp.so $S
 cd ../..

@@ -2,7 +2,7 @@
 # Diagnostic: build ablated variants of the attention dK/dV kernel and time the backward (results are WRONG by design).
 cd "$(dirname "$0")/../medical_tri_modal_pilot_amd/csrc"
 F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -shared"
-S="attention.hip gemm.hip elementwise.hip stem.hip swin.hip error.cpp"
+S="attention.hip gemm.hip elementwise.hip stem.hip swin.hip head.hip error.cpp"
 V="NOFETCH NOEXP NOLD NOMMA2"
 if [ "$1" = "build" ]; then
   for v in $V; do /opt/rocm/bin/hipcc $F -DMTMP_DKDV_$v -o ../libmtmp_ab_dkdv_$v.so $S & done; wait; exit 0
