@@ -77,6 +77,19 @@ def _staged_step(model, enc, optimizer, criterion, run_model, bounds):
     n_pre = min(max(enc.fusion_idx, 0), enc.n_layers)
     n_stage = len(bounds) - 1
 
+    flat = optimizer.flat
+
+    def partial(outputs, grad_outputs, bnd, prm):
+        """Backward from ``outputs`` that STOPS at the stream buffers ``bnd`` (returns their gradients) and accumulates
+        into the parameters ``prm`` -- torch.autograd.grad, not backward(inputs=...): the latter executes the
+        producer node of a non-leaf input (it retains its grad through a hook on that node), i.e. the next stage's
+        work.  Gradients the kernels wrote straight into the flat buffer come back as None."""
+        res = torch.autograd.grad(outputs, list(bnd) + prm, grad_outputs, allow_unused=True, retain_graph=True)
+        for q, g in zip(prm, res[len(bnd):]):
+            if g is not None:
+                flat.add_grad(q, g)
+        return res[:len(bnd)]
+
     def stage0(t, carry):
         optimizer.zero_grad()
         step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
@@ -87,21 +100,21 @@ def _staged_step(model, enc, optimizer, criterion, run_model, bounds):
             step_loss.backward()
             return
         prm = model.backward_stage_params(n_pre + bounds[-2], n_pre + bounds[-1], head=True)
-        torch.autograd.backward(step_loss, inputs=list(bnds[-1]) + prm, retain_graph=True)
+        carry["g"] = partial([step_loss], None, bnds[-1], prm)
 
     def later(k):
         def stage(t, carry):
             bnds = carry["bnds"]
             if not bnds:
                 return
-            j = len(bnds) - k                  # gradients sit on bnds[j]; this stage carries them down to bnds[j-1]
-            src = [z for z in bnds[j] if z.grad is not None]
-            grads = [z.grad for z in src]
+            j = len(bnds) - k                  # carry["g"] = gradients of bnds[j]; this stage takes them down to bnds[j-1]
+            src = [(z, g) for z, g in zip(bnds[j], carry["g"]) if g is not None]
+            outs, grads = [z for z, _ in src], [g for _, g in src]
             if j == 0:
-                torch.autograd.backward(src, grads)
+                torch.autograd.backward(outs, grads)
             else:
                 prm = model.backward_stage_params(n_pre + bounds[j], n_pre + bounds[j + 1], head=False)
-                torch.autograd.backward(src, grads, inputs=list(bnds[j - 1]) + prm, retain_graph=True)
+                carry["g"] = partial(outs, grads, bnds[j - 1], prm)
         return stage
 
     return [stage0] + [later(k) for k in range(1, n_stage)]

@@ -26,6 +26,7 @@ Gradient accumulation: wrap every backward but the last of a step in ``no_sync()
 arrives for a bucket already reduced raises instead of being silently left un-reduced.
 """
 import contextlib
+import traceback
 from typing import Iterable, List, Optional
 
 import torch
@@ -74,6 +75,7 @@ class GradReducer:
         self.pending = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.ready_log: List[int] = []           # buckets in the order they became complete this step
+        self.seen = {}                           # parameters that reported their gradient this step (-> who, if debug)
 
     def begin_step(self):
         """Called by FlatParams.zero_grad(): a new accumulation starts; the stream it is called on is the
@@ -99,6 +101,12 @@ class GradReducer:
         if not self._sync:
             return
         b = self.bucket_of[i]
+        if i in self.seen:
+            raise RuntimeError(f"GradReducer: '{self.flat.names[i]}' reported its gradient twice in one step (a second "
+                               "backward without no_sync(), or a kernel wrote it into the flat buffer AND autograd "
+                               "accumulated into it)"
+                               + (f"; first report from:\n{self.seen[i]}" if self.seen[i] else ""))
+        self.seen[i] = "".join(traceback.format_stack(limit=8)) if getattr(self, "debug", False) else None
         if self.launched[b]:
             raise RuntimeError(f"GradReducer: a gradient for '{self.flat.names[i]}' arrived after its bucket was "
                                "all-reduced -- with gradient accumulation wrap every backward but the last in no_sync()")
@@ -110,7 +118,12 @@ class GradReducer:
 
     def _make_hook(self, i: int):
         def hook(_param):
-            self._ready(i)
+            # autograd runs a leaf's AccumulateGrad node -- and this hook -- even when the producing node returned None
+            # for it: that is the case for every gradient a backward kernel wrote straight into the flat buffer, which
+            # was reported through FlatParams.mark_ready already (counted twice, a bucket would go out before its last
+            # slice is written)
+            if i not in self.flat.written:
+                self._ready(i)
         return hook
 
     def take_ready(self) -> List[int]:

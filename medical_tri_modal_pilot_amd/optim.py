@@ -53,7 +53,8 @@ class FlatParams:
 
     def _note_accumulated(self, i: int):
         def hook(_param):
-            self.accumulated.add(i)
+            if i not in self.written:      # (the hook also fires with an undefined gradient: ddp.GradReducer._make_hook)
+                self.accumulated.add(i)
         return hook
 
     def attach_grads(self):
@@ -87,6 +88,18 @@ class FlatParams:
         if self.ready_cb is not None:
             for i in idx:
                 self.ready_cb(i)
+
+    def add_grad(self, p: torch.nn.Parameter, g: torch.Tensor):
+        """Accumulate ``g`` into ``p.grad`` by hand (gradients obtained with torch.autograd.grad, which runs no
+        AccumulateGrad node and no post-accumulate hook), with the bookkeeping those would have done."""
+        if p.grad is None:
+            p.grad = g.detach().clone()
+        else:
+            p.grad.add_(g)
+        i = self.index_of.get(id(p))
+        if i is not None:
+            self.accumulated.add(i)
+            self.mark_ready([i])
 
     def slice_of(self, i: int) -> Tuple[int, int]:
         return self.offsets[i], self.offsets[i] + self.params[i].numel()

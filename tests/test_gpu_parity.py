@@ -968,6 +968,7 @@ def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
     def init_with_reducer(self, *a, **k):
         orig_init(self, *a, **k)
         self.reducer = GradReducer(self.flat)
+        self.reducer.debug = True
         self.grad_scale = 1.0
         made.append(self.reducer)
 
