@@ -92,6 +92,16 @@ int mtmp_ln_bwd_ws_floats(int M);
 int mtmp_ln_bwd(int dtype, const void* z, int ldz, const float* stats, const float* gamma, const void* dy,
                 const void* d_res, int ldr, void* dz, float* dgamma_dbeta, float* ws, int M, float eps, void* stream);
 
+/* The dX product of a LayerNorm-fed projection fused with that LayerNorm's backward -- autograd of
+ * module.py:138-144 in front of attention.py:68-70 (K = 768) / module.py:74-77 (K = 1024):
+ * dz[M,256] = LNbwd(dy[M,K] wt[256,K]^T; z, stats, gamma) (+ d_res); dgamma_dbeta float[512] overwritten.
+ * wt = W^T of y = LN(z) W^T, K-contiguous; the M x 256 product never goes to HBM.
+ * ws: mtmp_gemm_lnbwd_ws_floats(M) floats. */
+int mtmp_gemm_lnbwd_ws_floats(int M);
+int mtmp_gemm_lnbwd(int dtype, const void* dy, const void* wt, const void* z, int ldz, const float* stats,
+                    const float* gamma, const void* d_res, int ldr, void* dz, float* dgamma_dbeta, float* ws, int M,
+                    int K, int ldy, float eps, void* stream);
+
 /* TIE/UMSE event embedding (tri_mbt_vsltcls.py:59-71,183-190):
  * out[n,256] = ReLU(LN(value*w_v+b_v)) + ReLU(LN(time*w_t+b_t)) + ftab[feature].
  * events float[n,3] = (time, value, feature index); params float[8][256] = ie_vslt.{0.weight,0.bias,

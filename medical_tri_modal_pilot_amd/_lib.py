@@ -29,6 +29,9 @@ SIGNATURES = {
     "mtmp_ln_bwd_ws_floats": (c_int, [c_int]),
     "mtmp_ln_bwd": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_void_p, c_void_p, c_int, c_float, c_void_p]),
+    "mtmp_gemm_lnbwd_ws_floats": (c_int, [c_int]),
+    "mtmp_gemm_lnbwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "mtmp_tie_embed_fwd": (c_int, [c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_tie_bwd_ws_floats": (c_int, [c_int]),
     "mtmp_tie_embed_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int, c_void_p]),

@@ -81,18 +81,19 @@ class TransformerEncoderLayer(nn.Module):
                          ps[7].reshape(ps[7].shape[0], -1).to(dtype).contiguous())
 
     def _fused_weights(self, dtype):
-        """parts + W2^T; rebuilt only when a parameter changed (optimizer step / load_state_dict)."""
+        """parts + (W2^T, Wqkv^T, W1^T) -- the K-contiguous operands of the backward's dH / dX products; rebuilt only
+        when a parameter changed (optimizer step / load_state_dict)."""
         key, parts = self._fused_parts(dtype)
         if parts is not None:
             with torch.no_grad():
-                self._fused = parts + (parts[3].t().contiguous(),)
+                self._fused = parts + (parts[3].t().contiguous(), parts[0].t().contiguous(), parts[2].t().contiguous())
             self._fused_key = key
         return self._fused
 
     @staticmethod
     def fused_weights_of(blocks, dtype):
-        """``_fused_weights`` of many blocks with ONE batched transpose for all stale W2 (a stack and a
-        strided copy instead of one ~5 us launch per block on the critical path of every step)."""
+        """``_fused_weights`` of many blocks with ONE batched transpose per weight kind for all stale blocks (a stack
+        and a strided copy instead of ~5 us launches per block on the critical path of every step)."""
         stale = []
         for blk in blocks:
             key, parts = blk._fused_parts(dtype)
@@ -100,9 +101,9 @@ class TransformerEncoderLayer(nn.Module):
                 stale.append((blk, key, parts))
         if stale:
             with torch.no_grad():
-                w2t = torch.stack([p[3] for _, _, p in stale]).transpose(1, 2).contiguous()
+                w2t, wqkvt, w1t = (torch.stack([p[j] for _, _, p in stale]).transpose(1, 2).contiguous() for j in (3, 0, 2))
             for i, (blk, key, parts) in enumerate(stale):
-                blk._fused, blk._fused_key = parts + (w2t[i],), key
+                blk._fused, blk._fused_key = parts + (w2t[i], wqkvt[i], w1t[i]), key
         return [blk._fused for blk in blocks]
 
     def param_list(self):

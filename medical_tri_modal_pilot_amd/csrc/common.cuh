@@ -240,6 +240,34 @@ MTMP_DEV int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- streaming-kernel helpers shared by elementwise.hip and the fused dX + LayerNorm-backward GEMM (d_model = 256) ----
+MTMP_DEV f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// sum two values across the wave at once
+MTMP_DEV void wave_sum2(float& a, float& b) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+}
+
+// block partials: every wave adds its per-lane accumulators acc[NV][4] into LDS, block writes one slab row
+template <int NV>
+MTMP_DEV void flush_partials(float (&acc)[NV][4], float* slab_row, float* lds, int lane, int wave) {
+    // lds: [4 waves][NV*256]
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        *reinterpret_cast<f32x4*>(lds + (wave * NV + v) * 256 + 4 * lane) = f32x4{acc[v][0], acc[v][1], acc[v][2], acc[v][3]};
+    __syncthreads();
+    for (int i = threadIdx.x; i < NV * 256; i += 256)
+        slab_row[i] = lds[i] + lds[NV * 256 + i] + lds[2 * NV * 256 + i] + lds[3 * NV * 256 + i];
+}
+
+constexpr int RED_GROUPS = 64;            // most row groups of the first level of launch_slab_reduce (sizes its ws tail)
+// two-level column sum [rows][cols] -> out[cols] (elementwise.hip); ws_tail: RED_GROUPS * cols floats
+void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_tail, float* out, hipStream_t st);
+
 // ---- host side ----
 #define MTMP_OK 0
 #define MTMP_ERR_ARG 1

@@ -10,29 +10,6 @@ namespace {
 
 constexpr int D = 256;   // d_model, fixed on this path (tri_mbt_vsltcls.py:117,227-228 hard-code it)
 
-MTMP_DEV f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// sum two values across the wave at once
-MTMP_DEV void wave_sum2(float& a, float& b) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-    }
-}
-
-// block partials: every wave adds its per-lane accumulators acc[NV][4] into LDS, block writes one slab row
-template <int NV>
-MTMP_DEV void flush_partials(float (&acc)[NV][4], float* slab_row, float* lds, int lane, int wave) {
-    // lds: [4 waves][NV*256]
-#pragma unroll
-    for (int v = 0; v < NV; ++v)
-        *reinterpret_cast<f32x4*>(lds + (wave * NV + v) * D + 4 * lane) = f32x4{acc[v][0], acc[v][1], acc[v][2], acc[v][3]};
-    __syncthreads();
-    for (int i = threadIdx.x; i < NV * D; i += 256)
-        slab_row[i] = lds[i] + lds[NV * D + i] + lds[2 * NV * D + i] + lds[3 * NV * D + i];
-}
-
 // out[c] = sum_r slab[r][c]: a block owns 64 columns; 4 row-lanes sum interleaved rows (coalesced
 // 256-byte reads) and combine through LDS in a fixed order (bitwise reproducible).
 // blockIdx.y = row group g of gridDim.y: rows g, g + G, g + 2G ... ; out is [gridDim.y][cols].
@@ -51,10 +28,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
     if (rl == 0 && c < cols)
         out[(size_t)blockIdx.y * cols + c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
-constexpr int RED_GROUPS = 64;            // most row groups of the first level (sizes the ws tail)
 // two-level tree: [rows][cols] -> [G][cols] (in ws_tail) -> out[cols].  G is chosen so that the first level has >= 512
 // workgroups (a 2048 x 512 slab with 16 groups ran on 128 workgroups, 32 dependent loads per thread: 12-15 us).
-inline void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_tail, float* out, hipStream_t st) {
+}  // namespace
+// (also used by the fused dX + LayerNorm-backward GEMM of gemm.hip; declared in common.cuh)
+void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_tail, float* out, hipStream_t st) {
     const int gx = (cols + 63) / 64;
     if (rows <= 64) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, slab, rows, cols, out);
@@ -65,6 +43,7 @@ inline void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, 1), dim3(256), 0, st, (const float*)ws_tail, G, cols, out);
     }
 }
+namespace {
 
 // ------------------------------------------------------------------------------------------
 // custom LayerNorm backward (module.py:138-144):  y = gamma * (z - mu) / (sigma + eps) + beta,

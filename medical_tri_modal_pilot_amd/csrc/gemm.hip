@@ -833,6 +833,145 @@ int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
     const long long wgs128 = (long long)((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
     return wgs128 < 512 ? launch_gemm_nt_tm<T, 64>(a, relu, st) : launch_gemm_nt_tm<T, 128>(a, relu, st);
 }
+// ---------------------------------------------------------------------------
+// dX of a LayerNorm-fed projection fused with that LayerNorm's backward (autograd of module.py:138-144 in front of
+// attention.py:68-70 / module.py:74-77):
+//     dxn[M,256] = dY[M,K] W[K,256]        (W^T [256,K] is handed in, so both operands are K-contiguous: "NT")
+//     dz = LNbackward(dxn; z, stats, gamma) + d_res ;  dgamma = sum_rows dxn * xhat ;  dbeta = sum_rows dxn
+// One workgroup owns 128 token rows and ALL 256 output features (2 x 2 waves of 64 tokens x 128 features), so the
+// finished dxn tile never goes to HBM: it is parked in LDS, rounded to T exactly like the stand-alone GEMM's output
+// was, and the LayerNorm backward (same arithmetic and row-per-wave mapping as ln_bwd_kernel) reads it from there.
+// Replaces a library GEMM (hipBLASLt, 38 us at M = 64,320) + mtmp_ln_bwd (32 us) and their M x 256 round trip.
+constexpr int LDXT = 256 + 8;       // staging row (elements)
+
+template <typename T> struct LnBwdGemmArgs {
+    const T* dy; const T* wt; const T* z; const float* stats; const float* gamma; const T* d_res; T* dz; float* slab;
+    int M, K, ldy, ldz, ldr;
+    float eps;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kernel(LnBwdGemmArgs<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sA = reinterpret_cast<T*>(smem_raw);   // [128][LDW]  dY tile
+    T* sW = sA + 128 * LDW;                   // [256][LDW]  W^T tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int wr = wave & 1, wc = wave >> 1;
+    const int m0 = blockIdx.x * 128;
+    const int nk = (p.K + BK - 1) / BK;
+    TileRegs<T> areg, wreg0, wreg1;
+    tile_fetch<T>(areg, p.dy, p.ldy, m0, p.M, 0, tid, p.K);
+    tile_fetch<T>(wreg0, p.wt, p.K, 0, 256, 0, tid, p.K);
+    tile_fetch<T>(wreg1, p.wt, p.K, 128, 256, 0, tid, p.K);
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[rt][nt] = f32x16{0};
+    for (int kc = 0; kc < nk; ++kc) {
+        __syncthreads();
+        tile_commit<T>(sA, areg, tid);
+        tile_commit<T>(sW, wreg0, tid);
+        tile_commit<T>(sW + 128 * LDW, wreg1, tid);
+        __syncthreads();
+        if (kc + 1 < nk) {
+            tile_fetch<T>(areg, p.dy, p.ldy, m0, p.M, (kc + 1) * BK, tid, p.K);
+            tile_fetch<T>(wreg0, p.wt, p.K, 0, 256, (kc + 1) * BK, tid, p.K);
+            tile_fetch<T>(wreg1, p.wt, p.K, 128, 256, (kc + 1) * BK, tid, p.K);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Frag<T> a[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) a[rt] = frag_load<T>(sA + (64 * wr + 32 * rt + r) * LDW + 16 * c + 8 * half);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const Frag<T> w = frag_load<T>(sW + (128 * wc + 32 * nt + r) * LDW + 16 * c + 8 * half);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) mma<T>(acc[rt][nt], w, a[rt]);
+            }
+        }
+    }
+    __syncthreads();                          // every wave is done with sA / sW: the dxn tile takes their place
+    T* sX = reinterpret_cast<T*>(smem_raw);   // [128][LDXT]
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                store4<T>(sX + (64 * wr + 32 * rt + r) * LDXT + 128 * wc + 32 * nt + 8 * g + 4 * half, acc[rt][nt][4 * g],
+                          acc[rt][nt][4 * g + 1], acc[rt][nt][4 * g + 2], acc[rt][nt][4 * g + 3]);
+    __syncthreads();
+    // LayerNorm backward over the tile's rows: a wave owns 32 consecutive rows, 4 in flight per trip (ln_bwd_kernel)
+    const f32x4 gm = ld4f(p.gamma + 4 * lane);
+    float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    constexpr int RPW = 4;
+    const T* res = p.d_res ? p.d_res : p.z;                // no residual: a finite stand-in scaled by 0
+    const int ldres = p.d_res ? p.ldr : p.ldz;
+    const float rscale = p.d_res ? 1.0f : 0.0f;
+    for (int trip = 0; trip < 32 / RPW; ++trip) {
+        const int rl0 = wave * 32 + trip * RPW;
+        if (m0 + rl0 >= p.M) break;                        // wave-uniform: whole trips past M do nothing
+        f32x4 zv[RPW], dv[RPW], rv[RPW];
+        float mu[RPW], rs[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const size_t row = (size_t)min(m0 + rl0 + k, p.M - 1);
+            zv[k] = load4<T>(p.z + row * p.ldz + 4 * lane);
+            rv[k] = load4<T>(res + row * ldres + 4 * lane);
+            mu[k] = p.stats[2 * row];
+            rs[k] = p.stats[2 * row + 1];
+            dv[k] = load4<T>(sX + (rl0 + k) * LDXT + 4 * lane);
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const float live = m0 + rl0 + k < p.M ? 1.0f : 0.0f;   // rows past M (clamped loads) rewrite row M-1 identically
+            const float sigma = 1.0f / rs[k] - p.eps;
+            float xh[4], g[4], sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[i] = (zv[k][i] - mu[k]) * rs[k];
+                g[i] = dv[k][i] * gm[i];
+                sg += g[i];
+                sgx += g[i] * xh[i];
+                part[0][i] += live * dv[k][i] * xh[i];
+                part[1][i] += live * dv[k][i];
+            }
+            wave_sum2(sg, sgx);
+            const float mg = sg * (1.0f / 256);
+            const float kx = sgx / (255.0f * sigma);
+            // a clamped row recomputes row M-1 from ITS OWN dxn only when its staged row is that row's copy: the A tile
+            // replicates row M-1 for rows past M (tile_fetch), so the staged rows past M equal row M-1's
+            store4<T>(p.dz + (size_t)min(m0 + rl0 + k, p.M - 1) * 256 + 4 * lane,
+                      (g[0] - mg) * rs[k] - xh[0] * kx + rscale * rv[k][0], (g[1] - mg) * rs[k] - xh[1] * kx + rscale * rv[k][1],
+                      (g[2] - mg) * rs[k] - xh[2] * kx + rscale * rv[k][2], (g[3] - mg) * rs[k] - xh[3] * kx + rscale * rv[k][3]);
+        }
+    }
+    __syncthreads();                          // all rows of sX are consumed: its head becomes the partials' scratch
+    flush_partials<2>(part, p.slab + (size_t)blockIdx.x * 512, reinterpret_cast<float*>(smem_raw), lane, wave);
+}
+
+template <typename T>
+int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStream_t st) {
+    size_t sm = (size_t)(128 + 256) * LDW * sizeof(T);
+    const size_t stage = (size_t)128 * LDXT * sizeof(T);
+    if (sm < stage) sm = stage;
+    if (sm < 4 * 2 * 256 * sizeof(float)) sm = 4 * 2 * 256 * sizeof(float);
+    if (sm > 48 * 1024 && hipFuncSetAttribute((const void*)gemm_lnbwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)sm) != hipSuccess) {
+        mtmp_set_error("mtmp_gemm_lnbwd: cannot raise dynamic LDS to %zu", sm);
+        return MTMP_ERR_LAUNCH;
+    }
+    const int nb = (a.M + 127) / 128;
+    a.slab = ws;
+    hipLaunchKernelGGL(gemm_lnbwd_kernel<T>, dim3(nb), dim3(256), sm, st, a);
+    MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd");
+    launch_slab_reduce(ws, nb, 512, ws + (size_t)nb * 512, dgamma_dbeta, st);
+    MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd(reduce)");
+    return MTMP_OK;
+}
+
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
                    hipStream_t st) {
@@ -909,6 +1048,33 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
         return launch_gemm_nt<bf16>(g, 0, st);
     }
     mtmp_set_error("mtmp_gemm_nt: unknown dtype %d", dtype);
+    return MTMP_ERR_ARG;
+}
+
+extern "C" int mtmp_gemm_lnbwd_ws_floats(int M) { return ((M + 127) / 128 + RED_GROUPS) * 512; }
+
+// dz[M,256] = LNbackward(dY[M,K] Wt[256,K]^T; z, stats, gamma) (+ d_res);  dgamma_dbeta[512] overwritten.
+// Wt = W^T of the projection y = LN(z) W^T (W [K,256] row-major -> Wt [256,K]); ws: mtmp_gemm_lnbwd_ws_floats(M).
+// The dX product of attention.py:68-70 / module.py:74-77 and the backward of module.py:138-144 in one launch
+// (+ the two-level reduce of the gamma / beta partials).
+extern "C" int mtmp_gemm_lnbwd(int dtype, const void* dy, const void* wt, const void* z, int ldz, const float* stats,
+                               const float* gamma, const void* d_res, int ldr, void* dz, float* dgamma_dbeta, float* ws,
+                               int M, int K, int ldy, float eps, void* stream) {
+    MTMP_CHECK_ARG(dy && wt && z && stats && gamma && dz && dgamma_dbeta && ws, "mtmp_gemm_lnbwd: null pointer");
+    MTMP_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0 && ldy >= K && ldy % 8 == 0 && ldz >= 256 && ldz % 4 == 0 &&
+                       (!d_res || (ldr >= 256 && ldr % 4 == 0)), "mtmp_gemm_lnbwd: bad shape M=%d K=%d ldy=%d ldz=%d", M, K, ldy, ldz);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        LnBwdGemmArgs<float> a{(const float*)dy, (const float*)wt, (const float*)z, stats, gamma, (const float*)d_res,
+                               (float*)dz, nullptr, M, K, ldy, ldz, ldr, eps};
+        return launch_gemm_lnbwd<float>(a, dgamma_dbeta, ws, st);
+    }
+    if (dtype == 1) {
+        LnBwdGemmArgs<bf16> a{(const bf16*)dy, (const bf16*)wt, (const bf16*)z, stats, gamma, (const bf16*)d_res,
+                              (bf16*)dz, nullptr, M, K, ldy, ldz, ldr, eps};
+        return launch_gemm_lnbwd<bf16>(a, dgamma_dbeta, ws, st);
+    }
+    mtmp_set_error("mtmp_gemm_lnbwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
 

@@ -1,8 +1,7 @@
 """Torch-facing wrappers of the C-ABI kernels (include/mtmp.h) and the hand-written
 forward/backward of one encoder layer.
 
-PyTorch is plumbing here: it owns device memory and streams, and runs the *plain*
-backward GEMMs (dW = dY^T X, dX = dY W) through its BLAS.  Every fused op of the hot
+PyTorch is plumbing here: it owns device memory and streams.  Every op of the hot
 path (LN+projection, attention fwd/bwd, FFN, LN backward, TIE embedding, stem,
 AdamW) is a libmtmp_hip.so kernel; there is no CPU or eager fallback -- inputs
 that are not on a GPU raise.
@@ -242,6 +241,20 @@ def ln_bwd(z2d, stats, gamma, dy2d, d_res2d=None, gb_out=None):
     return dz, gb[:D_MODEL], gb[D_MODEL:]
 
 
+def gemm_lnbwd(dy2d, wt, z2d, stats, gamma, d_res2d=None, gb_out=None):
+    """-> (dz[M,256], dgamma[256], dbeta[256]): dz = LNbackward(dy wt^T; z, stats, gamma) (+ d_res) in ONE launch
+    (mtmp_gemm_lnbwd: the dX GEMM of the LayerNorm-fed projection with the LayerNorm backward as its epilogue).
+    dy2d [M,K]; wt [256,K] = W^T of the projection; gb_out: fp32[512] destination for (dgamma | dbeta)."""
+    _gpu(dy2d, wt, z2d)
+    M, K = dy2d.shape
+    dz = torch.empty(M, D_MODEL, dtype=z2d.dtype, device=z2d.device)
+    gb = gb_out if gb_out is not None else torch.empty(2 * D_MODEL, dtype=torch.float32, device=z2d.device)
+    ws = torch.empty(_lib.lib().mtmp_gemm_lnbwd_ws_floats(M), dtype=torch.float32, device=z2d.device)
+    call("mtmp_gemm_lnbwd", _dt(z2d), _p(dy2d), _p(wt), _p(z2d), z2d.stride(0), _p(stats), _p(gamma), _p(d_res2d),
+         0 if d_res2d is None else d_res2d.stride(0), _p(dz), _p(gb), _p(ws), M, K, dy2d.stride(0), LN_EPS, _stream())
+    return dz, gb[:D_MODEL], gb[D_MODEL:]
+
+
 def dropout_bwd(g, seed, p):
     out = torch.empty_like(g)
     call("mtmp_dropout_bwd", _dt(g), _p(g), _p(out), g.numel(), int(seed) & 0xFFFFFFFF, _p(_seed_word),
@@ -278,16 +291,6 @@ def bottleneck_exchange_bwd(dz, missing, resbottle=False, d_prev_in=None, d_prev
     B = dz[0].shape[0]
     call("mtmp_bottleneck_exchange_bwd", _dt(dz[0]), _p(dz[0]), _p(dz[1]), _p(dz[2]), B, dz[0].shape[1], dz[1].shape[1],
          dz[2].shape[1], _p(missing), int(bool(resbottle)), _p(d_prev_in), _p(d_prev_out), _stream())
-
-
-def _mm_f32(a, b):
-    """Plain library GEMM with an fp32 result (weight gradients are kept in fp32)."""
-    if a.dtype == torch.float32:
-        return a @ b
-    try:
-        return torch.mm(a, b, out_dtype=torch.float32)
-    except (TypeError, RuntimeError):
-        return (a @ b).float()
 
 
 def sink_param_grads(params, grads):
@@ -559,19 +562,20 @@ class StreamInputFn(torch.autograd.Function):
 #     r1  = z + MHA(LN1(z); kv_len)          mtmp_ln_gemm(QKV) + mtmp_attn_fwd(+residual)
 #     out = r1 + FFN(LN2(r1))                mtmp_ln_gemm(ReLU, drop1) + mtmp_gemm_nt(drop2, +residual)
 # The backward is written out by hand (no autograd graph inside): HIP kernels for attention,
-# LayerNorm, dropout, dW (split-M "TN" GEMM with the bias gradient fused) and the ReLU-gated
-# dH; plain BLAS GEMMs for the two remaining dX products.  Activations needed by the backward
+# dropout, dW (split-M "TN" GEMM with the bias gradient fused), the ReLU-gated dH, and the two
+# remaining dX products fused with the backward of the LayerNorm in front of them (mtmp_gemm_lnbwd).
+# No library GEMM is left on the path.  Activations needed by the backward
 # are kept (HBM is 288 GB; one vslt layer at B=64, T=1000 keeps ~0.4 GB in bf16).
 PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, c2
 
 
 def layer_forward(z, kv_len, P, fused, drop_p, seeds):
-    """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T) in compute dtype.
+    """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T, wqkv^T, w1^T) in compute dtype.
     Returns (out [B,N,256], saved tuple)."""
     B, N, D = z.shape
     M = B * N
     g1, b1, g2, b2, c1, c2 = P[0], P[1], P[8], P[9], P[11], P[13]
-    wqkv, bqkv, w1c, w2c, w2t = fused
+    wqkv, bqkv, w1c, w2c, w2t, wqkvt, w1t = fused
     z2 = z.view(M, D)
     qkv, xn1, st1 = ln_gemm(z2, g1, b1, wqkv, bqkv, 3 * D)
     qkv = qkv.view(B, N, 3 * D)
@@ -579,7 +583,7 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     r1_2 = r1.view(M, D)
     h, xn2, st2 = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0])
     out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
-    saved = (z, kv_len, g1, g2, wqkv, w1c, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds)
+    saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds)
     return out.view(B, N, D), saved
 
 
@@ -614,7 +618,7 @@ def layer_backward(saved, d_out, sink=None):
     """d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
     in PARAMS order; weights as 2-D [out,in])) -- or (dz, None) when the gradients went straight into
     the flat gradient buffer through `sink`."""
-    z, kv_len, g1, g2, wqkv, w1c, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds = saved
+    z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds = saved
     B, N, D = z.shape
     M = B * N
     d_out = d_out.view(M, D)
@@ -625,13 +629,12 @@ def layer_backward(saved, d_out, sink=None):
     # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue
     dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
     dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None)      # [1024,256], [1024]
-    dxn2 = dh @ w1c                                         # [M,256]   (plain BLAS)
-    dr1, dg2, db2 = ln_bwd(r1.view(M, D), st2, g2, dxn2, d_res2d=d_out, gb_out=sink.gb2 if direct else None)
+    # dXn2 = dH W1 and the backward of LN2 (+ the residual gradient) in one launch; the M x 256 product stays in LDS
+    dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D), st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None)
     # ---- attention: r1 = z + o  ->  d_o = dr1
     dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
     dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None)   # [768,256], [768]
-    dxn1 = dqkv @ wqkv                                      # [M,256]   (plain BLAS)
-    dz, dg1, db1 = ln_bwd(z.view(M, D), st1, g1, dxn1, d_res2d=dr1, gb_out=sink.gb1 if direct else None)
+    dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z.view(M, D), st1, g1, d_res2d=dr1, gb_out=sink.gb1 if direct else None)
     if direct:
         sink.flat.mark_ready(sink.idx)
         return dz.view(B, N, D), None

@@ -176,6 +176,38 @@ def test_ln_bwd(ops, dt, golden_dir):
     check(t + ".dbeta", db, bet.grad, 1e-4 if dt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,K", [(777, 768), (128, 1024), (3456, 1024), (50, 768)])
+def test_gemm_lnbwd_vs_autograd_of_ln_then_linear(ops, dt, M, K):
+    """mtmp_gemm_lnbwd = the dX product of a LayerNorm-fed projection with the LayerNorm backward as its epilogue:
+    against autograd through the oracle's custom LayerNorm followed by a Linear (module.py:138-144 + attention.py:68-70 /
+    module.py:74-77), with the residual-branch gradient added; M not a multiple of the 128-row tile, one tile, many."""
+    g = torch.Generator().manual_seed(M + K)
+    z = (torch.randn(M, 256, generator=g) * 2 + 0.3).to(dt).float().requires_grad_()
+    gam = (1 + 0.1 * torch.randn(256, generator=g)).requires_grad_()
+    bet = (0.1 * torch.randn(256, generator=g)).requires_grad_()
+    W = (torch.randn(K, 256, generator=g) / 16).to(dt).float()
+    dy = torch.randn(M, K, generator=g).to(dt).float()
+    dres = torch.randn(M, 256, generator=g).to(dt).float()
+    xn = O.custom_layernorm(z, gam, bet)
+    if dt == torch.bfloat16:          # the stand-alone path rounds the M x 256 product to bf16 before the LN backward
+        dxn = (dy @ W).to(dt).float()
+        (xn * dxn).sum().backward()
+    else:
+        ((xn @ W.t()) * dy).sum().backward()
+    mu = z.detach().mean(-1)
+    rs = 1 / (z.detach().std(-1) + 1e-6)
+    st = torch.stack([mu, rs], 1).to(DEV)
+    dz, dg, db = ops.gemm_lnbwd(dy.to(DEV, dt), W.t().contiguous().to(DEV, dt), z.detach().to(DEV, dt), st, gam.detach().to(DEV),
+                                dres.to(DEV, dt))
+    t = f"gemm_lnbwd[{str(dt)[6:]},M={M},K={K}]"
+    check(t + ".dz", dz.float(), z.grad + dres, TOL[dt] if dt == torch.float32 else 2e-2)
+    check(t + ".dgamma", dg, gam.grad, 1e-4 if dt == torch.float32 else 1e-2)
+    check(t + ".dbeta", db, bet.grad, 1e-4 if dt == torch.float32 else 1e-2)
+    dz0, _, _ = ops.gemm_lnbwd(dy.to(DEV, dt), W.t().contiguous().to(DEV, dt), z.detach().to(DEV, dt), st, gam.detach().to(DEV))
+    check(t + ".dz_no_residual", dz0.float(), z.grad, TOL[dt] if dt == torch.float32 else 2e-2)
+
+
 def test_ln_gemm_dropout_statistics(ops):
     """Dropout inside mtmp_ln_gemm (module.py:77-79 after the ReLU): kept elements are the no-dropout values / (1-p), the keep
     fraction is 1-p overall, per row and per column, a different seed gives a different mask, the same seed the same one."""
