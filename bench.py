@@ -160,7 +160,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if ddp:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on stdout when its communicator comes up: keep stdout for the JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from medical_tri_modal_pilot_amd import ops, synthetic
     from medical_tri_modal_pilot_amd.builder.trainer import get_trainer

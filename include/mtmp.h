@@ -147,7 +147,7 @@ int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float*
                           unsigned seed, const unsigned* seed_dev, void* stream);
 
 /* Classification head (tri_mbt_vsltcls.py:59-76 ie_demo, :248-255): out[b] = fc3(ReLU(BatchNorm1d(fc0([LN(cls[b]) |
- * ReLU(LN(ie_demo.0(age, gender)))])))), fp32, B <= 64, six launches forward + backward instead of ~65 torch kernels.
+ * ReLU(LN(ie_demo.0(age, gender)))])))), fp32, B <= 256, six launches forward + backward instead of ~65 torch kernels.
  * params: 14 device pointers (float): ie_demo.0.weight[256][2], ie_demo.0.bias, ie_demo.1.weight, ie_demo.1.bias,
  * layer_norms_after_concat.{weight,bias}, fc_list.0.{weight[256][512],bias}, fc_list.1.{weight,bias,running_mean,
  * running_var} (the running statistics are updated in place when training != 0), fc_list.3.{weight[256],bias[1]}.

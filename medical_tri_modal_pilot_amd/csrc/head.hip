@@ -2,10 +2,10 @@
 //     demo = ReLU(LN(age * w[:,0] + gender * w[:,1] + b))                         ie_demo (Linear(2,256), LayerNorm, ReLU)
 //     x    = [ LN(cls) | demo ]                                                   layer_norms_after_concat, torch.cat
 //     h    = x W1^T + b1 ;  y = BatchNorm1d(h) ;  a = ReLU(y) ;  out = a W2^T + b2  fc_list.{0,1,2,3}
-// Everything here is a few hundred KFLOP on B <= 64 rows: the torch modules cost ~65 launches of ~5 us forward +
+// Everything here is a few hundred KFLOP on B <= 256 rows: the torch modules cost ~65 launches of ~5 us forward +
 // backward, all of them on the critical path between the forward and the backward of the step.  Six launches here.
 //   forward : head_x (one wave per row: the two LayerNorms) -> head_fc (feature-parallel: 4 features per workgroup,
-//             a wave = one feature x all rows, so the BatchNorm statistics are wave reductions) -> head_out
+//             a wave = one feature x all rows -- R = 1, 2 or 4 rows per lane --, so the BatchNorm statistics are wave reductions) -> head_out
 //   backward: head_fc_bwd (feature-parallel: BatchNorm / Linear weight gradients, dh) -> head_x_bwd (row-parallel:
 //             dx = dh W1, both LayerNorm backwards, per-row partials of the row-summed gradients) -> slab reduce
 // fp32 throughout (the reference runs the head in fp32 under autocast too).  Deterministic: no float atomics.
@@ -13,7 +13,8 @@
 
 namespace {
 
-constexpr int D = 256, DX = 512, MAXB = 64, FPW = 4;   // d_model, head input width, rows per wave, features per workgroup
+constexpr int D = 256, DX = 512, MAXB = 256, FPW = 4;  // d_model, head input width, most rows per call, features per workgroup
+inline int rows_per_lane(int B) { return B <= 64 ? 1 : (B <= 128 ? 2 : 4); }
 
 MTMP_DEV float block_sum(float v, float* red, int tid) {   // 256 threads -> every thread gets the sum
     v = wave_sum(v);
@@ -60,37 +61,58 @@ __global__ __launch_bounds__(256) void head_x_kernel(const float* cls, const flo
     *reinterpret_cast<f32x4*>(x + (size_t)b * DX + D + c) = o;
 }
 
-// workgroup g owns features 4g..4g+3; thread = (row b = lane, feature jj = wave)
+// workgroup g owns features 4g..4g+3; thread = (rows b = lane + 64 rr for rr < R, feature jj = wave)
+template <int R>
 __global__ __launch_bounds__(256) void head_fc_kernel(const float* x, HeadParams p, float* hhat, float* rstd_out, float* partial,
                                                       int B, float eps, float momentum, int training) {
-    __shared__ float xT[64][MAXB + 1];          // one 64-column chunk of x, transposed: xT[k][b]
-    __shared__ float pl[FPW][MAXB];
-    const int tid = threadIdx.x, b = tid & 63, jj = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x * FPW + jj;
-    const bool live = b < B;
+    constexpr int NB = 64 * R;                  // row capacity of this instantiation
+    __shared__ float xT[64][NB + 1];            // one 64-column chunk of x, transposed: xT[k][b]
+    __shared__ float pl[FPW][NB];
+    const int tid = threadIdx.x, lane = tid & 63, jj = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x * FPW + jj;
     const float* wrow = p.w1 + (size_t)j * DX;
-    float acc = 0.f;
+    float acc[R];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) acc[rr] = 0.f;
     for (int k0 = 0; k0 < DX; k0 += 64) {
         __syncthreads();
-        // 64 rows x 64 columns: thread t loads row t>>2, columns 16*(t&3) .. +15
-        const int r = tid >> 2, cs = 16 * (tid & 3);
+        // NB rows x 64 columns: thread t loads rows (t>>2) + 64 rr, columns 16*(t&3) .. +15
+        const int cs = 16 * (tid & 3);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < B) v = *reinterpret_cast<const f32x4*>(x + (size_t)r * DX + k0 + cs + 4 * q);
+        for (int rr = 0; rr < R; ++rr) {
+            const int r = (tid >> 2) + 64 * rr;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xT[cs + 4 * q + i][r] = v[i];
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < B) v = *reinterpret_cast<const f32x4*>(x + (size_t)r * DX + k0 + cs + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xT[cs + 4 * q + i][r] = v[i];
+            }
         }
         __syncthreads();
 #pragma unroll 16
-        for (int kk = 0; kk < 64; ++kk) acc = fmaf(xT[kk][b], wrow[k0 + kk], acc);
+        for (int kk = 0; kk < 64; ++kk) {
+            const float wv = wrow[k0 + kk];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) acc[rr] = fmaf(xT[kk][lane + 64 * rr], wv, acc[rr]);
+        }
     }
-    const float h = acc + p.b1[j];
+    float h[R];
+    bool live[R];
+    float sh = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        h[rr] = acc[rr] + p.b1[j];
+        live[rr] = lane + 64 * rr < B;
+        sh += live[rr] ? h[rr] : 0.f;
+    }
     float mean, var;
     if (training) {
-        mean = wave_sum(live ? h : 0.f) / (float)B;
-        const float dv = live ? h - mean : 0.f;
-        var = wave_sum(dv * dv) / (float)B;                                    // biased, used for normalisation
-        if (b == 0) {                                                          // running statistics (unbiased variance)
+        mean = wave_sum(sh) / (float)B;
+        float sv = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) { const float dv = live[rr] ? h[rr] - mean : 0.f; sv += dv * dv; }
+        var = wave_sum(sv) / (float)B;                                         // biased, used for normalisation
+        if (lane == 0) {                                                       // running statistics (unbiased variance)
             p.run_mean[j] = (1.0f - momentum) * p.run_mean[j] + momentum * mean;
             p.run_var[j] = (1.0f - momentum) * p.run_var[j] + momentum * var * ((float)B / (float)max(B - 1, 1));
         }
@@ -99,47 +121,67 @@ __global__ __launch_bounds__(256) void head_fc_kernel(const float* x, HeadParams
         var = p.run_var[j];
     }
     const float rstd = rsqrtf(var + eps);
-    const float hh = (h - mean) * rstd;
-    const float a = fmaxf(fmaf(hh, p.bn_g[j], p.bn_b[j]), 0.f);
-    if (live) hhat[(size_t)b * D + j] = hh;
-    if (b == 0) rstd_out[j] = rstd;
-    pl[jj][b] = live ? a * p.w2[j] : 0.f;
+    if (lane == 0) rstd_out[j] = rstd;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int b = lane + 64 * rr;
+        const float hh = (h[rr] - mean) * rstd;
+        const float a = fmaxf(fmaf(hh, p.bn_g[j], p.bn_b[j]), 0.f);
+        if (live[rr]) hhat[(size_t)b * D + j] = hh;
+        pl[jj][b] = live[rr] ? a * p.w2[j] : 0.f;
+    }
     __syncthreads();
-    if (tid < MAXB) partial[(size_t)blockIdx.x * MAXB + tid] = pl[0][tid] + pl[1][tid] + pl[2][tid] + pl[3][tid];
+    for (int t = tid; t < NB; t += 256) partial[(size_t)blockIdx.x * NB + t] = pl[0][t] + pl[1][t] + pl[2][t] + pl[3][t];
 }
 
-__global__ __launch_bounds__(64) void head_out_kernel(const float* partial, const float* b2, float* out, int B) {
-    const int b = threadIdx.x;
+__global__ __launch_bounds__(256) void head_out_kernel(const float* partial, const float* b2, float* out, int B, int nb) {
+    const int b = threadIdx.x;                  // nb = row stride of `partial` (64 x rows per lane)
     if (b >= B) return;
     float s = 0.f;
-    for (int g = 0; g < D / FPW; ++g) s += partial[(size_t)g * MAXB + b];
+    for (int g = 0; g < D / FPW; ++g) s += partial[(size_t)g * nb + b];
     out[b] = s + b2[0];
 }
 
 // feature-parallel backward: dW2, db2, dbn_g, dbn_b, db1, dW1, dh[b][j]
+template <int R>
 __global__ __launch_bounds__(256) void head_fc_bwd_kernel(const float* dout, const float* x, const float* hhat, const float* rstd_in,
                                                           HeadParams p, float* dh_out, float* dw1, float* db1, float* dbn_g,
                                                           float* dbn_b, float* dw2, float* db2, int B, int training) {
-    __shared__ float dhs[FPW][MAXB];
-    const int tid = threadIdx.x, b = tid & 63, jj = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x * FPW + jj;
-    const bool live = b < B;
-    const float dl = live ? dout[b] : 0.f;
-    const float hh = live ? hhat[(size_t)b * D + j] : 0.f;
-    const float gam = p.bn_g[j], y = fmaf(hh, gam, p.bn_b[j]);
-    const float a = fmaxf(y, 0.f);
-    const float dy = (live && y > 0.f) ? dl * p.w2[j] : 0.f;
-    const float s_w2 = wave_sum(dl * a), s_g = wave_sum(dy * hh), s_b = wave_sum(dy);
-    const float rstd = rstd_in[j];
-    const float dh = training ? gam * rstd * (dy - s_b / (float)B - hh * s_g / (float)B) : gam * rstd * dy;
-    const float dhl = live ? dh : 0.f;
-    const float s_b1 = wave_sum(dhl);
-    if (b == 0) { dw2[j] = s_w2; dbn_g[j] = s_g; dbn_b[j] = s_b; db1[j] = s_b1; }
-    if (blockIdx.x == 0 && jj == 0) {
-        const float s = wave_sum(dl);
-        if (b == 0) db2[0] = s;
+    constexpr int NB = 64 * R;
+    __shared__ float dhs[FPW][NB];
+    const int tid = threadIdx.x, lane = tid & 63, jj = __builtin_amdgcn_readfirstlane(tid >> 6), j = blockIdx.x * FPW + jj;
+    const float gam = p.bn_g[j], rstd = rstd_in[j];
+    float dl[R], hh[R], dy[R];
+    bool live[R];
+    float t_w2 = 0.f, t_g = 0.f, t_b = 0.f, t_dl = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int b = lane + 64 * rr;
+        live[rr] = b < B;
+        dl[rr] = live[rr] ? dout[b] : 0.f;
+        hh[rr] = live[rr] ? hhat[(size_t)b * D + j] : 0.f;
+        const float y = fmaf(hh[rr], gam, p.bn_b[j]);
+        const float a = fmaxf(y, 0.f);
+        dy[rr] = (live[rr] && y > 0.f) ? dl[rr] * p.w2[j] : 0.f;
+        t_w2 += dl[rr] * a; t_g += dy[rr] * hh[rr]; t_b += dy[rr]; t_dl += dl[rr];
     }
-    if (live) dh_out[(size_t)b * D + j] = dh;
-    dhs[jj][b] = dhl;
+    const float s_w2 = wave_sum(t_w2), s_g = wave_sum(t_g), s_b = wave_sum(t_b);
+    float t_b1 = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int b = lane + 64 * rr;
+        const float dh = training ? gam * rstd * (dy[rr] - s_b / (float)B - hh[rr] * s_g / (float)B) : gam * rstd * dy[rr];
+        const float dhl = live[rr] ? dh : 0.f;
+        t_b1 += dhl;
+        if (live[rr]) dh_out[(size_t)b * D + j] = dh;
+        dhs[jj][b] = dhl;
+    }
+    const float s_b1 = wave_sum(t_b1);
+    if (lane == 0) { dw2[j] = s_w2; dbn_g[j] = s_g; dbn_b[j] = s_b; db1[j] = s_b1; }
+    if (blockIdx.x == 0 && jj == 0) {
+        const float s = wave_sum(t_dl);
+        if (lane == 0) db2[0] = s;
+    }
     __syncthreads();
     // dW1[j][k] = sum_b dh[b][j] x[b][k]: thread t owns columns t and t + 256 of the workgroup's four rows of W1
     float s0[FPW] = {0.f, 0.f, 0.f, 0.f}, s1[FPW] = {0.f, 0.f, 0.f, 0.f};
@@ -203,7 +245,7 @@ __global__ __launch_bounds__(256) void head_x_bwd_kernel(const float* dh, const 
     }
 }
 
-// out[c] = sum_r slab[r][c], r < rows <= 64: 256 threads over columns
+// out[c] = sum_r slab[r][c], r < rows <= 256: 256 threads over columns
 __global__ __launch_bounds__(256) void head_rows_reduce_kernel(const float* slab, int rows, int cols, float* out) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
@@ -235,11 +277,11 @@ extern "C" int mtmp_bce_logits_mean(const float* logits, const float* target, fl
     return MTMP_OK;
 }
 
-// ws_fwd: x[B][512] + hhat[B][256] + rstd[256] + partial[64][64] floats (kept for the backward)
-extern "C" int mtmp_head_ws_floats(int B) { return B * DX + B * D + D + (D / FPW) * MAXB; }
+// ws_fwd: x[B][512] + hhat[B][256] + rstd[256] + partial[64][64 x rows per lane] floats (kept for the backward)
+extern "C" int mtmp_head_ws_floats(int B) { return B * DX + B * D + D + (D / FPW) * 64 * rows_per_lane(B); }
 
 // params: 14 device pointers in HeadParams order (float; run_mean / run_var are updated in place when training).
-// cls float[B][256], age / gender float[B]; out float[B]; B <= 64.
+// cls float[B][256], age / gender float[B]; out float[B]; B <= 256 (one, two or four rows per lane).
 extern "C" int mtmp_head_fwd(const float* cls, const float* age, const float* gender, const void* const* params, float* out,
                              float* ws, int B, float ln_eps, float bn_eps, float momentum, int training, void* stream) {
     MTMP_CHECK_ARG(cls && age && gender && params && out && ws && B > 0 && B <= MAXB && (training == 0 || B > 1),
@@ -252,10 +294,11 @@ extern "C" int mtmp_head_fwd(const float* cls, const float* age, const float* ge
     float* x = ws; float* hhat = x + (size_t)B * DX; float* rstd = hhat + (size_t)B * D; float* partial = rstd + D;
     hipLaunchKernelGGL(head_x_kernel, dim3((B + 3) / 4), dim3(256), 0, st, cls, age, gender, p, x, B, ln_eps);
     MTMP_CHECK_LAUNCH("mtmp_head_fwd(x)");
-    hipLaunchKernelGGL(head_fc_kernel, dim3(D / FPW), dim3(256), 0, st, (const float*)x, p, hhat, rstd, partial, B, bn_eps,
-                       momentum, training);
+    const int R = rows_per_lane(B);
+    auto fc = R == 1 ? head_fc_kernel<1> : (R == 2 ? head_fc_kernel<2> : head_fc_kernel<4>);
+    hipLaunchKernelGGL(fc, dim3(D / FPW), dim3(256), 0, st, (const float*)x, p, hhat, rstd, partial, B, bn_eps, momentum, training);
     MTMP_CHECK_LAUNCH("mtmp_head_fwd(fc)");
-    hipLaunchKernelGGL(head_out_kernel, dim3(1), dim3(64), 0, st, (const float*)partial, p.b2, out, B);
+    hipLaunchKernelGGL(head_out_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, p.b2, out, B, 64 * R);
     MTMP_CHECK_LAUNCH("mtmp_head_fwd(out)");
     return MTMP_OK;
 }
@@ -274,8 +317,10 @@ extern "C" int mtmp_head_bwd(const float* d_out, const float* cls, const float* 
     hipStream_t st = (hipStream_t)stream;
     const float* x = ws_fwd; const float* hhat = x + (size_t)B * DX; const float* rstd = hhat + (size_t)B * D;
     float* dh = ws_bwd; float* slab = dh + (size_t)B * D;
-    hipLaunchKernelGGL(head_fc_bwd_kernel, dim3(D / FPW), dim3(256), 0, st, d_out, x, hhat, rstd, p, dh, dw1, g_feat,
-                       g_feat + D, g_feat + 2 * D, g_feat + 3 * D, db2, B, training);
+    const int R = rows_per_lane(B);
+    auto fcb = R == 1 ? head_fc_bwd_kernel<1> : (R == 2 ? head_fc_bwd_kernel<2> : head_fc_bwd_kernel<4>);
+    hipLaunchKernelGGL(fcb, dim3(D / FPW), dim3(256), 0, st, d_out, x, hhat, rstd, p, dh, dw1, g_feat, g_feat + D, g_feat + 2 * D,
+                       g_feat + 3 * D, db2, B, training);
     MTMP_CHECK_LAUNCH("mtmp_head_bwd(fc)");
     hipLaunchKernelGGL(head_x_bwd_kernel, dim3(B), dim3(256), 0, st, (const float*)dh, cls, age, gender, p, dcls, slab, ln_eps);
     MTMP_CHECK_LAUNCH("mtmp_head_bwd(x)");

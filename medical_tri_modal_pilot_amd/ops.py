@@ -434,7 +434,7 @@ class DataLinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- classification head (K10)
-HEAD_MAX_B = 64
+HEAD_MAX_B = 256        # rows per rank the head kernels take (csrc/head.hip: one, two or four rows per lane)
 
 
 class HeadFn(torch.autograd.Function):

@@ -300,10 +300,15 @@ def swin_window_attention(sd: SD, prefix: str, x: torch.Tensor, heads: int, shif
     return x[:, :H, :W, :].contiguous()
 
 
-def swin_forward(sd: SD, prefix: str, img: torch.Tensor) -> torch.Tensor:
-    """swin_transformer.py:559-618 + 621-654 (1-channel 4x4/4 stem), eval mode:
-    [B,1,224,224] -> [B,7,7,768] (final LayerNorm, no pooling/head)."""
+def swin_forward(sd: SD, prefix: str, img: torch.Tensor, row_scales=None) -> torch.Tensor:
+    """swin_transformer.py:559-618 + 621-654 (1-channel 4x4/4 stem): [B,1,224,224] -> [B,7,7,768] (final LayerNorm,
+    no pooling/head).  row_scales = None: eval mode.  Train mode (2_train.py:128 puts the frozen encoder back into it):
+    row_scales is a list of 12 (attention-branch, MLP-branch) pairs of float[B] factors -- the row-mode
+    StochasticDepth draws of swin_transformer.py:437,448-449 (torchvision.ops.stochastic_depth: each residual branch
+    of a sample is multiplied by bernoulli(1-p)/(1-p)), injected so that a test can give both sides the same draws."""
     p = prefix + "."
+    scales = iter(row_scales) if row_scales is not None else None
+    bc = lambda v: v.view(-1, 1, 1, 1)
     x = F.conv2d(img, sd[p + "features.0.0.weight"], sd[p + "features.0.0.bias"], stride=4)
     x = x.permute(0, 2, 3, 1)
     x = F.layer_norm(x, (x.shape[-1],), sd[p + "features.0.2.weight"], sd[p + "features.0.2.bias"], 1e-5)
@@ -312,11 +317,14 @@ def swin_forward(sd: SD, prefix: str, img: torch.Tensor) -> torch.Tensor:
         for blk in range(depth):
             bp = f"{p}features.{fi}.{blk}"
             C = x.shape[-1]
+            s_attn, s_mlp = next(scales) if scales is not None else (None, None)
             h = F.layer_norm(x, (C,), sd[bp + ".norm1.weight"], sd[bp + ".norm1.bias"], 1e-5)
-            x = x + swin_window_attention(sd, bp + ".attn", h, heads, 0 if blk % 2 == 0 else SWIN_WS // 2)
+            a = swin_window_attention(sd, bp + ".attn", h, heads, 0 if blk % 2 == 0 else SWIN_WS // 2)
+            x = x + (a if s_attn is None else bc(s_attn) * a)
             h = F.layer_norm(x, (C,), sd[bp + ".norm2.weight"], sd[bp + ".norm2.bias"], 1e-5)
             h = F.gelu(F.linear(h, sd[bp + ".mlp.0.weight"], sd[bp + ".mlp.0.bias"]))
-            x = x + F.linear(h, sd[bp + ".mlp.3.weight"], sd[bp + ".mlp.3.bias"])
+            f = F.linear(h, sd[bp + ".mlp.3.weight"], sd[bp + ".mlp.3.bias"])
+            x = x + (f if s_mlp is None else bc(s_mlp) * f)
         if stage < len(SWIN_DEPTHS) - 1:                                    # PatchMerging :60-85
             mp = f"{p}features.{fi + 1}"
             Hh, Ww = x.shape[1], x.shape[2]

@@ -26,7 +26,8 @@ DEV = "cuda:0"
 
 
 def _rel(a, b):
-    """max |a-b| / (max|b| + tiny): error relative to the tensor's scale."""
+    """max |a-b| / (max|b| + tiny): error relative to the tensor's scale (a max-norm relative error, NOT element-wise:
+    small entries of a tensor are held to the scale of its largest one; the full-step test adds an element-wise check)."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
@@ -411,7 +412,7 @@ def test_time_embed_and_data_linear_vs_torch(ops, dt):
 
 
 @pytest.mark.parametrize("training", [True, False])
-@pytest.mark.parametrize("B", [64, 5])
+@pytest.mark.parametrize("B", [64, 5, 128, 200])
 def test_head_vs_torch_modules(ops, training, B):
     """K10 (tri_mbt_vsltcls.py:59-76 ie_demo + :248-255 head): six HIP launches against the torch modules
     (Linear, LayerNorm, BatchNorm1d with its running statistics, ReLU), forward, every gradient, running stats."""
@@ -583,6 +584,41 @@ def test_swin_ln_linear_fused_vs_chain_and_torch(ops, C, rows):
         t = f"swin_ln_linear[C={C},rows={rows},bias={bias is not None}]"
         check(t + ".vs_chain", y.float(), chain.float(), 1e-2)
         check(t + ".vs_torch_fp32", y.float(), ref, 2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_swin_train_mode_stochastic_depth_vs_oracle(ops, dtype, monkeypatch):
+    """model.train() re-activates the frozen encoder's row-mode StochasticDepth (2_train.py:128 overrides the .eval() of
+    tri_mbt_vsltcls.py:104).  RNG streams cannot match across devices, so the same 24 draws are injected on both sides:
+    the product applies them in the projection GEMMs' epilogues (and splits stages 3-4 over two streams), the oracle
+    multiplies each residual branch (torchvision.ops.stochastic_depth, mode "row")."""
+    import medical_tri_modal_pilot_amd.builder.models.src.swin_transformer as sw
+    _, model = _product_model(2, 0, dtype)
+    enc = model.img_encoder
+    enc.train()
+    n = 16
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(n, 1, 224, 224, generator=g)
+    mods = [m for m in enc.modules() if isinstance(m, sw.StochasticDepth)]
+    assert len(mods) == 12 and mods[0].p == 0.0 and abs(mods[-1].p - 0.2) < 1e-12
+    pairs = []
+    for m in mods:
+        keep = 1.0 - m.p
+        if m.p == 0.0:
+            pairs.append((None, None))
+            continue
+        sa = (torch.rand(n, generator=g) < keep).float() / keep
+        sm = (torch.rand(n, generator=g) < keep).float() / keep
+        pairs.append((sa, sm))
+        m._predrawn = [sm.to(DEV), sa.to(DEV)]             # popped in call order: attention branch, then MLP
+    assert any(float(sa.min()) == 0.0 for sa, _ in pairs if sa is not None)      # some branch is really dropped
+    monkeypatch.setattr(sw, "draw_row_scales", lambda *a, **k: None)              # keep the injected draws
+    streams = model.fusion_transformer._side_streams(torch.device(DEV))
+    with torch.no_grad():
+        feat = enc(img.to(DEV), tail_streams=(streams[0], streams[1]))
+    torch.cuda.synchronize()
+    ref = O.swin_forward(_model_sd(2), "img_encoder", img, row_scales=pairs)
+    check(f"swin_train_stochastic_depth[{dtype}].features", feat.float(), ref, 2e-4 if dtype == "fp32" else 6e-2)
 
 
 def test_swin_tail_split_equals_single_stream(ops):
@@ -778,20 +814,28 @@ def test_full_training_step_fp32_vs_golden(ops, multi, tag, fused):
     # on noise-sized elements the sign is arbitrary, so parameters may differ by up to 2*lr.
     med = float(np.median(Gd["grad_digest"][:, 0]))
     lr1 = 1e-6
-    worst_g = worst_p = 0.0
+    worst_g = worst_p = worst_e = 0.0
     for n_, gd, pd in zip(names, Gd["grad_digest"], Gd["param_digest"]):
         got_g, got_p = _digest(grads[n_]), _digest(params1[n_])
         if gd[0] < 1e-4 * med:
             assert float(got_g[0]) < 1e-3 * med, f"grad {n_} should be ~0, norm {float(got_g[0])}"
         else:
-            eg = _rel(got_g, torch.from_numpy(gd))
+            ref_g = torch.from_numpy(gd)
+            eg = _rel(got_g, ref_g)
             worst_g = max(worst_g, eg)
-            assert eg < 2e-3, f"grad {n_}: {eg}"
+            assert eg < 1e-4, f"grad {n_}: {eg}"                 # north_star: 1e-4 forward + backward (max-norm relative)
+            # ... and element by element on the sampled entries that are not small against the tensor's own scale
+            big = ref_g[1:].abs() > 0.05 * ref_g[1:].abs().max()
+            if bool(big.any()):
+                ee = float(((got_g[1:] - ref_g[1:]).abs() / ref_g[1:].abs())[big].max())
+                worst_e = max(worst_e, ee)
+                assert ee < 1e-3, f"grad {n_}: element-wise relative error {ee}"
         dp = float((got_p[1:] - torch.from_numpy(pd)[1:]).abs().max())
         worst_p = max(worst_p, dp)
         assert dp <= 2.2 * lr1, f"param {n_}: |diff| {dp}"
         assert abs(float(got_p[0]) - pd[0]) <= 1e-5 * pd[0] + 1e-9, f"param norm {n_}"
-    REPORT[t + ".worst_grad_digest"] = {"rel_err": worst_g, "tol": 2e-3}
+    REPORT[t + ".worst_grad_digest"] = {"rel_err": worst_g, "tol": 1e-4}
+    REPORT[t + ".worst_grad_elementwise"] = {"rel_err": worst_e, "tol": 1e-3}
     REPORT[t + ".worst_param_abs_diff_after_adamw"] = {"rel_err": worst_p, "tol": 2.2 * lr1}
     assert abs(loss2 - float(Gd["loss2"])) < 1e-4
     assert abs(tl - float(Gd["test_loss"])) < 1e-4
@@ -936,6 +980,54 @@ def test_vsltonly0_training_step_vs_oracle(ops):
     for n, p in model.named_parameters():          # untouched: the skipped blocks (no weight decay either) and the frozen Swin
         if n not in hot:
             assert torch.equal(p.detach(), before[n]), n
+
+
+def test_cfg5_shape_four_images_twelve_layers_vs_oracle(ops):
+    """BASELINE configs[4] structure at a size the CPU oracle finishes in seconds: --multiimages 1 generalised to
+    --n-images 4 (the reference hard-codes 3, tri_mbt_vsltcls.py:161-162,226-231), 12 fusion layers, ragged vital-sign
+    series, one absent image slot per sample at most.  fp32 build, two train steps against the oracle; the image
+    stream's valid-key counts (4 + 1 + 49 * #present) are bit-exact."""
+    from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    L, K, B, T = 12, 4, 2, 40
+    args, model = _product_model(L, 1, "fp32", hip_graph=0, n_images=K, batch_size=B)
+    assert model.n_images == K
+    model.train()
+    model.img_encoder.eval()
+    opt = FusedAdamW(model.hot_parameters(), lr=args.lr_init, weight_decay=args.weight_decay)
+    sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=args.t_0 * 10, cycle_mult=args.t_mult,
+                                          max_lr=args.lr_init * math.sqrt(args.batch_size), min_lr=1e-6,
+                                          warmup_steps=args.t_up * 10, gamma=args.gamma)
+    bt = filler.make_batch(777, B, T, multiimages=1, n_images=K, missing_mode="none")
+    assert bt["img"].shape == (B, K, 1, 224, 224) and bt["img_time"].shape == (B, K)
+    # valid image keys per sample, as the encoder derives them (integer artefact: bit-exact)
+    present = (bt["img_time"] != 10).sum(1)
+    lens = model.fusion_transformer.key_lengths([bt["input_lengths"], present * 49, bt["txt_lengths"] + 2], "cpu")
+    assert torch.equal(lens[1], present * 49 + 1)
+    static = torch.stack([bt["gen"], bt["age"]], 1)
+    kw = dict(args=args, x=bt["x"], static=static, y=bt["y"], output_lengths=None, model=model, logger=_Logger(),
+              device=torch.device(DEV), scheduler=sched, optimizer=opt, criterion=torch.nn.BCEWithLogitsLoss(),
+              x_txt=bt["txt"], x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None,
+              missing=bt["missing"], reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+    _, loss1 = get_trainer(iteration=1, input_lengths=bt["input_lengths"].clone(), txt_lengths=bt["txt_lengths"].clone(),
+                           flow_type="train", **kw)
+    grads = {n: p.grad.detach().clone() for n, p in model.hot_parameters()}
+    _, loss2 = get_trainer(iteration=2, input_lengths=bt["input_lengths"].clone(), txt_lengths=bt["txt_lengths"].clone(),
+                           flow_type="train", **kw)
+    tr = O.OracleTrainer(_model_sd(L), O.Cfg(n_layers=L, multiimages=1), lr_init=args.lr_init, batch_size=args.batch_size,
+                         iters_per_epoch=10)
+    ref1 = tr.step(bt, 1)
+    ref_grads = {k: v.clone() for k, v in tr.grads.items()}
+    ref2 = tr.step(bt, 2)
+    REPORT["cfg5_k4_L12[fp32].loss1"] = {"rel_err": abs(loss1 - ref1), "tol": 1e-4}
+    REPORT["cfg5_k4_L12[fp32].loss2"] = {"rel_err": abs(loss2 - ref2), "tol": 1e-4}
+    assert abs(loss1 - ref1) < 1e-4 and abs(loss2 - ref2) < 1e-4, (loss1, ref1, loss2, ref2)
+    assert sorted(ref_grads) == sorted(grads)
+    med = float(np.median([float(v.norm()) for v in ref_grads.values()]))
+    worst = max(_rel(grads[n], g) for n, g in ref_grads.items() if float(g.norm()) >= 1e-4 * med)
+    REPORT["cfg5_k4_L12[fp32].worst_grad"] = {"rel_err": worst, "tol": 2e-4}
+    assert worst < 2e-4
 
 
 def test_cfg1_sample_data_windows_product_vs_oracle(ops):
