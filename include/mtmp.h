@@ -218,7 +218,9 @@ int mtmp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
  * prev [B,4,256] fp32 (mbt_encoder.py:741-742,778-779).  keep (may be NULL) receives the fp32 result.
  * _bwd transforms the gradient buffers dz_m the same way in place: rows 0..3 hold the consumers'
  * gradients on entry and each stream's own bottleneck-output gradient on exit; d_prev_in (may be NULL) /
- * d_prev_out carry the residual path between consecutive exchanges. */
+ * d_prev_out carry the residual path between consecutive exchanges.
+ * z_t / dz_t may be NULL: the two-stream encoder (BimodalTransformerEncoder_MBT, mbt_encoder.py:519-634), whose
+ * patterns {0: mean of both, 1: stream 0} the caller passes as rows 1 and 3. */
 int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, void* z_t, int B, int n_v, int n_i, int n_t,
                                  const long long* missing, int resbottle, const float* prev, float* keep, void* stream);
 int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, int B, int n_v, int n_i, int n_t,

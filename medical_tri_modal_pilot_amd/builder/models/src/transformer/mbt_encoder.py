@@ -1,5 +1,5 @@
-"""TrimodalTransformerEncoder_MBT -- host orchestration of the modality-aware bottleneck
-fusion (reference: builder/models/src/transformer/mbt_encoder.py:636-784).
+"""TrimodalTransformerEncoder_MBT (and the two-stream BimodalTransformerEncoder_MBT) -- host orchestration of the
+modality-aware bottleneck fusion (reference: builder/models/src/transformer/mbt_encoder.py:636-784 and :519-634).
 
 Same constructor, parameter names and forward contract as the reference.  What differs is
 how the work reaches the GPU:
@@ -169,3 +169,97 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         if self.vsltonly == 1:
             return [out_v[:, nb:]], 0
         return [out_v[:, nb:], out_i[:, nb:], out_t[:, nb:]], 0
+
+
+class BimodalTransformerEncoder_MBT(nn.Module):
+    """Two-stream bottleneck fusion (reference: builder/models/src/transformer/mbt_encoder.py:519-634).
+
+    Same constructor, parameter names and forward contract as the reference.  EVERY layer is a fusion layer (the
+    reference's uni-modal branch is commented out, :610-615, so ``fusion_startidx`` is stored and ignored like there);
+    after each layer the bottleneck tokens become the mean of both streams' (``missing == 0``) or stream 0's alone
+    (``missing == 1``), :629-632.  Runs on the same explicit-buffer engine as the three-stream encoder
+    (ops.FusionStackFn with ``n_streams=2``; the exchange kernel reads its weight-table rows 1 and 3)."""
+
+    def __init__(self, batch_size: int, n_modality: int, bottlenecks_n: int, fusion_startidx: int, d_input: int,
+                 n_layers: int, n_head: int, d_model: int, d_ff: int, dropout: float = 0.1, pe_maxlen: int = 10000,
+                 txt_idx: int = 2, mbt_bottlenecks_type: str = "skip", use_pe: list = [True, True],
+                 mask: list = [True, True], compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        if n_modality != 2:
+            raise ValueError("BimodalTransformerEncoder_MBT consumes exactly two streams (the reference builds n_modality "
+                             "CLS tokens and layer blocks but sets self.n_modality = 2, mbt_encoder.py:547)")
+        self.mbt_bottlenecks_type = mbt_bottlenecks_type
+        self.use_pe, self.mask = use_pe, mask
+        self.n_modality = 2
+        self.fusion_idx, self.txt_idx = fusion_startidx, txt_idx
+        self.n_layers, self.d_model, self.bottlenecks_n = n_layers, d_model, bottlenecks_n
+        self.compute_dtype = compute_dtype
+        self.idx_order = torch.arange(0, batch_size).type(torch.LongTensor)
+        self.layer_norms_after_concat = nn.LayerNorm(self.d_model)       # unused by forward, kept for state_dict parity
+        self.cls_token_per_modality = nn.ParameterList(
+            [nn.Parameter(torch.randn(1, 1, d_model)) for _ in range(n_modality)])
+        self.bottlenecks = nn.Parameter(torch.randn(1, bottlenecks_n, d_model))
+        self.layer_norms_in = nn.ModuleList([nn.LayerNorm(d_model) for _ in range(n_modality)])
+        self.positional_encoding = PositionalEncoding(d_model, max_len=pe_maxlen)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_stacks = nn.ModuleList(nn.ModuleList([
+            TransformerEncoderLayer(d_model=d_model, num_heads=n_head, d_ff=d_ff, dropout_p=dropout)
+            for _ in range(n_modality)]) for _ in range(n_layers))
+
+    _side_streams = TrimodalTransformerEncoder_MBT._side_streams
+
+    def key_lengths(self, varying_lengths, device) -> List[Optional[torch.Tensor]]:
+        """Valid tokens per stream including CLS (:583-591): +1; stream ``txt_idx``: 3 -> 0; None when unmasked."""
+        out = []
+        for m in range(2):
+            if not self.mask[m]:
+                out.append(None)
+                continue
+            v = torch.as_tensor(varying_lengths[m], device=device).to(torch.int64) + 1
+            if m == self.txt_idx:
+                v = torch.where(v == 3, torch.zeros_like(v), v)
+            out.append(v)
+        return out
+
+    def forward(self, enc_outputs, fixed_lengths=None, varying_lengths=None, return_attns=False, fusion_idx=None,
+                missing=None):
+        if len(enc_outputs) != 2:
+            raise ValueError("BimodalTransformerEncoder_MBT takes two streams")
+        dev, dt = enc_outputs[0].device, self.compute_dtype
+        if fusion_idx is not None:
+            self.fusion_idx = fusion_idx
+        lens = self.key_lengths(varying_lengths, dev)
+        pdrop = self.dropout.p if self.training else 0.0
+        streams = []
+        for m, x in enumerate(enc_outputs):                                   # (:575-607) CLS, LayerNorm (+PE), dropout
+            ln = self.layer_norms_in[m]
+            pe = self.positional_encoding(x.size(1) + 1) if self.use_pe[m] else None
+            seed = next_dropout_seed() if pdrop > 0 else 0
+            streams.append(ops.StreamInputFn.apply(x.to(dt), self.cls_token_per_modality[m], ln.weight, ln.bias, pe,
+                                                   self.bottlenecks, ln.eps, pdrop, seed))
+        kv = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
+        # missing 0 -> table row 1 (0.5, 0.5, 0), missing 1 -> row 3 (1, 0, 0); anything else is out of bounds for the
+        # reference's two candidates (:631) and stays out of bounds for the kernel's host check
+        missing = missing.to(dev).long()
+        if missing.numel() and (int(missing.max()) > 1 or int(missing.min()) < 0):
+            raise IndexError("BimodalTransformerEncoder_MBT: missing must be 0 (both streams) or 1 (stream 0 only)")
+        pattern = 1 + 2 * missing
+        fl = list(self.layer_stacks)
+        all_fused = iter(type(fl[0][0]).fused_weights_of([layer for layers in fl for layer in layers], dt))
+        params, fused, seeds, p = [], [], [], 0.0
+        for layers in fl:
+            frow, srow = [], []
+            for layer in layers:
+                params += layer.param_list()
+                frow.append(next(all_fused))
+                p, sd = layer.dropout_args()
+                srow.append(sd)
+            fused.append(frow)
+            seeds.append(srow)
+        sinks = [[layer.grad_sink() for layer in layers] for layers in fl] if torch.is_grad_enabled() else None
+        cfg = dict(n_layers=len(fl), n_streams=2, vsltonly=0, resbottle=False, kv=kv + [None], sinks=sinks, prebuilt=True,
+                   final=True, bott_rows_unused=True, missing=pattern, drop_p=p, seeds=seeds, fused=fused, dtype=dt,
+                   side_streams=self._side_streams(dev))
+        out0, out1, _, _ = ops.FusionStackFn.apply(streams[0], streams[1], None, self.bottlenecks, *params, cfg)
+        nb = self.bottlenecks_n
+        return [out0[:, nb:], out1[:, nb:]], 0

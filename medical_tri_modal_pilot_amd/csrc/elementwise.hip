@@ -583,12 +583,15 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel
     const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
     float v = __fmul_rn(to_f32(p.z[0][b * p.bstride[0] + o]), kExchangeW[pat][0]);
     v = __fadd_rn(v, __fmul_rn(to_f32(p.z[1][b * p.bstride[1] + o]), kExchangeW[pat][1]));
-    v = __fadd_rn(v, __fmul_rn(to_f32(p.z[2][b * p.bstride[2] + o]), kExchangeW[pat][2]));
+    // two-stream encoder (BimodalTransformerEncoder_MBT, mbt_encoder.py:629-632): z[2] is NULL and the caller maps its
+    // patterns {0: mean of both, 1: stream 0} onto rows {1, 3} of the table, whose third weight is 0
+    if (p.z[2]) v = __fadd_rn(v, __fmul_rn(to_f32(p.z[2][b * p.bstride[2] + o]), kExchangeW[pat][2]));
     if (p.resbottle) v = __fmul_rn(__fadd_rn(v, p.prev[ko]), 0.5f);
     if (p.keep) p.keep[ko] = v;
     const T t = from_f32<T>(v);
 #pragma unroll
-    for (int m = 0; m < 3; ++m) p.z[m][b * p.bstride[m] + o] = t;
+    for (int m = 0; m < 3; ++m)
+        if (p.z[m]) p.z[m][b * p.bstride[m] + o] = t;
 }
 
 // z[m] hold dL/d(input of the next layer): rows 0..3 are the gradients w.r.t. the exchanged tokens as seen by
@@ -600,14 +603,15 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_bwd_kernel
     const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
     float d = to_f32(p.z[0][b * p.bstride[0] + o]);
     d = __fadd_rn(d, to_f32(p.z[1][b * p.bstride[1] + o]));
-    d = __fadd_rn(d, to_f32(p.z[2][b * p.bstride[2] + o]));
+    if (p.z[2]) d = __fadd_rn(d, to_f32(p.z[2][b * p.bstride[2] + o]));
     if (p.d_prev_in) d = __fadd_rn(d, p.d_prev_in[ko]);
     if (p.resbottle) {
         d = __fmul_rn(d, 0.5f);
         p.d_prev_out[ko] = d;
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) p.z[m][b * p.bstride[m] + o] = from_f32<T>(__fmul_rn(d, kExchangeW[pat][m]));
+    for (int m = 0; m < 3; ++m)
+        if (p.z[m]) p.z[m][b * p.bstride[m] + o] = from_f32<T>(__fmul_rn(d, kExchangeW[pat][m]));
 }
 
 }  // namespace
@@ -618,7 +622,7 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_bwd_kernel
 extern "C" int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, void* z_t, int B, int n_v, int n_i, int n_t,
                                             const long long* missing, int resbottle, const float* prev, float* keep,
                                             void* stream) {
-    MTMP_CHECK_ARG(z_v && z_i && z_t && missing && B > 0 && n_v >= 4 && n_i >= 4 && n_t >= 4 && (!resbottle || prev),
+    MTMP_CHECK_ARG(z_v && z_i && missing && B > 0 && n_v >= 4 && n_i >= 4 && (!z_t || n_t >= 4) && (!resbottle || prev),
                    "mtmp_bottleneck_exchange_fwd: bad argument (B=%d rows %d/%d/%d)", B, n_v, n_i, n_t);
     if (dtype == 0) {
         ExchangeArgs<float> a{{(float*)z_v, (float*)z_i, (float*)z_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
@@ -641,7 +645,7 @@ extern "C" int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, voi
 extern "C" int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, int B, int n_v, int n_i, int n_t,
                                             const long long* missing, int resbottle, const float* d_prev_in,
                                             float* d_prev_out, void* stream) {
-    MTMP_CHECK_ARG(dz_v && dz_i && dz_t && missing && B > 0 && n_v >= 4 && n_i >= 4 && n_t >= 4 && (!resbottle || d_prev_out),
+    MTMP_CHECK_ARG(dz_v && dz_i && missing && B > 0 && n_v >= 4 && n_i >= 4 && (!dz_t || n_t >= 4) && (!resbottle || d_prev_out),
                    "mtmp_bottleneck_exchange_bwd: bad argument (B=%d rows %d/%d/%d)", B, n_v, n_i, n_t);
     if (dtype == 0) {
         ExchangeArgs<float> a{{(float*)dz_v, (float*)dz_i, (float*)dz_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},

@@ -280,17 +280,17 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, 
 
 def bottleneck_exchange_fwd(z, missing, resbottle=False, prev=None, keep=None):
     """In place on z = [z_v, z_i, z_t] ([B, n_m, 256] contiguous): rows 0..3 <- exchanged bottleneck tokens."""
-    _gpu(*z)
+    _gpu(*[t for t in z if t is not None])
     B = z[0].shape[0]
     call("mtmp_bottleneck_exchange_fwd", _dt(z[0]), _p(z[0]), _p(z[1]), _p(z[2]), B, z[0].shape[1], z[1].shape[1],
-         z[2].shape[1], _p(missing), int(bool(resbottle)), _p(prev), _p(keep), _stream())
+         0 if z[2] is None else z[2].shape[1], _p(missing), int(bool(resbottle)), _p(prev), _p(keep), _stream())
 
 
 def bottleneck_exchange_bwd(dz, missing, resbottle=False, d_prev_in=None, d_prev_out=None):
-    _gpu(*dz)
+    _gpu(*[t for t in dz if t is not None])
     B = dz[0].shape[0]
     call("mtmp_bottleneck_exchange_bwd", _dt(dz[0]), _p(dz[0]), _p(dz[1]), _p(dz[2]), B, dz[0].shape[1], dz[1].shape[1],
-         dz[2].shape[1], _p(missing), int(bool(resbottle)), _p(d_prev_in), _p(d_prev_out), _stream())
+         0 if dz[2] is None else dz[2].shape[1], _p(missing), int(bool(resbottle)), _p(d_prev_in), _p(d_prev_out), _stream())
 
 
 def sink_param_grads(params, grads):
@@ -698,6 +698,8 @@ class FusionStackFn(torch.autograd.Function):
         bottleneck exchange like every inner layer, returns no CLS vector, and its three output buffers are the next
         node's prebuilt inputs -- the trainer captures the backward of each node in its own hipGraph so that the
         gradient all-reduce of the later layers overlaps the backward of the earlier ones (ddp.GradReducer, staged mode).
+      n_streams (default 3): 2 = the two-stream encoder (BimodalTransformerEncoder_MBT, mbt_encoder.py:519-634): xt is
+        None, layer_params hold two blocks per layer, and ``missing`` carries table rows 1 (mean of both) / 3 (stream 0).
       bott_rows_unused: the caller never reads rows 0..3 of the outputs (mbt_encoder.py slices them off), so with
         vsltonly == 0 and no gradient for the image / text outputs the last layer's image / text blocks get no
         backward at all (in the reference their gradient is None, not zero).
@@ -711,7 +713,8 @@ class FusionStackFn(torch.autograd.Function):
         final = cfg.get("final", True)
         if not final and (not cfg.get("prebuilt") or cfg["resbottle"]):
             raise ValueError("a non-final FusionStackFn segment needs prebuilt inputs and resbottle off")
-        xs = [xv, xi, xt]
+        n_s = cfg.get("n_streams", 3)
+        xs = [xv, xi, xt][:n_s]
         _gpu(xv)
         B, dev = xv.shape[0], xv.device
         if cfg.get("prebuilt"):            # xs ARE the [B, 4+N, 256] buffers (ops.StreamInputFn); read, never written
@@ -725,6 +728,7 @@ class FusionStackFn(torch.autograd.Function):
                 buf[:, NB:] = x
                 buf[:, :NB] = bott.to(dt)
                 z.append(buf)
+        Ns, z = Ns + [0] * (3 - n_s), z + [None] * (3 - n_s)
         wsel = _exchange_w(dev)
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
@@ -732,14 +736,14 @@ class FusionStackFn(torch.autograd.Function):
         prev_bott = bott.expand(B, -1, -1).float().contiguous() if cfg["resbottle"] else None
         for li in range(L):
             last = final and cfg["vsltonly"] == 1 and li == L - 1
-            ms = [0] if last else [0, 1, 2]
+            ms = [0] if last else list(range(n_s))
             outs = [None, None, None]
             row = [None, None, None]
             if streams is not None and len(ms) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
             for m in ms:
-                P = params[(li * 3 + m) * PARAMS_PER_LAYER:(li * 3 + m + 1) * PARAMS_PER_LAYER]
+                P = params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER]
                 if streams is not None and m > 0:
                     s = streams[m - 1]
                     s.wait_event(ev)
@@ -786,12 +790,13 @@ class FusionStackFn(torch.autograd.Function):
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
         n_run = len(saved)
+        n_s = cfg.get("n_streams", 3)
         final = cfg.get("final", True)
         # vsltonly == 0: the last layer ran all three streams, but when nothing downstream read the image / text outputs
         # (and nobody reads the exchanged bottleneck rows) their blocks have no gradient: run the backward of the last
         # layer like the vslt-only one (the reference's autograd never reaches those blocks either)
         if (final and cfg["vsltonly"] != 1 and d_i is None and d_t is None and cfg.get("bott_rows_unused")
-                and not cfg["resbottle"] and len(active[-1]) == 3):
+                and not cfg["resbottle"] and len(active[-1]) == n_s):
             active = active[:-1] + [[0]]
             skip_last_exchange = True
         else:
@@ -830,7 +835,7 @@ class FusionStackFn(torch.autograd.Function):
                     mark(f"b{li}.m{m}.s")
                     nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
                     mark(f"b{li}.m{m}.e")
-                base = (li * 3 + m) * PARAMS_PER_LAYER
+                base = (li * n_s + m) * PARAMS_PER_LAYER
                 if g is not None:
                     for k in range(PARAMS_PER_LAYER):
                         pgrads[base + k] = g[k].view(pshapes[base + k])
@@ -840,7 +845,7 @@ class FusionStackFn(torch.autograd.Function):
             saved[li] = None
             # streams skipped by the vslt-only last layer re-enter here with zero gradient
             if len(ms) == 1 and li > 0:
-                for m in (1, 2):
+                for m in range(1, n_s):
                     nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
             dz = nxt
         if cfg.get("prebuilt"):            # the bottleneck rows' gradient flows on through the stream-input nodes

@@ -228,6 +228,42 @@ def mbt_encoder(sd: SD, prefix: str, streams: Sequence[torch.Tensor],
     return ys, bott
 
 
+def mbt_encoder_bimodal(sd: SD, prefix: str, streams: Sequence[torch.Tensor], varying_lengths: Sequence[torch.Tensor],
+                        missing: torch.Tensor, *, n_layers: int, n_head: int, txt_idx: int = 2,
+                        use_pe=(True, True), mask=(True, True), dropout_p: float = 0.0, training: bool = False):
+    """BimodalTransformerEncoder_MBT.forward (mbt_encoder.py:575-634): two streams, EVERY layer is a fusion layer
+    (the uni-modal branch is commented out, :610-615), bottleneck candidates = (mean of both, stream 0 alone) picked
+    by ``missing`` in {0, 1} (:629-632).  ``varying_lengths`` as the caller passes them (before the +1 of :584)."""
+    B, d = streams[0].shape[0], streams[0].shape[-1]
+    p = prefix + "." if prefix else ""
+    xs = [torch.cat([sd[f"{p}cls_token_per_modality.{m}"].expand(B, 1, d), s], 1) for m, s in enumerate(streams)]
+    kv = []
+    for m in range(2):
+        v = varying_lengths[m].clone() + 1                                     # (:584)
+        if m == txt_idx:
+            v[v == 3] = 0                                                      # (:586-587)
+        kv.append(v + N_BOTTLENECK if mask[m] else None)                       # (:621)
+    ys = []
+    for m, x in enumerate(xs):                                                 # (:596-607)
+        y = F.layer_norm(x, (d,), sd[f"{p}layer_norms_in.{m}.weight"], sd[f"{p}layer_norms_in.{m}.bias"], 1e-5)
+        if use_pe[m]:
+            y = y + sinusoid_table(x.shape[1], d).unsqueeze(0)
+        ys.append(F.dropout(y, dropout_p, training))
+    bott = sd[f"{p}bottlenecks"].expand(B, N_BOTTLENECK, d)
+    idx = torch.arange(B)
+    for layer in range(n_layers):
+        xs, ys, b_out = ys, [], []
+        for m in range(2):
+            z = torch.cat([bott, xs[m]], 1)                                    # (:618)
+            km = None if kv[m] is None else key_pad_mask(z.shape[1], kv[m])
+            o = encoder_layer(sd, f"{p}layer_stacks.{layer}.{m}", z, km, n_head, dropout_p, training)
+            b_out.append(o[:, :N_BOTTLENECK])
+            ys.append(o[:, N_BOTTLENECK:])
+        st = torch.stack(b_out)
+        bott = torch.stack([st.mean(0), st[0]])[missing, idx]                  # (:629-632)
+    return ys, bott
+
+
 # --------------------------------------------------------------------------
 # Swin-T forward (eval; frozen, no_grad in the model) -- swin_transformer.py
 # --------------------------------------------------------------------------

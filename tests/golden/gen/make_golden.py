@@ -158,6 +158,46 @@ def gen_encoder():
     save("encoder", **out)
 
 
+def gen_bimodal():
+    """BimodalTransformerEncoder_MBT (mbt_encoder.py:519-634): forward outputs of the real class and the
+    gradients of a scalar of them w.r.t. both inputs and three parameters, for the four (mask, use_pe / txt_idx)
+    combinations a two-stream model can ask for."""
+    from builder.models.src.transformer.mbt_encoder import BimodalTransformerEncoder_MBT
+    out = {}
+    B, T, L = 4, 20, 3
+    case = 0
+    for mask1 in (True, False):
+        for txt_idx, pe1 in ((1, True), (2, False)):
+            g = torch.Generator().manual_seed(300 + case)
+            enc = BimodalTransformerEncoder_MBT(batch_size=B, n_modality=2, bottlenecks_n=4, fusion_startidx=0,
+                                                d_input=256, n_layers=L, n_head=4, d_model=256, d_ff=1024, dropout=0.0,
+                                                pe_maxlen=2500, txt_idx=txt_idx, use_pe=[False, pe1], mask=[True, mask1])
+            enc.eval()
+            load_filled(enc, "g5.")
+            v = torch.randn(B, T, 256, generator=g).requires_grad_()
+            t = torch.randn(B, 30, 256, generator=g).requires_grad_()
+            in_len = torch.tensor([T, 3, 11, 7])
+            txt_len = torch.tensor([20, 0, 5, 0])
+            missing = torch.tensor([0, 1, 1, 0])
+            outs, _ = enc(enc_outputs=[v, t], fixed_lengths=[T, 30], varying_lengths=[in_len.clone(), txt_len + 2],
+                          fusion_idx=None, missing=missing)
+            w0 = torch.randn(outs[0].shape, generator=g)
+            w1 = torch.randn(outs[1].shape, generator=g)
+            ((outs[0] * w0).sum() + (outs[1] * w1).sum()).backward()
+            tag = f"c{case}"
+            out[tag + "_cfg"] = np.array([int(mask1), txt_idx, int(pe1), B, T, L])
+            out[tag + "_out0"] = outs[0]
+            out[tag + "_out1"] = outs[1][:, ::7]
+            out[tag + "_dv"] = v.grad[:, ::ROWSTEP]
+            out[tag + "_dt"] = t.grad[:, ::ROWSTEP]
+            out[tag + "_dbott"] = enc.bottlenecks.grad
+            out[tag + "_dw1"] = digest(enc.layer_stacks[1][1].feed_forward.w_1.weight.grad)
+            out[tag + "_dwq"] = digest(enc.layer_stacks[0][0].self_attention.query_proj.linear.weight.grad)
+            case += 1
+    out["n_cases"] = np.array(case)
+    save("bimodal", **out)
+
+
 # ------------------------------------------------------------------------ g6
 def build_model(args):
     from builder.models import get_model
@@ -316,12 +356,14 @@ def gen_misc():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "encoder", "model", "misc", "shapes"]
+    which = sys.argv[1:] or ["blocks", "encoder", "bimodal", "model", "misc", "shapes"]
     ref_args()
     if "blocks" in which:
         gen_blocks()
     if "encoder" in which:
         gen_encoder()
+    if "bimodal" in which:
+        gen_bimodal()
     if "misc" in which:
         gen_misc()
     if "model" in which:

@@ -98,15 +98,15 @@ def test_custom_layernorm_and_layer(golden_dir):
     np.testing.assert_allclose(sd["L.attention_prenorm.gamma"].grad.numpy(), G["lay_dgamma_attn"], rtol=2e-4, atol=2e-4)
 
 
-def encoder_keys(L):
+def encoder_keys(L, n_mod=3):
     keys = {"layer_norms_after_concat.weight": (256,), "layer_norms_after_concat.bias": (256,),
             "bottlenecks": (1, 4, 256), "positional_encoding.pe": (1, 2500, 256)}
-    for m in range(3):
+    for m in range(n_mod):
         keys[f"cls_token_per_modality.{m}"] = (1, 1, 256)
         keys[f"layer_norms_in.{m}.weight"] = (256,)
         keys[f"layer_norms_in.{m}.bias"] = (256,)
     for l in range(L):
-        for m in range(3):
+        for m in range(n_mod):
             p = f"layer_stacks.{l}.{m}."
             for n in ("attention_prenorm", "feed_forward_prenorm"):
                 keys[p + n + ".gamma"] = (256,)
@@ -147,6 +147,34 @@ def test_mbt_encoder_all_variants(golden_dir):
             ref = G[f"c{case}_out{m}"]
             got = o if m == 0 else o[:, ::7]
             np.testing.assert_allclose(got.numpy(), ref, rtol=1e-4, atol=2e-5, err_msg=f"case {case} stream {m}")
+
+
+def test_bimodal_mbt_encoder(golden_dir):
+    """the restated BimodalTransformerEncoder_MBT against outputs and gradients of the real class."""
+    G = _g(golden_dir, "bimodal")
+    n = int(G["n_cases"])
+    assert n == 4
+    for case in range(n):
+        mask1, txt_idx, pe1, B, T, L = [int(v) for v in G[f"c{case}_cfg"]]
+        sd = {"f." + k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(".pe"))
+              for k, v in _filled(encoder_keys(L, 2), "g5.").items()}
+        g = torch.Generator().manual_seed(300 + case)
+        v = torch.randn(B, T, 256, generator=g).requires_grad_()
+        t = torch.randn(B, 30, 256, generator=g).requires_grad_()
+        in_len, txt_len = torch.tensor([T, 3, 11, 7]), torch.tensor([20, 0, 5, 0])
+        outs, _ = O.mbt_encoder_bimodal(sd, "f", [v, t], [in_len, txt_len + 2], torch.tensor([0, 1, 1, 0]), n_layers=L,
+                                        n_head=4, txt_idx=txt_idx, use_pe=(False, bool(pe1)), mask=(True, bool(mask1)))
+        np.testing.assert_allclose(outs[0].detach().numpy(), G[f"c{case}_out0"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(outs[1][:, ::7].detach().numpy(), G[f"c{case}_out1"], rtol=1e-4, atol=2e-5)
+        w0 = torch.randn(outs[0].shape, generator=g)
+        w1 = torch.randn(outs[1].shape, generator=g)
+        ((outs[0] * w0).sum() + (outs[1] * w1).sum()).backward()
+        np.testing.assert_allclose(v.grad[:, ::ROWSTEP].numpy(), G[f"c{case}_dv"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(t.grad[:, ::ROWSTEP].numpy(), G[f"c{case}_dt"], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(sd["f.bottlenecks"].grad.numpy(), G[f"c{case}_dbott"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(digest(sd["f.layer_stacks.1.1.feed_forward.w_1.weight"].grad), G[f"c{case}_dw1"], rtol=2e-4, atol=1e-4)
+        np.testing.assert_allclose(digest(sd["f.layer_stacks.0.0.self_attention.query_proj.linear.weight"].grad), G[f"c{case}_dwq"],
+                                   rtol=2e-4, atol=1e-4)
 
 
 def test_missing_num_and_lengths(golden_dir):
