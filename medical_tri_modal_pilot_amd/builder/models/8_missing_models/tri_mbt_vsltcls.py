@@ -28,8 +28,21 @@ def _compute_dtype(args) -> torch.dtype:
     raise ValueError(f"--compute-dtype must be bf16 or fp32, got {name}")
 
 
-def _lin_ln_relu(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
-    return seq(x)
+def flat_layout(named, layer_stacks):
+    """Order ``named`` parameters for optim.FlatParams: every encoder layer block in ops.PARAMS order -- (gamma,beta),
+    (Wq,Wk,Wv), (bq,bk,bv), ... adjacent -- so that the backward kernels get contiguous gradient destinations
+    (ops.GradSink); everything else keeps its place in front of / behind the blocks."""
+    order = {}
+    rank = [0, 1, 2, 5, 3, 6, 4, 7, 8, 9, 10, 11, 12, 13]     # param_list index -> position in the flat layout
+    for li, layers in enumerate(layer_stacks):
+        for m, layer in enumerate(layers):
+            for k, q in enumerate(layer.param_list()):
+                order[id(q)] = (li, m, rank[k])
+    first = min((i for i, (_, q) in enumerate(named) if id(q) in order), default=len(named))
+    head = [x for x in named[:first] if id(x[1]) not in order]
+    body = sorted((x for x in named if id(x[1]) in order), key=lambda x: order[id(x[1])])
+    tail = [x for x in named[first:] if id(x[1]) not in order]
+    return head + body + tail
 
 
 # The image / text input chains run on side streams on purpose (their backward tails overlap); autograd's warning
@@ -131,19 +144,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # tri_mbt_vsltcls.py:248) -- their gradient is None in the reference, so AdamW leaves them alone
         skip += [f"fusion_transformer.layer_stacks.{L - 1}.1.", f"fusion_transformer.layer_stacks.{L - 1}.2."]
         named = [(n, p) for n, p in self.named_parameters() if not n.startswith(tuple(skip))]
-        # Lay every encoder layer out in ops.PARAMS order -- (gamma,beta), (Wq,Wk,Wv), (bq,bk,bv), ... adjacent --
-        # so that FlatParams gives the backward kernels contiguous gradient destinations (ops.GradSink).
-        order = {}
-        rank = [0, 1, 2, 5, 3, 6, 4, 7, 8, 9, 10, 11, 12, 13]     # param_list index -> position in the flat layout
-        for li, layers in enumerate(self.fusion_transformer.layer_stacks):
-            for m, layer in enumerate(layers):
-                for k, q in enumerate(layer.param_list()):
-                    order[id(q)] = (li, m, rank[k])
-        first = min((i for i, (_, q) in enumerate(named) if id(q) in order), default=len(named))
-        head = [x for x in named[:first] if id(x[1]) not in order]
-        body = sorted((x for x in named if id(x[1]) in order), key=lambda x: order[id(x[1])])
-        tail = [x for x in named[first:] if id(x[1]) not in order]
-        return head + body + tail
+        return flat_layout(named, self.fusion_transformer.layer_stacks)
 
     def backward_stage_params(self, lo: int, hi: int, head: bool):
         """Trained parameters used by the fusion layers [lo, hi) (and the classifier head): what a staged backward

@@ -23,6 +23,8 @@ from .module import PositionalEncoding
 
 
 class TrimodalTransformerEncoder_MBT(nn.Module):
+    supports_segments = True      # forward() can cut the fusion stack at ``graph_segments`` (staged hipGraph steps)
+
     def __init__(self, batch_size: int, n_modality: int, bottlenecks_n: int, fusion_startidx: int, d_input: int,
                  n_layers: int, n_head: int, d_model: int, d_ff: int, dropout: float = 0.1, pe_maxlen: int = 10000,
                  resbottle: bool = False, txt_idx: int = 2, vsltonly: int = 0, mbt_bottlenecks_type: str = "skip",
@@ -206,6 +208,8 @@ class BimodalTransformerEncoder_MBT(nn.Module):
             TransformerEncoderLayer(d_model=d_model, num_heads=n_head, d_ff=d_ff, dropout_p=dropout)
             for _ in range(n_modality)]) for _ in range(n_layers))
 
+    supports_segments = False
+    resbottle = False
     _side_streams = TrimodalTransformerEncoder_MBT._side_streams
 
     def key_lengths(self, varying_lengths, device) -> List[Optional[torch.Tensor]]:

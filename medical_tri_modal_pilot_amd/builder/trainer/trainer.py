@@ -60,7 +60,8 @@ def _stage_bounds(args, enc, ddp: bool):
     want = int(getattr(args, "graph_stages", 0))
     if want <= 0:
         want = 3 if ddp else 1
-    if enc is None or want <= 1 or enc.resbottle or getattr(args, "vslt_type", "TIE") == "QIE":
+    if (enc is None or want <= 1 or enc.resbottle or not getattr(enc, "supports_segments", False)
+            or getattr(args, "vslt_type", "TIE") == "QIE"):
         return [0, 0]
     n_fl = enc.n_layers - min(max(enc.fusion_idx, 0), enc.n_layers)
     want = min(want, n_fl)
@@ -201,7 +202,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         bounds = _stage_bounds(args, enc, red is not None)
         if red is not None:
             red.staged = True
-        if enc is not None:
+        if enc is not None and getattr(enc, "supports_segments", False):
             enc.graph_segments = bounds[1:-1]
         inputs = dict(data=data, age=age, gender=gender, input_lengths=input_lengths, x_txt=x_txt,
                       txt_lengths=txt_lengths, x_img=x_img, missing_num=missing_num, img_time=img_time,
@@ -222,7 +223,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
     elif flow_type == "train":
         if red is not None:
             red.staged = False
-        if getattr(model, "fusion_transformer", None) is not None:
+        if getattr(getattr(model, "fusion_transformer", None), "supports_segments", False):
             model.fusion_transformer.graph_segments = None
         optimizer.zero_grad()
         output = run_model()

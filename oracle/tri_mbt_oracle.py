@@ -433,6 +433,28 @@ def model_forward(sd: SD, cfg: Cfg, x, age, gen, input_lengths, txts, txt_length
     return F.linear(h, sd["fc_list.3.weight"], sd["fc_list.3.bias"])                       # :253-255
 
 
+def bi_vslttxt_forward(sd: SD, x, age, gen, input_lengths, txts, txt_lengths, missing, txt_time, *, n_layers: int,
+                       n_head: int = 4, imgtxt_time: int = 1, dropout: float = 0.0, training: bool = False):
+    """BI_VSLTTXT_MBT_V1.forward (8_missing_models/bi_vslttxt_mbt_v1.py:121-183, TIE / biobert path): logits [B].
+    ``missing`` in {0, 1} as the trainer hands it over for --input-types vslt_txt (trainer.py:99-101)."""
+    d = sd["ie_feat.weight"].shape[1]
+    demo = lin_ln_relu(sd, "ie_demo", torch.stack([age, gen], 1))                          # :129-130,138-146
+    v = tie_embedding(sd, x)                                                               # :139-145
+    t = F.linear(txts, sd["txt_embedding.weight"], sd["txt_embedding.bias"])               # :157
+    if imgtxt_time == 1:                                                                   # :159-165
+        t = t + lin_ln_relu(sd, "ie_time", txt_time.unsqueeze(1)).unsqueeze(1) + sd["ie_feat.weight"][19]
+    outs, _ = mbt_encoder_bimodal(sd, "fusion_transformer", [v, t], [input_lengths, txt_lengths + 2], missing,
+                                  n_layers=n_layers, n_head=n_head, txt_idx=1, use_pe=(False, True), mask=(True, True),
+                                  dropout_p=dropout, training=training)
+    c = torch.stack([outs[0][:, 0, :], outs[1][:, 0, :]])                                  # :171-174
+    cls = torch.stack([c.mean(0), outs[0][:, 0, :]])[missing, torch.arange(x.shape[0])]
+    cls = F.layer_norm(cls, (d,), sd["layer_norms_after_concat.weight"], sd["layer_norms_after_concat.bias"], 1e-5)
+    h = F.linear(torch.cat([cls, demo], 1), sd["fc_list.0.weight"], sd["fc_list.0.bias"])
+    h = F.batch_norm(h, sd["fc_list.1.running_mean"], sd["fc_list.1.running_var"], sd["fc_list.1.weight"],
+                     sd["fc_list.1.bias"], training, 0.1, 1e-5)
+    return F.linear(torch.relu(h), sd["fc_list.3.weight"], sd["fc_list.3.bias"]).squeeze()   # :178
+
+
 def bce_with_logits_mean(logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """2_train.py:76 + trainer.py:128,176 -- BCEWithLogitsLoss(mean) on output.squeeze()."""
     return F.binary_cross_entropy_with_logits(logits.squeeze(), y.float())

@@ -198,6 +198,42 @@ def gen_bimodal():
     save("bimodal", **out)
 
 
+def gen_bimodel():
+    """BI_VSLTTXT_MBT_V1 (8_missing_models/bi_vslttxt_mbt_v1.py, the one sibling whose forward returns): logits, BCE
+    loss and every parameter gradient of the real class in train mode (dropout 0), plus its state_dict shapes."""
+    import json
+    args = ref_args(input_types="vslt_txt", model="bi_vslttxt_mbt_v1", batch_size=4, transformer_num_layers=2)
+    from builder.models import get_model
+    model = get_model(args)(args)
+    load_filled(model)
+    model.train()
+    seed, B, T = 4242, 4, 24
+    bt = filler.make_batch(seed, B, T)
+    mnum = bt["missing_num"].clone()
+    mnum[mnum == 2] = 0                                   # trainer.py:99-101 (input_types == "vslt_txt")
+    mnum[mnum == 3] = 1
+    tmax = int(bt["input_lengths"].max())
+    out, o2, o3 = model(bt["x"][:, :tmax], None, None, None, None, bt["age"], bt["gen"], bt["input_lengths"].clone(),
+                        bt["txt"], bt["txt_lengths"].clone(), None, mnum, None, None, bt["txt_time"].half().float(),
+                        "train", None, None)
+    assert o2 is None and o3 is None
+    loss = torch.nn.BCEWithLogitsLoss()(out, bt["y"].float())
+    loss.backward()
+    names, nograd, dig = [], [], []
+    for n, p_ in model.named_parameters():
+        if p_.grad is None:
+            nograd.append(n)
+        else:
+            names.append(n)
+            dig.append(digest(p_.grad))
+    save("bimodel_step", seed=np.array(seed), B=np.array(B), T=np.array(T), logits=out, loss=loss, missing_num=mnum,
+         grad_names=np.array(names), nograd_names=np.array(nograd), grad_digest=np.stack(dig))
+    d = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
+    with open(os.path.join(GOLD, "state_shapes_bi_vslttxt_L2.json"), "w") as f:
+        json.dump(d, f, indent=0)
+    ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls")     # leave the global args as the other sections expect
+
+
 # ------------------------------------------------------------------------ g6
 def build_model(args):
     from builder.models import get_model
@@ -356,7 +392,7 @@ def gen_misc():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["blocks", "encoder", "bimodal", "model", "misc", "shapes"]
+    which = sys.argv[1:] or ["blocks", "encoder", "bimodal", "bimodel", "model", "misc", "shapes"]
     ref_args()
     if "blocks" in which:
         gen_blocks()
@@ -364,6 +400,8 @@ if __name__ == "__main__":
         gen_encoder()
     if "bimodal" in which:
         gen_bimodal()
+    if "bimodel" in which:
+        gen_bimodel()
     if "misc" in which:
         gen_misc()
     if "model" in which:

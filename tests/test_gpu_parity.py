@@ -759,6 +759,66 @@ def test_bimodal_mbt_encoder_vs_golden(ops):
     REPORT["bimodal_mbt_encoder[fp32].worst_of_4_cases"] = {"rel_err": worst, "tol": 1e-4}
 
 
+def test_bi_vslttxt_model_train_step_vs_golden(ops):
+    """BI_VSLTTXT_MBT_V1 through get_model / get_trainer (--input-types vslt_txt: the trainer folds the four
+    modality patterns onto {0, 1}) -- logits-derived loss and all 86 parameter gradients against the real class, then
+    the same step replayed from a hipGraph."""
+    import json
+    from medical_tri_modal_pilot_amd.control.config import parse_args
+    from medical_tri_modal_pilot_amd.builder.models import get_model
+    from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    Gd = G("bimodel_step")
+    with open(os.path.join(ROOT, "tests", "golden", "state_shapes_bi_vslttxt_L2.json")) as f:
+        shapes = json.load(f)
+    sd = {k: filler.fill_tensor(k, torch.zeros(s)) for k, (s, dt_) in shapes.items() if dt_.startswith("float")}
+    sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
+    losses = {}
+    for graph in (0, 1):
+        a = parse_args(["--input-types", "vslt_txt", "--model", "bi_vslttxt_mbt_v1", "--modality-inclusion",
+                        "train-missing_test-missing", "--lr-init", "1e-5", "--batch-size", "4", "--transformer-num-layers", "2",
+                        "--imgtxt-time", "1", "--dropout", "0.0", "--compute-dtype", "fp32", "--hip-graph", str(graph)])
+        a.device = torch.device(DEV)
+        model = get_model(a)(a)
+        model.load_state_dict(sd, strict=False)
+        model = model.to(DEV).train()
+        opt = FusedAdamW(model.hot_parameters(), lr=a.lr_init, weight_decay=a.weight_decay)
+        sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=a.t_0 * 10, cycle_mult=a.t_mult,
+                                              max_lr=a.lr_init * math.sqrt(a.batch_size), min_lr=1e-6,
+                                              warmup_steps=a.t_up * 10, gamma=a.gamma)
+        bt = filler.make_batch(int(Gd["seed"]), int(Gd["B"]), int(Gd["T"]))
+        static = torch.stack([bt["gen"], bt["age"]], 1)
+        kw = dict(args=a, x=bt["x"], static=static, y=bt["y"], output_lengths=None, model=model, logger=_Logger(),
+                  device=torch.device(DEV), scheduler=sched, optimizer=opt, criterion=torch.nn.BCEWithLogitsLoss(),
+                  x_txt=bt["txt"], x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None,
+                  missing=bt["missing"], reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+        seq = []
+        for it in range(3 if graph else 1):
+            _, l = get_trainer(iteration=it + 1, input_lengths=bt["input_lengths"].clone(),
+                               txt_lengths=bt["txt_lengths"].clone(), flow_type="train", **kw)
+            seq.append(l)
+            if it == 0 and not graph:
+                grads = {n: p.grad.detach().clone() for n, p in model.hot_parameters()}
+        losses[graph] = seq
+    assert abs(losses[0][0] - float(Gd["loss"])) < 1e-5, (losses, float(Gd["loss"]))
+    assert losses[1][0] == losses[0][0]                         # eager warm-up step of the graph path = the eager step
+    gs = getattr(model, "_mtmp_graph_step", None)
+    assert gs is not None and gs.captures == 1 and gs.replays == 1 and all(math.isfinite(x) for x in losses[1])
+    names = [str(s) for s in Gd["grad_names"]]
+    assert sorted(names) == sorted(grads)
+    med = float(np.median(Gd["grad_digest"][:, 0]))
+    worst = 0.0
+    for n_, gd in zip(names, Gd["grad_digest"]):
+        if gd[0] < 1e-4 * med:
+            assert float(_digest(grads[n_])[0]) < 1e-3 * med, n_
+            continue
+        worst = max(worst, _rel(_digest(grads[n_]), torch.from_numpy(gd)))
+    REPORT["bi_vslttxt_step[fp32].loss"] = {"rel_err": abs(losses[0][0] - float(Gd["loss"])), "tol": 1e-5}
+    REPORT["bi_vslttxt_step[fp32].worst_grad_digest"] = {"rel_err": worst, "tol": 1e-4}
+    assert worst < 1e-4
+
+
 class _Logger:
     class _Ev:
         def __init__(self):

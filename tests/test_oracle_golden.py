@@ -177,6 +177,36 @@ def test_bimodal_mbt_encoder(golden_dir):
                                    rtol=2e-4, atol=1e-4)
 
 
+def _bimodel_sd(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "state_shapes_bi_vslttxt_L2.json")) as f:
+        shapes = json.load(f)
+    sd = {k: filler.fill_tensor(k, torch.zeros(s)) for k, (s, dt) in shapes.items() if dt.startswith("float")}
+    sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
+    return sd
+
+
+def test_bi_vslttxt_model_step(golden_dir):
+    """the restated BI_VSLTTXT_MBT_V1 against logits, loss and all 86 parameter gradients of the real class."""
+    G = _g(golden_dir, "bimodel_step")
+    sd = _bimodel_sd(golden_dir)
+    names = [str(s) for s in G["grad_names"]]
+    for k in names:
+        sd[k].requires_grad_(True)
+    bt = filler.make_batch(int(G["seed"]), int(G["B"]), int(G["T"]))
+    mnum = torch.from_numpy(G["missing_num"])
+    tmax = int(bt["input_lengths"].max())
+    out = O.bi_vslttxt_forward(sd, bt["x"][:, :tmax], bt["age"], bt["gen"], bt["input_lengths"], bt["txt"], bt["txt_lengths"],
+                               mnum, bt["txt_time"].half().float(), n_layers=2, training=True)
+    np.testing.assert_allclose(out.detach().numpy(), G["logits"], rtol=1e-4, atol=1e-5)
+    loss = O.bce_with_logits_mean(out, bt["y"])
+    assert abs(float(loss) - float(G["loss"])) < 1e-5
+    loss.backward()
+    assert all(sd[str(k)].grad is None for k in G["nograd_names"] if str(k) in sd)
+    for n_, gd in zip(names, G["grad_digest"]):
+        np.testing.assert_allclose(digest(sd[n_].grad), gd, rtol=1e-4, atol=2e-6, err_msg="grad " + n_)
+
+
 def test_missing_num_and_lengths(golden_dir):
     G = _g(golden_dir, "model_step")
     bt = filler.make_batch(int(G["seed"]), int(G["B"]), int(G["T"]))
