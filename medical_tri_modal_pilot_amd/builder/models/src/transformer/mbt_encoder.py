@@ -244,9 +244,11 @@ class BimodalTransformerEncoder_MBT(nn.Module):
         kv = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
         # missing 0 -> table row 1 (0.5, 0.5, 0), missing 1 -> row 3 (1, 0, 0); anything else is out of bounds for the
         # reference's two candidates (:631) and stays out of bounds for the kernel's host check
-        missing = missing.to(dev).long()
-        if missing.numel() and (int(missing.max()) > 1 or int(missing.min()) < 0):
+        # (checked on the host only when ``missing`` lives there: a device-side check would be a sync, and a captured
+        #  step cannot have one; the kernel clamps its table index)
+        if not missing.is_cuda and missing.numel() and (int(missing.max()) > 1 or int(missing.min()) < 0):
             raise IndexError("BimodalTransformerEncoder_MBT: missing must be 0 (both streams) or 1 (stream 0 only)")
+        missing = missing.to(dev).long()
         pattern = 1 + 2 * missing
         fl = list(self.layer_stacks)
         all_fused = iter(type(fl[0][0]).fused_weights_of([layer for layers in fl for layer in layers], dt))
