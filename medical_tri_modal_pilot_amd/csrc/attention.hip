@@ -121,9 +121,17 @@ MTMP_DEV float half_sum(float x) {
 // fma 4 + exp 8 + add 4 + max 2 + cvt 2.25 issue cycles against 16 cycles of matrix pipe, PMC: vector issue
 // ~60 %, MFMA ~30 % busy), so the loop carries no masks, clamps or address arithmetic: full tiles run a
 // mask-free body on running pointers, the ragged last tile a second copy of the body.
-// (Measured and rejected here: the running maximum as the C operand of the score MFMAs -- saves the fma but
+// (Measured and rejected here, round 1: the running maximum as the C operand of the score MFMAs -- saves the fma but
 //  its 16 registers cost the fourth wave per SIMD: 116-121 us against 107; 256-query workgroups with two
-//  query blocks per wave software-pipelined against each other, double-buffered LDS: 128 us.)
+//  query blocks per wave software-pipelined against each other, double-buffered LDS: 128 us.
+//  Round 2, same harness (tools/bench_kernels.py, 114-122 us for this kernel on gaussian data), all correct against the
+//  oracle, none faster -- DESIGN.md section 4 has the counters behind it: 64 queries per wave at two waves per SIMD
+//  with the four 32 x 32 sub-blocks of a tile software-pipelined in the wave, one barrier per tile: 127-131 us;
+//  K / V tiles by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled unpadded images, tools/dbg/dma_probe), two stages:
+//  116-120 us, three stages at three workgroups per CU: 110-117 us; three or two workgroups per CU with the register
+//  budget that buys: 126-127 us; a start stagger or static priorities by hardware wave slot: no change; the row sums
+//  on the matrix pipe (an all-ones V^T block, 4 more MFMAs and 32 vector adds fewer per tile): 120-124 us at three
+//  workgroups per CU, 165 us at four (225 spilled registers).)
 template <typename T> struct TileR { Frag<T> a, b; };
 
 template <typename T> MTMP_DEV void put_rows_r(T* dst, const TileR<T>& t, int tid) {
@@ -143,18 +151,11 @@ MTMP_DEV void put_tr_r(float* dst, const TileR<float>& t, int tid) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(d + e * LDT) = f32x2{t.a.v[e], t.b.v[e]};
 }
-#ifndef MTMP_FWD_OCC
-#define MTMP_FWD_OCC 4          // waves per SIMD the register allocation is bounded for (A/B builds)
-#endif
-#ifndef MTMP_FWD_DB
-#define MTMP_FWD_DB 0           // 1: double-buffered LDS, one barrier per tile (A/B builds; needs MTMP_FWD_OCC <= 3)
-#endif
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
     T* sVt = sK + KT * LDT;                   // V image for the transposed role (frag_tr)
-    constexpr int STAGE1 = KT * LDT + tr_elems<T>();
     const int nqt = (p.N + 127) >> 7;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
@@ -200,29 +201,23 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
         }
     };
     fetch(0);
-#if MTMP_FWD_DB
-    put_rows_r<T>(sK, kreg, tid);
-    put_tr_r(sVt, vreg, tid);
-    if (ntiles > 1) fetch(1);
-    T* const sK0 = sK;
-#endif
     STAMP_DECL
     auto body = [&](int it, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         STAMP(ts0)
-#if MTMP_FWD_DB
-        __syncthreads();                       // tile `it` visible; every wave is done with the other stage
-        sK = sK0 + (it & 1) * STAGE1;
-        sVt = sK + KT * LDT;
-#else
+#ifndef MTMP_ABLATE_BARRIER                    // (ablation builds: results are wrong by design, only the timing is read)
         __syncthreads();
+#endif
+#ifndef MTMP_ABLATE_PUT
         put_rows_r<T>(sK, kreg, tid);
         put_tr_r(sVt, vreg, tid);
+#endif
+#ifndef MTMP_ABLATE_BARRIER
         __syncthreads();
+#endif
         STAMP(ts1)
 #ifndef MTMP_ABLATE_FETCH                      // (ablation builds: tools/ablate_attn.sh -- never shipped)
         if (it + 1 < ntiles) fetch(it + 1);
-#endif
 #endif
         f32x16 st[2];
         tile_qk<T>(st[0], sK, r, half, qf);
@@ -241,6 +236,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
         // a wrong maximum is still a valid softmax shift).  `seed` is an ordinary instruction on the LAST
         // accumulator written, so the required wait states are inserted in front of it, and every asm below
         // depends on it.
+#ifdef MTMP_ABLATE_MAX
+        const float mx = (st[0][15] + st[1][15]) * c2;
+#else
         const float seed = fmaxf(st[0][15], st[1][15]);
         float mxa = max3(seed, st[0][0], st[0][1]), mxb = max3(seed, st[1][0], st[1][1]);
 #pragma unroll
@@ -249,6 +247,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
             mxb = max3(mxb, st[1][t], st[1][t + 1]);
         }
         const float mx = half_max(max3(mxa, mxb, fmaxf(st[0][14], st[1][14]))) * c2;
+#endif
         // Deferred rescale (exact): O, l and m move only when some row's maximum grew; while it has
         // not, p = exp2(s - m) <= 1 still holds.  Wave-uniform branch, rare after the first tiles.
         if (!wave_all(mx <= m)) {
@@ -278,14 +277,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? MTMP_FWD_OCC : 1)) void attn
                 mma<T>(o0, frag_tr(sVt, 32 * kb + 16 * s, 0, lane), pf);
                 mma<T>(o1, frag_tr(sVt, 32 * kb + 16 * s, 32, lane), pf);
             }
-#if MTMP_FWD_DB
-        if (it + 1 < ntiles) {                 // the next tile (in registers since the last iteration) -> other stage
-            T* nK = sK0 + ((it + 1) & 1) * STAGE1;
-            put_rows_r<T>(nK, kreg, tid);
-            put_tr_r(nK + KT * LDT, vreg, tid);
-            if (it + 2 < ntiles) fetch(it + 2);
-        }
-#endif
         STAMP(ts4)
         STAMP_ACC
     };
@@ -347,251 +338,6 @@ template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
     for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
     return r;
 }
-// =============================== forward, two waves per SIMD ===================================
-// Same arithmetic as attn_fwd_kernel, restructured so that ONE wave keeps the matrix pipe and the vector ALU busy at
-// the same time instead of relying on four co-resident waves to interleave by chance (counters of the kernel above,
-// profiles/r01t_heavy_kernels_sq_counters.json: matrix pipe 33 % busy, vector issue 57 %, 13.2 vector instructions
-// per MFMA, two barriers per tile):
-//   * workgroup = 4 waves = 256 queries, a wave owns 64 (two 32-query blocks A, B): every K / V^T fragment read from
-//     LDS feeds two MFMAs (one per block) -- half the LDS reads per MFMA;
-//   * 256 registers per wave (two waves per SIMD): the 64-key tile is processed as four 32-query x 32-key
-//     sub-blocks in the order (A,k0) (B,k0) (A,k1) (B,k1), software-pipelined INSIDE the wave:
-//         slot t:  S(t) = K Q^T [4 MFMA]  +  O += V^T P(t-2) [4 MFMA]   beside   P(t-1) = exp2(S(t-1) - m), row sums
-//     then the row maximum of S(t) and the (rare, wave-uniform) rescale decision close the slot, so that a slot is one
-//     basic block in which sched_group_barrier interleaves 8 MFMAs with ~40 vector instructions;
-//   * the running maximum enters the score MFMAs as their C operand (-m in 16 registers per block) and the softmax
-//     scale is folded into Q once: per score exp2 + row-sum add + 1/2 max3 + 1/2 cvt_pk is all the vector work;
-//   * LDS is double buffered: the next tile goes from registers into the other stage at the end of the iteration --
-//     ONE barrier per tile.
-template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd2_kernel(AttnArgs<T> p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int KEL = KT * LDT, STAGE = KT * LDT + tr_elems<T>();
-    T* smem = reinterpret_cast<T*>(smem_raw);
-    const int nqt = (p.N + 255) >> 8;
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, half = lane >> 5;
-    int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
-    const bool uniform = kvl <= 0;            // all keys masked -> uniform average over all N keys: Q = 0, every p = 1
-    if (uniform) kvl = p.N;
-    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
-    const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
-    const int q0w = qt * 256 + wave * 64;     // this wave's queries: block A = q0w .. q0w+31, block B = q0w+32 .. q0w+63
-    const float c2 = p.scale * LOG2E;
-    Frag<T> qf[2][4];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = q0w + 32 * qb + r;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            qf[qb][c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half),
-                                  qrow < p.N && !uniform);
-    }
-    f32x16 oA0 = {0}, oA1 = {0}, oB0 = {0}, oB1 = {0};
-    float mA = -INFINITY, mB = -INFINITY, lA = 0.f, lB = 0.f;
-    const int nfull = kvl / KT, ntiles = (kvl + KT - 1) / KT;
-    int ra, rb, col;
-    tile_map<T>(tid, ra, rb, col);
-    const size_t tstep = (size_t)KT * p.ld_qkv;
-    const T* kpa = Kb + (size_t)ra * p.ld_qkv + col;
-    const T* kpb = Kb + (size_t)rb * p.ld_qkv + col;
-    const ptrdiff_t kv_off = Vb - Kb;
-    // The next tile travels global -> registers -> LDS in two halves (K, then V) so that only 8 staging registers are
-    // live at a time: K is requested in slot 1 and stored into the other LDS stage in slot 3, V in slots 3 and 5 (the
-    // other stage is free for the whole iteration: its last readers passed this iteration's barrier).
-    TileR<T> treg;
-    auto fetch = [&](int t, ptrdiff_t off) {
-        if (t < nfull) {
-            treg.a = frag_load<T>(kpa + off); treg.b = frag_load<T>(kpb + off);
-        } else {
-            treg.a = frag_load<T>(Kb + (size_t)min(t * KT + ra, kvl - 1) * p.ld_qkv + col + off);
-            treg.b = frag_load<T>(Kb + (size_t)min(t * KT + rb, kvl - 1) * p.ld_qkv + col + off);
-        }
-    };
-    auto put_k = [&](int stage) { put_rows_r<T>(smem + stage * STAGE, treg, tid); };
-    auto put_v = [&](int stage) { put_tr_r(smem + stage * STAGE + KEL, treg, tid); };
-    fetch(0, 0); put_k(0);
-    fetch(0, kv_off); put_v(0);
-    if (nfull > 0) { kpa += tstep; kpb += tstep; }
-    // row maximum of one sub-block + the rescale decision for its query block (closes a slot)
-    auto decide = [&](const f32x16& st, float& m, float& l, f32x16& o0, f32x16& o1) {
-        const float seed = fmaxf(st[14], st[15]);           // ordinary first reader of the MFMA result (hazard waits)
-        float mxa = max3(seed, st[0], st[1]), mxb = max3(seed, st[2], st[3]);
-        mxa = max3(mxa, st[4], st[5]);  mxb = max3(mxb, st[6], st[7]);
-        mxa = max3(mxa, st[8], st[9]);  mxb = max3(mxb, st[10], st[11]);
-        const float mx = half_max(max3(mxa, mxb, fmaxf(st[12], st[13]))) * c2;
-        // deferred rescale (exact): O, l and m move only when some row's maximum grew (wave-uniform, rare after the
-        // first tiles); while it has not, p = exp2(s c2 - m) <= 1 still holds
-        if (__builtin_expect(!wave_all(mx <= m), 0)) {
-            const float m_new = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - m_new);
-            l *= alpha; o0 *= alpha; o1 *= alpha;
-            m = m_new;
-        }
-    };
-    // p = exp2(s c2 - m), row sums, and the conversion to the P.V operand fragments right away: between two slots a
-    // sub-block lives in 8 registers (bf16), not 16
-    auto expsum = [&](f32x16& st, float m, float& l, Frag<T> (&pf)[2]) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float pv = fast_exp2(fmaf(st[t], c2, -m));
-            l += pv;
-            st[t] = pv;
-        }
-        pf[0] = frag_from_acc<T>(st, 0);
-        pf[1] = frag_from_acc<T>(st, 1);
-    };
-    auto load_k = [&](const T* sK, int kb, Frag<T> (&kf)[4]) {
-        const T* arow = sK + (32 * kb + swz23(r)) * LDT + 8 * half;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) kf[c] = frag_load<T>(arow + 16 * c);
-    };
-    auto load_v = [&](const T* sVt, int kb, Frag<T> (&vf)[2][2]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            vf[s][0] = frag_tr(sVt, 32 * kb + 16 * s, 0, lane);
-            vf[s][1] = frag_tr(sVt, 32 * kb + 16 * s, 32, lane);
-        }
-    };
-    auto qk = [&](f32x16& st, const Frag<T> (&kf)[4], const Frag<T> (&q)[4]) {
-        st = mma0<T>(kf[0], q[0]);
-#pragma unroll
-        for (int c = 1; c < 4; ++c) mma<T>(st, kf[c], q[c]);
-    };
-    auto pv = [&](f32x16& o0, f32x16& o1, const Frag<T> (&pf)[2], const Frag<T> (&vf)[2][2]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            mma<T>(o0, vf[s][0], pf[s]);
-            mma<T>(o1, vf[s][1], pf[s]);
-        }
-    };
-    auto mask_tail = [&](f32x16& st, int k0) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (k0 + acc_row_swz(t, half) >= kvl) st[t] = -INFINITY;
-    };
-    // interleave the slot's MFMAs with its vector work: per MFMA two transcendental and four plain vector
-    // instructions (bf16 build only: the fp32 build's MFMA chains are 8x longer and need no hand placement)
-#define MTMP_WEAVE(N_MFMA)                                                     \
-    if (sizeof(T) == 2) {                                                      \
-        _Pragma("unroll") for (int g_ = 0; g_ < (N_MFMA); ++g_) {              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                 \
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 \
-        }                                                                      \
-    }
-    auto body = [&](int it, auto tail_tag) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        const T* sK = smem + (it & 1) * STAGE;
-        const T* sVt = sK + KEL;
-        const int k0 = it * KT;
-        __syncthreads();                       // tile `it` is visible; every wave is done reading the other stage
-        f32x16 s0, s1, s2, s3;                 // scores of (A,k0) (B,k0) (A,k1) (B,k1)
-        Frag<T> p0[2], p1[2], p2[2], p3[2];    // ... and their probabilities as P.V operand fragments
-        Frag<T> kf[4], vf[2][2];               // one set each: the k1 fragments are requested once the k0 MFMAs are issued
-        // slot 0
-        load_k(sK, 0, kf);
-        qk(s0, kf, qf[0]);
-        if (TAIL) mask_tail(s0, k0);
-        decide(s0, mA, lA, oA0, oA1);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 1
-        const bool more = it + 1 < ntiles;
-#ifndef MTMP_ABLATE_FETCH2
-        if (more) fetch(it + 1, 0);
-#endif
-        qk(s1, kf, qf[1]);
-        load_v(sVt, 0, vf);
-        load_k(sK, 1, kf);
-        expsum(s0, mA, lA, p0);
-        MTMP_WEAVE(4)
-        if (TAIL) mask_tail(s1, k0);
-        decide(s1, mB, lB, oB0, oB1);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 2
-        qk(s2, kf, qf[0]);
-        pv(oA0, oA1, p0, vf);
-        expsum(s1, mB, lB, p1);
-        MTMP_WEAVE(8)
-        if (TAIL) mask_tail(s2, k0 + 32);
-        decide(s2, mA, lA, oA0, oA1);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 3
-#ifndef MTMP_ABLATE_FETCH2
-        if (more) { put_k((it + 1) & 1); fetch(it + 1, kv_off); }
-#else
-        if (more) put_k((it + 1) & 1);
-#endif
-        qk(s3, kf, qf[1]);
-        pv(oB0, oB1, p1, vf);
-        load_v(sVt, 1, vf);
-        expsum(s2, mA, lA, p2);
-        MTMP_WEAVE(8)
-        if (TAIL) mask_tail(s3, k0 + 32);
-        decide(s3, mB, lB, oB0, oB1);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 4
-        pv(oA0, oA1, p2, vf);
-        expsum(s3, mB, lB, p3);
-        MTMP_WEAVE(4)
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 5
-        pv(oB0, oB1, p3, vf);
-        if (more) { put_v((it + 1) & 1); if (it + 1 < nfull) { kpa += tstep; kpb += tstep; } }
-    };
-    for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
-    if (ntiles > nfull) body(nfull, std::true_type{});
-    lA = half_sum(lA);
-    lB = half_sum(lB);
-    // Epilogue: each 32 x 64 block goes through a wave-private LDS tile and leaves as whole 128-byte head rows.
-    __syncthreads();                                  // all waves are done with the stages: reuse them as staging
-    constexpr int CH = DH * (int)sizeof(T) / 16, RPP = 64 / CH;       // 16-byte chunks per row, rows per pass
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        T* sO = smem + (wave * 2 + qb) * 32 * LDT;
-        const float inv = 1.0f / (qb ? lB : lA);
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x16& o = qb ? (dt ? oB1 : oB0) : (dt ? oA1 : oA0);
-                store4<T>(sO + r * LDT + 32 * dt + 8 * g + 4 * half, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv,
-                          o[4 * g + 3] * inv);
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tiles: in-order LDS, no barrier needed
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const T* sO = smem + (wave * 2 + qb) * 32 * LDT;
-        const int q0b = q0w + 32 * qb;
-#pragma unroll
-        for (int ps = 0; ps < 32 / RPP; ++ps) {
-            const int rl = ps * RPP + lane / CH, ch = lane % CH;
-            if (q0b + rl < p.N) {
-                const size_t off = ((size_t)b * p.N + q0b + rl) * p.ld_o + hd * DH + ch * (16 / (int)sizeof(T));
-                const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sO + rl * LDT) + 16 * ch);
-                *reinterpret_cast<u32x4_t*>(p.o + off) = ov;
-                if (p.o_res) {                 // residual epilogue (encoder.py:27): adds O as stored (rounded to T)
-                    constexpr int E = 16 / (int)sizeof(T);
-                    T ob[E], rbuf[E], sb[E];
-                    __builtin_memcpy(ob, &ov, 16);
-                    const u32x4_t rvv = *reinterpret_cast<const u32x4_t*>(p.res + off);
-                    __builtin_memcpy(rbuf, &rvv, 16);
-#pragma unroll
-                    for (int i = 0; i < E; ++i) sb[i] = from_f32<T>(to_f32(ob[i]) + to_f32(rbuf[i]));
-                    u32x4_t sv;
-                    __builtin_memcpy(&sv, sb, 16);
-                    *reinterpret_cast<u32x4_t*>(p.o_res + off) = sv;
-                }
-            }
-        }
-        const int qrow = q0b + r;
-        if (qrow < p.N && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = (qb ? mB : mA) + log2f(qb ? lB : lA);
-    }
-}
-
 // ---- helpers of the backward kernels ----
 
 // 32x32 tile: C + A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
@@ -974,7 +720,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
 }
 
 template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T); }
-template <typename T> size_t fwd2_smem() { return 2 * fwd_smem<T>(); }
 template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T); }
 template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float); }
 
@@ -994,17 +739,10 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, const void*
                const int* kv_len, int B, int N, int H, int ld_qkv, int ld_o, float scale, hipStream_t st) {
     AttnArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (T*)o, (const T*)res, (T*)o_res, lse, kv_len,
                   B, N, H, ld_qkv, ld_o, scale};
-#ifndef MTMP_ATTN_FWD_V2                        // (A/B builds: attn_fwd2_kernel, measured slower -- see its header)
     const int nwg = ((N + 127) / 128) * H * B;
-    const size_t sm = fwd_smem<T>() * (MTMP_FWD_DB ? 2 : 1);
+    const size_t sm = fwd_smem<T>();
     if (int e = set_smem(attn_fwd_kernel<T>, sm)) return e;
     hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(nwg), dim3(256), sm, st, a);
-#else
-    const int nwg = ((N + 255) / 256) * H * B;
-    const size_t sm = fwd2_smem<T>();
-    if (int e = set_smem(attn_fwd2_kernel<T>, sm)) return e;
-    hipLaunchKernelGGL(attn_fwd2_kernel<T>, dim3(nwg), dim3(256), sm, st, a);
-#endif
     MTMP_CHECK_LAUNCH("mtmp_attn_fwd");
     return MTMP_OK;
 }
