@@ -340,6 +340,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
     const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
     const int tok = lane / P::LPT, ch = lane % P::LPT;           // store phase: this lane's token (+ 64/LPT per pass), 16 B chunk
+#if defined(MTMP_LNG_PRIO) || defined(MTMP_LNG_SLEEP)
+    {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6);      // HW_REG_LDS_ALLOC.LDS_BASE: 0 for the first WG on a CU
+        if (lds_base != 0) {
+#ifdef MTMP_LNG_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+#ifdef MTMP_LNG_SLEEP
+            __builtin_amdgcn_s_sleep(MTMP_LNG_SLEEP);
+#endif
+        }
+    }
+#endif
     for (int j = j0; j < j1; ++j) {
         const int n0 = j * P::NP;
         T* cur = sP + ((j - j0) & 1) * P::NP * P::LDP;
@@ -349,14 +362,185 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 #pragma unroll
         for (int g = 0; g < P::G; ++g)
             acc[g] = mma_c<T>(frag_load<T>(cur + (32 * g + r) * P::LDP + 8 * half), af[0], binit[g]);
+#ifdef MTMP_LNG_NOMMA      // (diagnostic builds, results wrong by design: tools/ablate_lng.sh)
+        constexpr int CEND = 2;
+#else
+        constexpr int CEND = 16;
+#endif
 #pragma unroll
-        for (int c = 1; c < 16; ++c)
+        for (int c = 1; c < CEND; ++c)
 #pragma unroll
             for (int g = 0; g < P::G; ++g)
                 mma<T>(acc[g], frag_load<T>(cur + (32 * g + r) * P::LDP + 16 * c + 8 * half), af[c]);
         panel_commit<T>(nxt, wreg, tid);                         // panel j+1 (or a harmless repeat of the last one)
         bias_fetch<T>(binit, p.bias, p.w, min(j + 1, j1 - 1) * P::NP, half);
         panel_fetch<T>(wreg, p.w, min(j + 2, j1 - 1) * P::NP, p.N, tid);
+#ifdef MTMP_LNG_NOEPI
+        if (p.M < 0)
+#endif
+#pragma unroll
+        for (int g = 0; g < P::G; ++g) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const int col = n0 + 32 * g + 8 * i4 + 4 * half;
+                unsigned fld[4];
+                if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[g][4 * i4 + i];
+                    if (RELU) v[i] = relu1(v[i]);
+                    if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
+                }
+                store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+            }
+            wave_lds_handover();
+#pragma unroll
+            for (int ps = 0; ps < P::PASSES; ++ps) {
+                const int t = tok + ps * (64 / P::LPT);
+                const u32x4_t d = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + t * P::FS) + 16 * ch);
+                T* dst = p.y + (size_t)min(m_wave + t, p.M - 1) * p.ldy + n0 + 32 * g;
+#ifdef MTMP_LNG_NOSTORE
+                if (p.M < 0)
+#endif
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst) + 16 * ch) = d;
+            }
+            wave_lds_handover();
+        }
+        __syncthreads();                                         // nxt visible to all waves, cur free for the next commit
+    }
+}
+
+// ---------------------------------------------------------------------------
+// bf16 build of the same row-panel kernel with the weight panels moved by LDS-DMA (global_load_lds_dwordx4: LDS[M0 + 16 * lane]
+// <- 16 bytes from the lane's own global address, tools/dbg/dma_probe).  What that buys over ln_gemm_kernel<bf16>:
+//   * no panel prefetch registers (32 VGPRs) and no ds_write_b128 commit (13 LDS-path cycles each, 8 per thread per panel);
+//   * the bias block lives in LDS (a broadcast ds_read_b128 into the accumulators at the top of a panel) instead of 32 more
+//     registers that stayed live across the epilogue -- the first version ran at 256 VGPRs with spills and its MFMA phase began
+//     with ten "ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma" round trips because nothing was left to prefetch into.
+// A DMA instruction writes 1 KiB of CONTIGUOUS LDS, i.e. two unpadded 512-byte weight rows, so bank conflicts are avoided by
+// permuting the 16-byte chunks inside a row instead of padding it: chunk c of panel row R sits at position c ^ (R & 15) (the
+// lanes of one ds_read_b128 service group hold 16 rows that are distinct mod 16).  The permutation is applied on the SOURCE
+// side (each lane picks the global chunk that belongs at its fixed LDS slot), the reader XORs its chunk index.
+// Order of one panel iteration: issue DMA(j+1) -> bias -> 32 MFMAs on panel j -> epilogue (4 row-piece stores per wave) ->
+// s_waitcnt vmcnt(4) (the DMA is older than exactly those four stores) -> barrier.
+struct PanelDma {
+    static constexpr int NP = 64, G = 2, FS = 40, LPT = 4, PASSES = 2, MAXP = 16;   // MAXP panels (1024 features) per workgroup
+    static constexpr unsigned panel_bytes = NP * 512, stage_off = 2 * panel_bytes, bias_off = stage_off + 4 * 32 * FS * 2;
+    static constexpr size_t lds_bytes = bias_off + MAXP * NP * 4;
+};
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // (m0 is "reserved"; naming it as clobbered is exactly the point)
+MTMP_DEV void dma16(unsigned voff, const void* sbase, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+template <bool RELU, bool DROP>
+__global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
+    using T = bf16;
+    using P = PanelDma;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, half = lane >> 5;
+    T* sS = reinterpret_cast<T*>(smem_raw + P::stage_off) + wave * 32 * P::FS;      // wave-private [32][FS]
+    float* sG = reinterpret_cast<float*>(smem_raw + P::stage_off);                  // gamma|beta, prologue only (aliases sS)
+    float* sB = reinterpret_cast<float*>(smem_raw + P::bias_off);                   // bias of this workgroup's panels
+    const int npanels = p.N / P::NP;
+    const int per = (npanels + gridDim.y - 1) / gridDim.y;
+    const int j0 = blockIdx.y * per, j1 = min(npanels, j0 + per);
+    if (j0 >= j1) return;
+    const int m_wave = blockIdx.x * BM + wave * 32;
+    const int row = min(m_wave + r, p.M - 1);
+    // DMA slot of this lane: instruction i of wave w fills panel rows 16w + 2i + (lane >> 5); LDS position lane & 31 of that row
+    // takes global chunk (lane & 31) ^ (row & 15)
+    unsigned dsrc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dsrc[i] = (unsigned)(16 * wave + 2 * i + half) * 512u + 16u * (unsigned)(r ^ (2 * i + half));
+    auto panel_dma = [&](int j, int buf) {
+        const char* src = reinterpret_cast<const char*>(p.w + (size_t)j * P::NP * 256);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma16(dsrc[i], src, lds0 + buf * P::panel_bytes + (unsigned)(8 * wave + i) * 1024u);
+    };
+    panel_dma(j0, 0);
+    if (p.gamma) {
+        sG[tid] = p.gamma[tid];
+        sG[256 + tid] = p.beta[tid];
+    }
+    for (int i = tid; i < (j1 - j0) * P::NP; i += 256) sB[i] = p.bias ? p.bias[j0 * P::NP + i] : 0.f;
+    // ---- LayerNorm prologue, in registers: lane (r, half) holds k = 16c + 8*half + j of row r
+    Frag<T> af[16];
+    float s1 = 0.f;
+    const T* arow = p.a + (size_t)row * p.lda + 8 * half;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        af[c] = frag_load<T>(arow + 16 * c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    const float mean = s1 * (1.0f / 256.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 32, 64);
+    const float sigma = sqrtf(s2 * (1.0f / 255.0f));             // torch.std: Bessel-corrected
+    const float rs = 1.0f / (sigma + p.eps);
+    __syncthreads();                                             // sG ready
+    if (p.gamma) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = 16 * c + 8 * half;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
+            if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
+        }
+        if (p.stats && half == 0 && blockIdx.y == 0) {
+            p.stats[2 * (size_t)row] = mean;
+            p.stats[2 * (size_t)row + 1] = rs;
+        }
+    }
+    const unsigned thr = dropout_threshold(p.drop_p);
+    const float keep_scale = 1.0f / (1.0f - p.drop_p);
+    const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
+    const int tok = lane / P::LPT, ch = lane % P::LPT;           // store phase: this lane's token (+ 16 per pass), 16 B chunk
+    // reader: row 32g + r, k-step c -> chunk (2c + half) ^ (r & 15); the XOR only touches chunk bits 0-3, so c >> 3 and g are
+    // immediate offsets on eight per-lane addresses
+    const char* rd[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rd[c] = smem_raw + r * 512 + 16 * ((2 * c + half) ^ (r & 15));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // panel j0 landed (this wave's share)
+    __syncthreads();                                             // ... everyone's; sB written; sG dead (sS may be written)
+    for (int j = j0; j < j1; ++j) {
+        const int n0 = j * P::NP, buf = (j - j0) & 1;
+        panel_dma(min(j + 1, j1 - 1), buf ^ 1);                  // (a harmless repeat after the last panel keeps vmcnt static)
+        const char* cur = reinterpret_cast<const char*>(0) + buf * P::panel_bytes;
+        f32x16 acc[P::G];
+#pragma unroll
+        for (int g = 0; g < P::G; ++g)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (n0 - j0 * P::NP) + 32 * g + 8 * i4 + 4 * half);
+                acc[g][4 * i4] = v[0]; acc[g][4 * i4 + 1] = v[1]; acc[g][4 * i4 + 2] = v[2]; acc[g][4 * i4 + 3] = v[3];
+            }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int g = 0; g < P::G; ++g) {
+                Frag<T> b;
+                b.v = *reinterpret_cast<const bf16x8*>(rd[c & 7] + (size_t)cur + g * 16384 + (c >> 3) * 256);
+                mma<T>(acc[g], b, af[c]);
+            }
+        // issue order: the bias block and the first eight weight fragments, then one fragment read per MFMA (eight ahead)
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+        for (int k = 0; k < 24; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 #pragma unroll
         for (int g = 0; g < P::G; ++g) {
 #pragma unroll
@@ -383,7 +567,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
             }
             wave_lds_handover();
         }
-        __syncthreads();                                         // nxt visible to all waves, cur free for the next commit
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::G * P::PASSES) : "memory");   // DMA(j+1) done; this panel's stores may fly
+        __syncthreads();                                         // panel j+1 visible to all waves, panel j free for DMA(j+2)
     }
 }
 
@@ -775,6 +960,30 @@ int tn_splits(int M, int N, int K, int target_wgs) {
     return s < 1 ? 1 : s;
 }
 
+int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, hipStream_t st) {
+    using P = PanelDma;
+    const void* fs[4] = {(const void*)ln_gemm_dma_kernel<false, false>, (const void*)ln_gemm_dma_kernel<false, true>,
+                         (const void*)ln_gemm_dma_kernel<true, false>, (const void*)ln_gemm_dma_kernel<true, true>};
+    const void* f = fs[(relu ? 2 : 0) + (a.drop_p > 0.f ? 1 : 0)];
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
+        mtmp_set_error("mtmp_ln_gemm: cannot raise dynamic LDS to %zu", P::lds_bytes);
+        return MTMP_ERR_LAUNCH;
+    }
+    // as launch_ln_gemm below; a workgroup's bias block in LDS holds at most MAXP panels
+    const int mtiles = (a.M + BM - 1) / BM, npanels = a.N / P::NP;
+    int nsplit = 512 / mtiles;
+    nsplit = nsplit < 1 ? 1 : (nsplit > npanels ? npanels : nsplit);
+    const int need = (npanels + P::MAXP - 1) / P::MAXP;
+    if (nsplit < need) nsplit = need;
+    dim3 grid(mtiles, nsplit);
+    const bool drop = a.drop_p > 0.f;
+    if (relu && drop)       hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true>), grid, dim3(256), P::lds_bytes, st, a);
+    else if (relu)          hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false>), grid, dim3(256), P::lds_bytes, st, a);
+    else if (drop)          hipLaunchKernelGGL((ln_gemm_dma_kernel<false, true>), grid, dim3(256), P::lds_bytes, st, a);
+    else                    hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false>), grid, dim3(256), P::lds_bytes, st, a);
+    MTMP_CHECK_LAUNCH("mtmp_ln_gemm");
+    return MTMP_OK;
+}
 template <typename T>
 int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
     const size_t sm = Panel<T>::lds_bytes;
@@ -782,6 +991,9 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
         mtmp_set_error("mtmp_ln_gemm: N=%d must be a multiple of %d for this dtype", a.N, Panel<T>::NP);
         return MTMP_ERR_ARG;
     }
+#ifndef MTMP_LNG_OLD
+    if constexpr (sizeof(T) == 2) return launch_ln_gemm_dma(a, relu, st);
+#endif
     if (sm > 48 * 1024) {
         const void* fs[4] = {(const void*)ln_gemm_kernel<T, false, false>, (const void*)ln_gemm_kernel<T, false, true>,
                              (const void*)ln_gemm_kernel<T, true, false>, (const void*)ln_gemm_kernel<T, true, true>};

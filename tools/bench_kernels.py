@@ -82,7 +82,11 @@ def main():
         for n, relu in ((768, False), (1024, True)):
             w = R(n, 256) * 0.05
             b = torch.zeros(n, device=DEV)
-            rec(f"ln_gemm[M,{n},256]", timeit(lambda: ops.ln_gemm(x, gm, bt, w, b, n, relu=relu), a.rounds), 2.0 * M * n * 256)
+            rec(f"ln_gemm[M,{n},256]", timeit(lambda: ops.ln_gemm(x, gm, bt, w, b, n, relu=relu), a.rounds), 2.0 * M * n * 256,
+                2.0 * M * (256 + n + 256))
+            if relu:
+                rec(f"ln_gemm[M,{n},256].drop", timeit(lambda: ops.ln_gemm(x, gm, bt, w, b, n, relu=True, drop_p=0.1, seed=7), a.rounds),
+                    2.0 * M * n * 256, 2.0 * M * (256 + n + 256))
             rec(f"ln_gemm[M,{n},256].blas_nolN", timeit(lambda: torch.addmm(b.to(BF), x, w.t()), a.rounds), 2.0 * M * n * 256)
     # ---- TN (weight gradient) GEMMs
     if want("gemm_tn"):
