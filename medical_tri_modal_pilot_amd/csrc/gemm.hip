@@ -21,10 +21,12 @@
 // 8/16-byte pieces of its own row.  Weights arrive in the compute dtype (bf16 shadow copy or
 // fp32 master), gamma/beta/bias always fp32.
 #include "common.cuh"
+#include <type_traits>
 
 // Diagnostic build only (make stamp): s_memtime stamps around the phases of the gemm_tn token loop.
 #ifdef MTMP_STAMP
 __device__ unsigned long long g_stamp_tn[8];
+__device__ unsigned long long g_stamp_lng[1024 * 2];      // per workgroup (wave 0): prologue, panel loop
 #define TSTAMP(var)                                                                                  \
     {                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                           \
@@ -422,8 +424,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 // permuting the 16-byte chunks inside a row instead of padding it: chunk c of panel row R sits at position c ^ (R & 15) (the
 // lanes of one ds_read_b128 service group hold 16 rows that are distinct mod 16).  The permutation is applied on the SOURCE
 // side (each lane picks the global chunk that belongs at its fixed LDS slot), the reader XORs its chunk index.
-// Order of one panel iteration: issue DMA(j+1) -> bias -> 32 MFMAs on panel j -> epilogue (4 row-piece stores per wave) ->
-// s_waitcnt vmcnt(4) (the DMA is older than exactly those four stores) -> barrier.
+// A panel is two accumulator groups of 32 features; the loop is rotated so that the epilogue of one group (vector work + the
+// staging round trip) is issued between the MFMAs of the other: [MFMA g1(j) | epilogue g0(j)] -> s_waitcnt vmcnt(4) (DMA(j+1)
+// is older than exactly the four row-piece stores of the last two epilogues) -> barrier -> DMA(j+2) -> [MFMA g0(j+1) |
+// epilogue g1(j)].
 struct PanelDma {
     static constexpr int NP = 64, G = 2, FS = 40, LPT = 4, PASSES = 2, MAXP = 16;   // MAXP panels (1024 features) per workgroup
     static constexpr unsigned panel_bytes = NP * 512, stage_off = 2 * panel_bytes, bias_off = stage_off + 4 * 32 * FS * 2;
@@ -461,6 +465,10 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dma16(dsrc[i], src, lds0 + buf * P::panel_bytes + (unsigned)(8 * wave + i) * 1024u);
     };
+#ifdef MTMP_STAMP
+    unsigned long long ts0, ts1, ts2;
+    TSTAMP(ts0)
+#endif
     panel_dma(j0, 0);
     if (p.gamma) {
         sG[tid] = p.gamma[tid];
@@ -511,65 +519,143 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     const char* rd[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) rd[c] = smem_raw + r * 512 + 16 * ((2 * c + half) ^ (r & 15));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // panel j0 landed (this wave's share)
+    panel_dma(min(j0 + 1, j1 - 1), 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // panels j0, j0 + 1 landed (this wave's share)
     __syncthreads();                                             // ... everyone's; sB written; sG dead (sS may be written)
-    for (int j = j0; j < j1; ++j) {
-        const int n0 = j * P::NP, buf = (j - j0) & 1;
-        panel_dma(min(j + 1, j1 - 1), buf ^ 1);                  // (a harmless repeat after the last panel keeps vmcnt static)
-        const char* cur = reinterpret_cast<const char*>(0) + buf * P::panel_bytes;
-        f32x16 acc[P::G];
+    f32x16 acc[P::G];
+    // One phase = the 16 MFMAs of accumulator group gm of panel jm, issued in eight slices of two; between them (EPI) the
+    // epilogue of group ge of panel je, cut into eight pieces of vector work: per 4 features [mask hash] and [ReLU / select /
+    // round / park in the staging tile].  sched_barrier(0) between slices keeps hipcc from regrouping them (left alone it
+    // issues the MFMAs back to back, and a wave cannot issue past an MFMA that waits for the matrix pipe); inside a slice the
+    // order is MFMA, half of the piece, MFMA, the other half.  Weight fragments are read eight MFMAs ahead.
+    // The staging tile of an epilogue is drained (two ds_read_b128 + two row-piece stores) in the first slices of the NEXT phase,
+    // so that LDS round trip also runs under MFMAs; a wave's LDS instructions execute in order, so the next epilogue's first
+    // ds_write (slice 1) cannot overtake those reads.
+    auto drain_load = [&](u32x4_t (&d)[P::PASSES]) {
 #pragma unroll
-        for (int g = 0; g < P::G; ++g)
+        for (int ps = 0; ps < P::PASSES; ++ps)
+            d[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + (tok + ps * (64 / P::LPT)) * P::FS) + 16 * ch);
+    };
+    auto drain_store = [&](const u32x4_t (&d)[P::PASSES], int jp, int gp) {
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (n0 - j0 * P::NP) + 32 * g + 8 * i4 + 4 * half);
-                acc[g][4 * i4] = v[0]; acc[g][4 * i4 + 1] = v[1]; acc[g][4 * i4 + 2] = v[2]; acc[g][4 * i4 + 3] = v[3];
-            }
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-            for (int g = 0; g < P::G; ++g) {
-                Frag<T> b;
-                b.v = *reinterpret_cast<const bf16x8*>(rd[c & 7] + (size_t)cur + g * 16384 + (c >> 3) * 256);
-                mma<T>(acc[g], b, af[c]);
-            }
-        // issue order: the bias block and the first eight weight fragments, then one fragment read per MFMA (eight ahead)
-        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-#pragma unroll
-        for (int k = 0; k < 24; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        for (int ps = 0; ps < P::PASSES; ++ps) {
+            const int t = tok + ps * (64 / P::LPT);
+            T* dst = p.y + (size_t)min(m_wave + t, p.M - 1) * p.ldy + jp * P::NP + 32 * gp;
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst) + 16 * ch) = d[ps];
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    auto phase = [&](int jm, int gm, int je, int ge, auto epi_tag, int jp, int gp, auto pend_tag) {
+        constexpr bool EPI = decltype(epi_tag)::value, PEND = decltype(pend_tag)::value;
+        const size_t cur = (size_t)(((jm - j0) & 1) * P::panel_bytes + gm * 16384);
+        const int n0 = je * P::NP;
 #pragma unroll
-        for (int g = 0; g < P::G; ++g) {
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (jm - j0) * P::NP + 32 * gm + 8 * i4 + 4 * half);
+            acc[gm][4 * i4] = v[0]; acc[gm][4 * i4 + 1] = v[1]; acc[gm][4 * i4 + 2] = v[2]; acc[gm][4 * i4 + 3] = v[3];
+        }
+        Frag<T> b[16];
 #pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const int col = n0 + 32 * g + 8 * i4 + 4 * half;
-                unsigned fld[4];
-                if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
-                float v[4];
+        for (int c = 0; c < 8; ++c) b[c].v = *reinterpret_cast<const bf16x8*>(rd[c] + cur);
+        u32x4_t dr[P::PASSES];
+        if (PEND) {
+            wave_lds_handover();
+            drain_load(dr);
+            wave_lds_handover();
+        }
+        unsigned fld[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = acc[g][4 * i4 + i];
-                    if (RELU) v[i] = relu1(v[i]);
-                    if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
+        for (int s8 = 0; s8 < 8; ++s8) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s8 < 4) {
+                b[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd[2 * s8] + cur + 256);
+                b[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd[2 * s8 + 1] + cur + 256);
+            }
+            mma<T>(acc[gm], b[2 * s8], af[2 * s8]);
+            mma<T>(acc[gm], b[2 * s8 + 1], af[2 * s8 + 1]);
+            if (PEND && s8 == 0) drain_store(dr, jp, gp);
+            if (EPI) {
+                const int i4 = s8 >> 1;
+                if ((s8 & 1) == 0) {
+                    const int col = n0 + 32 * ge + 8 * i4 + 4 * half;
+                    if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = acc[ge][4 * i4 + i];
+                        if (RELU) v[i] = relu1(v[i]);
+                        if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
+                    }
+                    store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
                 }
-                store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+                constexpr int NV = DROP ? 9 : 3;
+                if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV + 2, 0);
             }
-            wave_lds_handover();
-#pragma unroll
-            for (int ps = 0; ps < P::PASSES; ++ps) {
-                const int t = tok + ps * (64 / P::LPT);
-                const u32x4_t d = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + t * P::FS) + 16 * ch);
-                T* dst = p.y + (size_t)min(m_wave + t, p.M - 1) * p.ldy + n0 + 32 * g;
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst) + 16 * ch) = d;
-            }
-            wave_lds_handover();
         }
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P::G * P::PASSES) : "memory");   // DMA(j+1) done; this panel's stores may fly
-        __syncthreads();                                         // panel j+1 visible to all waves, panel j free for DMA(j+2)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the last group's epilogue has no MFMAs left to hide under
+    auto epi_alone = [&](int j, int g, int jp, int gp) {
+        u32x4_t dr[P::PASSES];
+        wave_lds_handover();
+        drain_load(dr);
+        wave_lds_handover();
+        drain_store(dr, jp, gp);
+        const int n0 = j * P::NP;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int col = n0 + 32 * g + 8 * i4 + 4 * half;
+            unsigned fld[4];
+            if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc[g][4 * i4 + i];
+                if (RELU) v[i] = relu1(v[i]);
+                if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
+            }
+            store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+        }
+        wave_lds_handover();
+        drain_load(dr);
+        drain_store(dr, j, g);
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    // phases of panel j: A(j) = [MFMA g0(j) | epilogue g1(j-1) | drain g0(j-1)], B(j) = [MFMA g1(j) | epilogue g0(j) | drain g1(j-1)]
+#ifdef MTMP_STAMP
+    TSTAMP(ts1)
+#endif
+    phase(j0, 0, 0, 0, No{}, 0, 0, No{});
+    if (j0 < j1 - 1) {
+        phase(j0, 1, j0, 0, Yes{}, 0, 0, No{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        panel_dma(min(j0 + 2, j1 - 1), 0);
+        phase(j0 + 1, 0, j0, 1, Yes{}, j0, 0, Yes{});
+        for (int j = j0 + 1; j < j1 - 1; ++j) {
+            phase(j, 1, j, 0, Yes{}, j - 1, 1, Yes{});
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P::PASSES) : "memory");   // DMA(j+1) is older than the last two drains
+            __syncthreads();                                     // panel j+1 visible to all waves, panel j free
+            panel_dma(min(j + 2, j1 - 1), (j - j0) & 1);         // (a harmless repeat at the end keeps vmcnt static)
+            phase(j + 1, 0, j, 1, Yes{}, j, 0, Yes{});
+        }
+        phase(j1 - 1, 1, j1 - 1, 0, Yes{}, j1 - 2, 1, Yes{});
+    } else {
+        phase(j0, 1, j0, 0, Yes{}, 0, 0, No{});
     }
+    epi_alone(j1 - 1, 1, j1 - 1, 0);
+#ifdef MTMP_STAMP
+    TSTAMP(ts2)
+    if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
+        g_stamp_lng[2 * blockIdx.x] = ts1 - ts0;
+        g_stamp_lng[2 * blockIdx.x + 1] = ts2 - ts1;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1345,6 +1431,9 @@ extern "C" int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long l
 
 #ifdef MTMP_STAMP
 // diagnostic build: read and clear {barrier 1, load wait + transpose + LDS write, barrier 2, fetch issue + MFMA, steps}
+extern "C" int mtmp_debug_stamps_lng(unsigned long long* out2048) {
+    return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_stamp_lng), 2048 * sizeof(unsigned long long)) != hipSuccess;
+}
 extern "C" int mtmp_debug_stamps_tn(unsigned long long* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_tn), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
     unsigned long long z[8] = {0};
