@@ -227,33 +227,6 @@ MTMP_DEV void dropout_fields4(unsigned seed, unsigned g, unsigned (&f)[4]) {
     unsigned x = (g * 0x9E3779B1u) ^ seed;
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     unsigned y = x * 0x27D4EB2Fu; y ^= y >> 15;
-    return ((x & 0xFFFFu) >= thr ? 1u : 0u) | ((x >> 16) >= thr ? 2u : 0u) | ((y & 0xFFFFu) >= thr ? 4u : 0u) |
-           ((y >> 16) >= thr ? 8u : 0u);
-}
-
-// The same four decisions as 16-bit fields (element 4g+i is kept iff f[i] >= thr): a caller that compares the fields itself
-// feeds the compare result straight into its select instead of building the 4-bit mask and testing it again
-// (4 instructions per element less in the GEMM epilogues).
-MTMP_DEV void dropout_fields4(unsigned seed, unsigned g, unsigned (&f)[4]) {
-#ifdef MTMP_CHEAPHASH      // (diagnostic: what does the hash itself cost?  statistics are wrong)
-    {
-        unsigned x = g ^ seed; x ^= x >> 7; unsigned y = x + 0x9E3779B1u;
-        f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
-        return;
-    }
-#endif
-#ifdef MTMP_HASH24         // (diagnostic: 24-bit multiplies)
-    {
-        unsigned x = __builtin_amdgcn_mul_u24(g, 0x9E3779u) ^ seed;
-        x ^= x >> 16; x = __builtin_amdgcn_mul_u24(x, 0x85EBCBu) ^ (x >> 8); x ^= x >> 13; x = __builtin_amdgcn_mul_u24(x, 0xC2B2AFu) ^ (x << 9); x ^= x >> 16;
-        unsigned y = __builtin_amdgcn_mul_u24(x, 0x27D4EBu) ^ (x >> 11); y ^= y >> 15;
-        f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
-        return;
-    }
-#endif
-    unsigned x = (g * 0x9E3779B1u) ^ seed;
-    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-    unsigned y = x * 0x27D4EB2Fu; y ^= y >> 15;
     f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
 }
 // ReLU as ONE integer max (fmaxf() / fmed3 on an MFMA output cost an extra canonicalising v_max each): negative floats
