@@ -72,6 +72,20 @@ int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, con
                  int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed, const unsigned* seed_dev,
                  const void* gate, float gate_scale, const float* row_scale, int rows_per_scale, void* stream);
 
+/* Sign bits of a ReLU projection (bf16 build, N % 64 == 0): one bit per output, "y > 0", in the row-panel kernels' private
+ * order; mtmp_sign_bits_bytes(M, N) bytes (= M N / 8).
+ *   mtmp_ln_gemm_signs  = mtmp_ln_gemm with relu = 1 (module.py:74-77 + drop1) that also writes them;
+ *   mtmp_gemm_nt_signs  : y[M,N] = signs ? (a[M,256] w[N,256]^T) * gate_scale : 0 -- the FFN backward's dH = dY W2 taken
+ *     through the ReLU + drop1 of module.py:77-79 (autograd) without re-reading the M x N hidden activation, whose sign is
+ *     all that step needs: 4 MB of gate traffic per launch at config 2 instead of 132 MB.
+ * Other dtypes return MTMP_ERR_ARG (the fp32 build gates on the stored activation through mtmp_gemm_nt). */
+long long mtmp_sign_bits_bytes(int M, int N);
+int mtmp_ln_gemm_signs(int dtype, const void* x, const float* gamma, const float* beta, const void* w, const float* bias,
+                       void* y, void* xn, float* stats, int M, int N, int ldx, int ldy, float eps, float drop_p,
+                       unsigned seed, const unsigned* seed_dev, void* signs, void* stream);
+int mtmp_gemm_nt_signs(int dtype, const void* a, const void* w, void* y, int M, int N, int lda, int ldy,
+                       const void* signs, float gate_scale, void* stream);
+
 /* Weight / bias gradient of the Linear and k=1 Conv1d layers (attention.py:60-62, module.py:74-78):
  * dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db[N] (fp32, may be NULL) = column sums of dy.
  * N % 128 == 0, K % 128 == 0; the contraction runs over the M tokens (split over workgroups,

@@ -22,6 +22,7 @@
 // fp32 master), gamma/beta/bias always fp32.
 #include "common.cuh"
 #include <type_traits>
+template <int N> using template_int = std::integral_constant<int, N>;
 
 // Diagnostic build only (make stamp): s_memtime stamps around the phases of the gemm_tn token loop.
 #ifdef MTMP_STAMP
@@ -55,6 +56,7 @@ template <typename T> struct GemmArgs {
     int act;             // 0 none, 1 ReLU, 2 exact GELU (Swin MLP, swin_transformer.py:439)
     const float* row_scale;   // optional per-sample factor (row-mode StochasticDepth): y *= row_scale[row / rows_per_scale]
     int rows_per_scale;
+    unsigned short* signs = nullptr;   // row-panel kernels (bf16): 1 bit per output, "y > 0" -- written by the forward, read as the gate
 };
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread).  The loads are
@@ -439,7 +441,17 @@ MTMP_DEV void dma16(unsigned voff, const void* sbase, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_off) : "memory", "m0");
 }
 #pragma clang diagnostic pop
-template <bool RELU, bool DROP>
+// 2-byte global load the compiler does not count (the loop's vmcnt budget is kept by hand, see the phase list below); the
+// matching wait names the destination register as read-write so that no use can be scheduled above it.
+MTMP_DEV void gload_u16(unsigned& d, const void* ptr) { asm volatile("global_load_ushort %0, %1, off" : "=v"(d) : "v"(ptr) : "memory"); }
+template <int N> MTMP_DEV void gwait1(unsigned& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
+
+// SIGNS (forward, with RELU): besides y the kernel writes one bit per output, "y > 0", 16 bits per lane and 32-feature group in
+// the lane's own accumulator order: signs[((2 j + g) M + row) 2 + half] for panel j, group g.  GATE (backward): the FFN's
+// dH = dY W2 gated by the saved hidden activation (y = h > 0 ? y * gate_scale : 0, autograd of module.py:77-79) reads those
+// bits instead of h itself -- the same kernel geometry, so a lane needs exactly the 16 bits its forward twin wrote: 4 MB of
+// gate traffic per launch at config 2 instead of 132 MB.  No LayerNorm in GATE mode (p.gamma == nullptr).
+template <bool RELU, bool DROP, bool GATE, bool SIGNS>
 __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     using T = bf16;
     using P = PanelDma;
@@ -477,37 +489,39 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     for (int i = tid; i < (j1 - j0) * P::NP; i += 256) sB[i] = p.bias ? p.bias[j0 * P::NP + i] : 0.f;
     // ---- LayerNorm prologue, in registers: lane (r, half) holds k = 16c + 8*half + j of row r
     Frag<T> af[16];
-    float s1 = 0.f;
     const T* arow = p.a + (size_t)row * p.lda + 8 * half;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        af[c] = frag_load<T>(arow + 16 * c);
+    for (int c = 0; c < 16; ++c) af[c] = frag_load<T>(arow + 16 * c);
+    if constexpr (!GATE) {
+        float s1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
-    }
-    s1 += __shfl_xor(s1, 32, 64);
-    const float mean = s1 * (1.0f / 256.0f);
-    float s2 = 0.f;
+        for (int c = 0; c < 16; ++c)
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
+            for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.0f / 256.0f);
+        float s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
-    s2 += __shfl_xor(s2, 32, 64);
-    const float sigma = sqrtf(s2 * (1.0f / 255.0f));             // torch.std: Bessel-corrected
-    const float rs = 1.0f / (sigma + p.eps);
-    __syncthreads();                                             // sG ready
-    if (p.gamma) {
+        for (int c = 0; c < 16; ++c)
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int k = 16 * c + 8 * half;
+            for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
+        s2 += __shfl_xor(s2, 32, 64);
+        const float sigma = sqrtf(s2 * (1.0f / 255.0f));         // torch.std: Bessel-corrected
+        const float rs = 1.0f / (sigma + p.eps);
+        __syncthreads();                                         // sG ready
+        if (p.gamma) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
-            if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
-        }
-        if (p.stats && half == 0 && blockIdx.y == 0) {
-            p.stats[2 * (size_t)row] = mean;
-            p.stats[2 * (size_t)row + 1] = rs;
+            for (int c = 0; c < 16; ++c) {
+                const int k = 16 * c + 8 * half;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
+                if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
+            }
+            if (p.stats && half == 0 && blockIdx.y == 0) {
+                p.stats[2 * (size_t)row] = mean;
+                p.stats[2 * (size_t)row + 1] = rs;
+            }
         }
     }
     const unsigned thr = dropout_threshold(p.drop_p);
@@ -531,6 +545,12 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     // The staging tile of an epilogue is drained (two ds_read_b128 + two row-piece stores) in the first slices of the NEXT phase,
     // so that LDS round trip also runs under MFMAs; a wave's LDS instructions execute in order, so the next epilogue's first
     // ds_write (slice 1) cannot overtake those reads.
+    constexpr int NG = GATE ? 1 : 0, NS = SIGNS ? 1 : 0;         // gate loads / sign stores per tile
+    auto tile_ptr = [&](const T* base, int ld, int jp, int gp, int ps) {
+        const int t = tok + ps * (64 / P::LPT);
+        return reinterpret_cast<const char*>(base + (size_t)min(m_wave + t, p.M - 1) * ld + jp * P::NP + 32 * gp) + 16 * ch;
+    };
+    auto signs_ptr = [&](int j, int g) { return p.signs + ((size_t)(2 * j + g) * p.M + row) * 2 + half; };
     auto drain_load = [&](u32x4_t (&d)[P::PASSES]) {
 #pragma unroll
         for (int ps = 0; ps < P::PASSES; ++ps)
@@ -538,16 +558,47 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     };
     auto drain_store = [&](const u32x4_t (&d)[P::PASSES], int jp, int gp) {
 #pragma unroll
-        for (int ps = 0; ps < P::PASSES; ++ps) {
-            const int t = tok + ps * (64 / P::LPT);
-            T* dst = p.y + (size_t)min(m_wave + t, p.M - 1) * p.ldy + jp * P::NP + 32 * gp;
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst) + 16 * ch) = d[ps];
-        }
+        for (int ps = 0; ps < P::PASSES; ++ps) *reinterpret_cast<u32x4_t*>(const_cast<char*>(tile_ptr(p.y, p.ldy, jp, gp, ps))) = d[ps];
     };
-    auto phase = [&](int jm, int gm, int je, int ge, auto epi_tag, int jp, int gp, auto pend_tag) {
+    // one 4-feature piece of an epilogue: activation / dropout / gate, sign bits, rounding, parked in the staging tile
+    auto piece = [&](int g, int i4, const unsigned (&fld)[4], unsigned gate_bits, unsigned& sign_bits) {
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = acc[g][4 * i4 + i];
+            if (SIGNS) {       // "positive and kept" as ONE lane mask: it selects the value and is shifted into the collection
+                unsigned long long lm = __builtin_amdgcn_ballot_w64(v[i] > 0.f);
+                if (DROP) lm &= __builtin_amdgcn_ballot_w64(fld[i] >= thr);
+                const float sv = DROP ? v[i] * keep_scale : v[i];
+                // v = lm ? sv : 0;  sign_bits = 2 * sign_bits + lm  (one add-with-carry whose carry-in is the lane mask; written in
+                // C++ hipcc rebuilds the mask from a 0/1 register and spells the update with two selects, a shift and an or).
+                // s_nop: a compare result read as a mask by the very next vector instruction is a hazard nobody checks inside asm.
+                asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %2, %3\n\tv_addc_co_u32_e64 %1, vcc, %1, %1, %3"
+                    : "=&v"(v[i]), "+v"(sign_bits) : "v"(sv), "s"(lm) : "vcc");
+            } else {
+                if (RELU) v[i] = relu1(v[i]);
+                if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
+            }
+            if (GATE)          // bit 15 - (4 i4 + i) of the lane's 16: all ones or zero, and-ed onto the scaled value
+                v[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[i] * p.gate_scale) &
+                                                     __builtin_amdgcn_sbfe((int)gate_bits, 15 - (4 * i4 + i), 1));
+        }
+        store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+    };
+    // One phase = the 16 MFMAs of accumulator group gm of panel jm, issued in eight slices of two; between them (EPI) the
+    // epilogue of group ge of panel je, cut into eight pieces of vector work: per 4 features [mask hash] and [ReLU / select /
+    // round / park in the staging tile], and (PEND) the drain of the previous phase's tile.  sched_barrier(0) between slices
+    // keeps hipcc from regrouping them (left alone it issues the MFMAs back to back, and a wave cannot issue past an MFMA that
+    // waits for the matrix pipe); inside a slice the order is MFMA, half of the piece, MFMA, the other half.  Weight fragments
+    // are read eight MFMAs ahead.  gnext / gcur: gate bits of the group being multiplied (loaded here) and of the epilogue's
+    // group (loaded one phase ago; GW = vector-memory operations issued since, i.e. the vmcnt that proves them landed).
+    auto phase = [&](int jm, int gm, int je, int ge, auto epi_tag, int jp, int gp, auto pend_tag, unsigned& gnext, unsigned& gcur,
+                     auto gw_tag) {
         constexpr bool EPI = decltype(epi_tag)::value, PEND = decltype(pend_tag)::value;
+        constexpr int GW = decltype(gw_tag)::value;
         const size_t cur = (size_t)(((jm - j0) & 1) * P::panel_bytes + gm * 16384);
         const int n0 = je * P::NP;
+        if (GATE) gload_u16(gnext, signs_ptr(jm, gm));
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (jm - j0) * P::NP + 32 * gm + 8 * i4 + 4 * half);
@@ -562,7 +613,8 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
             drain_load(dr);
             wave_lds_handover();
         }
-        unsigned fld[4];
+        if (GATE && EPI) gwait1<GW>(gcur);
+        unsigned fld[4], sign_bits = 0;
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             __builtin_amdgcn_sched_barrier(0);
@@ -579,14 +631,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
                     const int col = n0 + 32 * ge + 8 * i4 + 4 * half;
                     if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
                 } else {
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[i] = acc[ge][4 * i4 + i];
-                        if (RELU) v[i] = relu1(v[i]);
-                        if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
-                    }
-                    store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+                    piece(ge, i4, fld, gcur, sign_bits);
                 }
                 constexpr int NV = DROP ? 9 : 3;
                 if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -597,58 +642,59 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (SIGNS && EPI) *signs_ptr(je, ge) = (unsigned short)sign_bits;
     };
     // the last group's epilogue has no MFMAs left to hide under
-    auto epi_alone = [&](int j, int g, int jp, int gp) {
+    auto epi_alone = [&](int j, int g, int jp, int gp, unsigned& gcur) {
         u32x4_t dr[P::PASSES];
         wave_lds_handover();
         drain_load(dr);
         wave_lds_handover();
         drain_store(dr, jp, gp);
+        if (GATE) gwait1<0>(gcur);
         const int n0 = j * P::NP;
+        unsigned sign_bits = 0;
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
             const int col = n0 + 32 * g + 8 * i4 + 4 * half;
             unsigned fld[4];
             if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = acc[g][4 * i4 + i];
-                if (RELU) v[i] = relu1(v[i]);
-                if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
-            }
-            store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+            piece(g, i4, fld, gcur, sign_bits);
         }
+        if (SIGNS) *signs_ptr(j, g) = (unsigned short)sign_bits;
         wave_lds_handover();
         drain_load(dr);
         drain_store(dr, j, g);
     };
     using Yes = std::true_type;
     using No = std::false_type;
-    // phases of panel j: A(j) = [MFMA g0(j) | epilogue g1(j-1) | drain g0(j-1)], B(j) = [MFMA g1(j) | epilogue g0(j) | drain g1(j-1)]
-#ifdef MTMP_STAMP
-    TSTAMP(ts1)
-#endif
-    phase(j0, 0, 0, 0, No{}, 0, 0, No{});
+    // Phases of panel j: A(j) = [MFMA g0(j) | epilogue g1(j-1) | drain g0(j-1)], B(j) = [MFMA g1(j) | epilogue g0(j) | drain g1(j-1)].
+    // Vector-memory operations in issue order (G = the gate load of the group being multiplied, S = the PASSES row-piece stores
+    // of a drain + the sign store of an epilogue):
+    //   ... B(j): G S | barrier | DMA(j+2) x8 | A(j+1): G S | B(j+1): G S | wait DMA | barrier ...
+    // so DMA(j+2) is older than 2 (G + S) operations when it is waited for; the gate bits an A phase's epilogue uses (loaded at
+    // the top of the B phase before) are older than S + 8 + G, a B phase's than S + G.
+    constexpr int NST = P::PASSES + NS, WDMA = 2 * (NG + NST), WA = NST + 8 + NG, WB = NST + NG;
+    unsigned g0bits = 0, g1bits = 0;                             // gate bits of the g = 0 / g = 1 group in flight
+    phase(j0, 0, 0, 0, No{}, 0, 0, No{}, g0bits, g1bits, template_int<0>{});
     if (j0 < j1 - 1) {
-        phase(j0, 1, j0, 0, Yes{}, 0, 0, No{});
+        phase(j0, 1, j0, 0, Yes{}, 0, 0, No{}, g1bits, g0bits, template_int<NG>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         panel_dma(min(j0 + 2, j1 - 1), 0);
-        phase(j0 + 1, 0, j0, 1, Yes{}, j0, 0, Yes{});
+        phase(j0 + 1, 0, j0, 1, Yes{}, j0, 0, Yes{}, g0bits, g1bits, template_int<8 + NG>{});   // (nothing was drained yet)
         for (int j = j0 + 1; j < j1 - 1; ++j) {
-            phase(j, 1, j, 0, Yes{}, j - 1, 1, Yes{});
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P::PASSES) : "memory");   // DMA(j+1) is older than the last two drains
+            phase(j, 1, j, 0, Yes{}, j - 1, 1, Yes{}, g1bits, g0bits, template_int<WB>{});
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WDMA) : "memory");
             __syncthreads();                                     // panel j+1 visible to all waves, panel j free
             panel_dma(min(j + 2, j1 - 1), (j - j0) & 1);         // (a harmless repeat at the end keeps vmcnt static)
-            phase(j + 1, 0, j, 1, Yes{}, j, 0, Yes{});
+            phase(j + 1, 0, j, 1, Yes{}, j, 0, Yes{}, g0bits, g1bits, template_int<WA>{});
         }
-        phase(j1 - 1, 1, j1 - 1, 0, Yes{}, j1 - 2, 1, Yes{});
+        phase(j1 - 1, 1, j1 - 1, 0, Yes{}, j1 - 2, 1, Yes{}, g1bits, g0bits, template_int<WB>{});
     } else {
-        phase(j0, 1, j0, 0, Yes{}, 0, 0, No{});
+        phase(j0, 1, j0, 0, Yes{}, 0, 0, No{}, g1bits, g0bits, template_int<NG>{});
     }
-    epi_alone(j1 - 1, 1, j1 - 1, 0);
+    epi_alone(j1 - 1, 1, j1 - 1, 0, g1bits);
 #ifdef MTMP_STAMP
     TSTAMP(ts2)
     if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
@@ -1046,12 +1092,16 @@ int tn_splits(int M, int N, int K, int target_wgs) {
     return s < 1 ? 1 : s;
 }
 
-int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, hipStream_t st) {
+// mode: 0 forward (relu / dropout from the arguments; a.signs != nullptr with relu: also write the sign bits), 1 gate by a.signs
+int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, int gate, hipStream_t st) {
     using P = PanelDma;
-    const void* fs[4] = {(const void*)ln_gemm_dma_kernel<false, false>, (const void*)ln_gemm_dma_kernel<false, true>,
-                         (const void*)ln_gemm_dma_kernel<true, false>, (const void*)ln_gemm_dma_kernel<true, true>};
-    const void* f = fs[(relu ? 2 : 0) + (a.drop_p > 0.f ? 1 : 0)];
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
+    const bool drop = a.drop_p > 0.f, signs = !gate && relu && a.signs;
+    const void* fs[7] = {(const void*)ln_gemm_dma_kernel<false, false, false, false>, (const void*)ln_gemm_dma_kernel<false, true, false, false>,
+                         (const void*)ln_gemm_dma_kernel<true, false, false, false>, (const void*)ln_gemm_dma_kernel<true, true, false, false>,
+                         (const void*)ln_gemm_dma_kernel<true, false, false, true>, (const void*)ln_gemm_dma_kernel<true, true, false, true>,
+                         (const void*)ln_gemm_dma_kernel<false, false, true, false>};
+    const int which = gate ? 6 : signs ? 4 + (drop ? 1 : 0) : (relu ? 2 : 0) + (drop ? 1 : 0);
+    if (hipFuncSetAttribute(fs[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
         mtmp_set_error("mtmp_ln_gemm: cannot raise dynamic LDS to %zu", P::lds_bytes);
         return MTMP_ERR_LAUNCH;
     }
@@ -1062,11 +1112,15 @@ int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, hipStream_t st) {
     const int need = (npanels + P::MAXP - 1) / P::MAXP;
     if (nsplit < need) nsplit = need;
     dim3 grid(mtiles, nsplit);
-    const bool drop = a.drop_p > 0.f;
-    if (relu && drop)       hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true>), grid, dim3(256), P::lds_bytes, st, a);
-    else if (relu)          hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false>), grid, dim3(256), P::lds_bytes, st, a);
-    else if (drop)          hipLaunchKernelGGL((ln_gemm_dma_kernel<false, true>), grid, dim3(256), P::lds_bytes, st, a);
-    else                    hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false>), grid, dim3(256), P::lds_bytes, st, a);
+    switch (which) {
+    case 0: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
+    case 1: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, true, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
+    case 2: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
+    case 3: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
+    case 4: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false, false, true>), grid, dim3(256), P::lds_bytes, st, a); break;
+    case 5: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true, false, true>), grid, dim3(256), P::lds_bytes, st, a); break;
+    default: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, true, false>), grid, dim3(256), P::lds_bytes, st, a); break;
+    }
     MTMP_CHECK_LAUNCH("mtmp_ln_gemm");
     return MTMP_OK;
 }
@@ -1078,7 +1132,7 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
         return MTMP_ERR_ARG;
     }
 #ifndef MTMP_LNG_OLD
-    if constexpr (sizeof(T) == 2) return launch_ln_gemm_dma(a, relu, st);
+    if constexpr (sizeof(T) == 2) return launch_ln_gemm_dma(a, relu, 0, st);
 #endif
     if (sm > 48 * 1024) {
         const void* fs[4] = {(const void*)ln_gemm_kernel<T, false, false>, (const void*)ln_gemm_kernel<T, false, true>,
@@ -1298,13 +1352,14 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
 // Y[M,N] = act(LN(X[M,256]; gamma, beta, eps) W[N,256]^T + bias); xn[M,256] and stats[M,2]
 // (mean, 1/(std+eps)) are optional outputs.  Replaces module.py:138-144 + attention.py:68-70
 // (relu=0, N=768) and module.py:138-144 + module.py:74-77 (relu=1, N=1024).
-extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, const void* w,
-                            const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
-                            float eps, int relu, float drop_p, unsigned seed, const unsigned* seed_dev, void* stream) {
+static int ln_gemm_entry(int dtype, const void* x, const float* gamma, const float* beta, const void* w, const float* bias,
+                         void* y, void* xn, float* stats, int M, int N, int ldx, int ldy, float eps, int relu, float drop_p,
+                         unsigned seed, const unsigned* seed_dev, void* signs, void* stream) {
     MTMP_CHECK_ARG(x && gamma && beta && w && y, "mtmp_ln_gemm: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && N % 32 == 0 && ldx >= 256 && ldx % 8 == 0 && ldy >= N && ldy % 8 == 0,
                    "mtmp_ln_gemm: bad shape M=%d N=%d ldx=%d ldy=%d (K is fixed at 256)", M, N, ldx, ldy);
     MTMP_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f && (double)M * N < 4294967296.0, "mtmp_ln_gemm: bad dropout %f", drop_p);
+    MTMP_CHECK_ARG(!signs || (dtype == 1 && relu && N % PanelDma::NP == 0), "mtmp_ln_gemm_signs: bf16, ReLU and N %% 64 == 0 only");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         GemmArgs<float> a{(const float*)x, (const float*)w, bias, nullptr, (float*)y, gamma, beta, (float*)xn, stats,
@@ -1313,11 +1368,37 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
     }
     if (dtype == 1) {
         GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, gamma, beta, (bf16*)xn, stats,
-                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, seed_dev, nullptr, 1.f, 0, nullptr, 1};
+                         M, N, 256, ldx, ldy, 0, eps, drop_p, seed, seed_dev, nullptr, 1.f, 0, nullptr, 1, (unsigned short*)signs};
         return launch_ln_gemm<bf16>(a, relu, st);
     }
     mtmp_set_error("mtmp_ln_gemm: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
+}
+extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta, const void* w,
+                            const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
+                            float eps, int relu, float drop_p, unsigned seed, const unsigned* seed_dev, void* stream) {
+    return ln_gemm_entry(dtype, x, gamma, beta, w, bias, y, xn, stats, M, N, ldx, ldy, eps, relu, drop_p, seed, seed_dev, nullptr, stream);
+}
+// Sign bits of a ReLU projection (bf16 build of the row-panel kernels only): one bit per output, "y > 0", in the kernels'
+// private order; mtmp_sign_bits_bytes(M, N) bytes.  mtmp_ln_gemm_signs = mtmp_ln_gemm (relu = 1) that also writes them;
+// mtmp_gemm_nt_signs: Y[M,N] = signs ? (A[M,256] W[N,256]^T) * gate_scale : 0 -- the FFN backward's dH = dY W2 through the
+// ReLU + dropout of module.py:77-79 without re-reading the M x N hidden activation (its sign is all the backward needs).
+extern "C" long long mtmp_sign_bits_bytes(int M, int N) { return (long long)(N / 32) * M * 4; }
+extern "C" int mtmp_ln_gemm_signs(int dtype, const void* x, const float* gamma, const float* beta, const void* w,
+                                  const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
+                                  float eps, float drop_p, unsigned seed, const unsigned* seed_dev, void* signs, void* stream) {
+    MTMP_CHECK_ARG(signs, "mtmp_ln_gemm_signs: null pointer");
+    return ln_gemm_entry(dtype, x, gamma, beta, w, bias, y, xn, stats, M, N, ldx, ldy, eps, 1, drop_p, seed, seed_dev, signs, stream);
+}
+extern "C" int mtmp_gemm_nt_signs(int dtype, const void* a, const void* w, void* y, int M, int N, int lda, int ldy,
+                                  const void* signs, float gate_scale, void* stream) {
+    MTMP_CHECK_ARG(a && w && y && signs, "mtmp_gemm_nt_signs: null pointer");
+    MTMP_CHECK_ARG(dtype == 1, "mtmp_gemm_nt_signs: bf16 only (dtype %d)", dtype);
+    MTMP_CHECK_ARG(M > 0 && N > 0 && N % PanelDma::NP == 0 && lda >= 256 && lda % 8 == 0 && ldy >= N && ldy % 8 == 0,
+                   "mtmp_gemm_nt_signs: bad shape M=%d N=%d lda=%d ldy=%d (K is fixed at 256)", M, N, lda, ldy);
+    GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, nullptr, nullptr, (bf16*)y, nullptr, nullptr, nullptr, nullptr, M, N, 256, lda, ldy,
+                     0, 0.f, 0.f, 0u, nullptr, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs};
+    return launch_ln_gemm_dma(g, 0, 1, (hipStream_t)stream);
 }
 
 // Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32

@@ -94,16 +94,33 @@ def set_seed_word(t: Optional[torch.Tensor]):
 
 
 # ----------------------------------------------------------------------------- raw kernels
-def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, want_xn=True):
-    """y = act(LN(x) w^T + bias); returns (y[M,n_out], xn[M,256] | None, stats[M,2])."""
+def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, want_xn=True, want_signs=False):
+    """y = act(LN(x) w^T + bias); returns (y[M,n_out], xn[M,256] | None, stats[M,2]) -- with want_signs (ReLU only) a fourth
+    item: the sign bits of y for gemm_nt_signs (bf16 and n_out % 64 == 0), else None."""
     _gpu(x2d, w)
     M = x2d.shape[0]
     y = torch.empty(M, n_out, dtype=x2d.dtype, device=x2d.device)
     xn = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=x2d.device) if want_xn else None
     stats = torch.empty(M, 2, dtype=torch.float32, device=x2d.device)
+    if want_signs and not relu:
+        raise ValueError("ln_gemm: sign bits are those of a ReLU output")
+    if want_signs and x2d.dtype == torch.bfloat16 and n_out % 64 == 0:
+        signs = torch.empty(_lib.lib().mtmp_sign_bits_bytes(M, n_out), dtype=torch.uint8, device=x2d.device)
+        call("mtmp_ln_gemm_signs", _dt(x2d), _p(x2d), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), _p(xn), _p(stats),
+             M, n_out, x2d.stride(0), n_out, LN_EPS, float(drop_p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _p(signs), _stream())
+        return y, xn, stats, signs
     call("mtmp_ln_gemm", _dt(x2d), _p(x2d), _p(gamma), _p(beta), _p(w), _p(bias), _p(y), _p(xn), _p(stats),
          M, n_out, x2d.stride(0), n_out, LN_EPS, int(relu), float(drop_p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _stream())
-    return y, xn, stats
+    return (y, xn, stats, None) if want_signs else (y, xn, stats)
+
+
+def gemm_nt_signs(a2d, w, signs, gate_scale=1.0):
+    """y[M,N] = signs ? (a[M,256] w[N,256]^T) * gate_scale : 0 (bf16; signs from ln_gemm(..., want_signs=True))."""
+    _gpu(a2d, w, signs)
+    M, N = a2d.shape[0], w.shape[0]
+    y = torch.empty(M, N, dtype=a2d.dtype, device=a2d.device)
+    call("mtmp_gemm_nt_signs", _dt(a2d), _p(a2d), _p(w), _p(y), M, N, a2d.stride(0), N, _p(signs), float(gate_scale), _stream())
+    return y
 
 
 ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
@@ -581,9 +598,9 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     qkv = qkv.view(B, N, 3 * D)
     o, r1, lse = attn_fwd(qkv, kv_len, res=z)
     r1_2 = r1.view(M, D)
-    h, xn2, st2 = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0])
+    h, xn2, st2, hsign = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
     out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
-    saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds)
+    saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds, hsign)
     return out.view(B, N, D), saved
 
 
@@ -618,7 +635,7 @@ def layer_backward(saved, d_out, sink=None):
     """d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
     in PARAMS order; weights as 2-D [out,in])) -- or (dz, None) when the gradients went straight into
     the flat gradient buffer through `sink`."""
-    z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds = saved
+    z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds, hsign = saved
     B, N, D = z.shape
     M = B * N
     d_out = d_out.view(M, D)
@@ -626,8 +643,12 @@ def layer_backward(saved, d_out, sink=None):
     dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
     direct = sink is not None and sink.usable()
     dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None)       # [256,1024], [256]
-    # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue
-    dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
+    # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue: from the forward's sign bits
+    # (bf16: M N / 8 bytes of gate instead of re-reading h) or, in the fp32 build, from h itself
+    if hsign is not None:
+        dh = gemm_nt_signs(dy2, w2t, hsign, 1.0 / (1.0 - p))
+    else:
+        dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
     dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None)      # [1024,256], [1024]
     # dXn2 = dH W1 and the backward of LN2 (+ the residual gradient) in one launch; the M x 256 product stays in LDS
     dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D), st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None)

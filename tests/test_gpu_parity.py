@@ -145,6 +145,53 @@ def test_ln_gemm_and_gemm_nt(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [4990, 20001, 33000])
+def test_row_panel_kernels_multi_panel(ops, dt, M):
+    """The row-panel kernels walk 1 / 2 / 4-6 / all 12-16 weight panels per workgroup depending on M (launch_ln_gemm*): every
+    loop shape of mtmp_ln_gemm and of the gated K = 256 mtmp_gemm_nt (dH of the FFN backward) against fp32 torch on the GPU."""
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = (torch.randn(M, 256, generator=g, device=DEV) * 2 + 0.3).to(dt)
+    gam = 1 + 0.1 * torch.randn(256, generator=g, device=DEV)
+    bet = 0.1 * torch.randn(256, generator=g, device=DEV)
+    xf = x.float()
+    mu, sd = xf.mean(-1, keepdim=True), xf.std(-1, keepdim=True)
+    xn_ref = gam * (xf - mu) / (sd + 1e-6) + bet
+    for N, relu in ((768, False), (1024, True)):
+        w = (torch.randn(N, 256, generator=g, device=DEV) / 16).to(dt)
+        b = 0.1 * torch.randn(N, generator=g, device=DEV)
+        y_ref = torch.nn.functional.linear(xn_ref.to(dt).float(), w.float(), b)
+        if relu:
+            y_ref = torch.relu(y_ref)
+        y, xn, st = ops.ln_gemm(x, gam, bet, w, b, N, relu=relu)
+        t = f"ln_gemm.panels[{str(dt)[6:]},M={M},N={N}]"
+        check(t + ".xn", xn.float(), xn_ref, TOL[dt] if dt == torch.float32 else 1e-2)
+        check(t + ".y", y.float(), y_ref, TOL[dt] if dt == torch.float32 else 2e-2)
+        assert torch.isfinite(y.float()).all()
+    dy = torch.randn(M, 256, generator=g, device=DEV).to(dt)
+    w2t = (torch.randn(1024, 256, generator=g, device=DEV) / 16).to(dt)
+    h = torch.relu(torch.randn(M, 1024, generator=g, device=DEV)).to(dt)
+    dh = ops.gemm_nt(dy, w2t, gate=h, gate_scale=1.0 / 0.9)
+    ref = torch.nn.functional.linear(dy.float(), w2t.float())
+    ref = torch.where(h.float() > 0, (ref.to(dt).float() if dt != torch.float32 else ref) * (1.0 / 0.9), torch.zeros_like(ref))
+    check(f"gemm_nt.gated.panels[{str(dt)[6:]},M={M}]", dh.float(), ref, TOL[dt] if dt == torch.float32 else 2e-2)
+    assert torch.all(dh.float()[h.float() <= 0] == 0)
+    # the same product gated by the forward's sign bits (bf16): bits of the ReLU (+ dropout) output, then dH against fp32 torch
+    for p_drop in (0.0, 0.1):
+        w1 = (torch.randn(1024, 256, generator=g, device=DEV) / 16).to(dt)
+        hh, _, _, signs = ops.ln_gemm(x, gam, bet, w1, None, 1024, relu=True, drop_p=p_drop, seed=77, want_signs=True)
+        if dt == torch.float32:
+            assert signs is None
+            continue
+        dh2 = ops.gemm_nt_signs(dy, w2t, signs, 1.0 / (1.0 - p_drop))
+        ref2 = torch.nn.functional.linear(dy.float(), w2t.float()) * (1.0 / (1.0 - p_drop))
+        ref2 = torch.where(hh.float() > 0, ref2, torch.zeros_like(ref2))
+        check(f"gemm_nt_signs.panels[M={M},p={p_drop}]", dh2.float(), ref2, 2e-2)
+        assert torch.equal(dh2.float() != 0, (hh.float() > 0) & (dh2.float() != 0)) and torch.all(dh2.float()[hh.float() <= 0] == 0)
+        nz = (hh.float() > 0) & (ref2.abs() > 1e-3)
+        assert torch.all(dh2.float()[nz] != 0)
+
+
+@pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(3456, 768, 256), (1000, 256, 1024), (70, 1024, 256), (20033, 256, 1024)])
 def test_gemm_tn_weight_gradient(ops, dt, M, N, K):
     g = torch.Generator().manual_seed(M)

@@ -56,7 +56,7 @@ def main():
         print(name, d, flush=True)
 
     def want(k):
-        return not only or any(k.startswith(o) for o in only)
+        return not only or any(k.startswith(o) or o.startswith(k) for o in only)
 
     # ---- NT GEMMs
     for name, (m, n, k) in {"gemm_nt.ffn2[M,256,1024]": (M, 256, 1024), "gemm_nt.dH[M,1024,256]": (M, 1024, 256),
@@ -75,6 +75,12 @@ def main():
     if want("gemm_nt"):             # dH = dY W2 gated by the saved hidden activation (FFN backward)
         dy, w2t, h = R(M, 256), R(1024, 256) * 0.05, R(M, 1024)
         rec("gemm_nt.dH_gated[M,1024,256]", timeit(lambda: ops.gemm_nt(dy, w2t, gate=h, gate_scale=1.0 / 0.9), a.rounds), 2.0 * M * 1024 * 256)
+    if want("gemm_nt"):             # the same product gated by the forward's sign bits
+        x0, w1 = R(M, 256), R(1024, 256) * 0.05
+        _, _, _, sg = ops.ln_gemm(x0, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), w1, None, 1024, relu=True, drop_p=0.1,
+                                  seed=3, want_signs=True)
+        rec("gemm_nt.dH_signs[M,1024,256]", timeit(lambda: ops.gemm_nt_signs(dy, w2t, sg, 1.0 / 0.9), a.rounds), 2.0 * M * 1024 * 256,
+            2.0 * M * (256 + 1024) + M * 128)
     # ---- LN-fused GEMMs
     if want("ln_gemm"):
         x = R(M, 256)
@@ -85,6 +91,9 @@ def main():
             rec(f"ln_gemm[M,{n},256]", timeit(lambda: ops.ln_gemm(x, gm, bt, w, b, n, relu=relu), a.rounds), 2.0 * M * n * 256,
                 2.0 * M * (256 + n + 256))
             if relu:
+                rec(f"ln_gemm[M,{n},256].drop.signs", timeit(lambda: ops.ln_gemm(x, gm, bt, w, b, n, relu=True, drop_p=0.1, seed=7,
+                                                                                   want_signs=True), a.rounds),
+                    2.0 * M * n * 256, 2.0 * M * (256 + n + 256))
                 rec(f"ln_gemm[M,{n},256].drop", timeit(lambda: ops.ln_gemm(x, gm, bt, w, b, n, relu=True, drop_p=0.1, seed=7), a.rounds),
                     2.0 * M * n * 256, 2.0 * M * (256 + n + 256))
             rec(f"ln_gemm[M,{n},256].blas_nolN", timeit(lambda: torch.addmm(b.to(BF), x, w.t()), a.rounds), 2.0 * M * n * 256)
