@@ -241,6 +241,18 @@ int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, 
                                  const long long* missing, int resbottle, const float* d_prev_in, float* d_prev_out,
                                  void* stream);
 
+/* Batched 2-D transposes in one launch: dst[i] [cols[i]][rows[i]] = src[i] [rows[i]][cols[i]]^T, elements of elem_bytes = 2 | 4.
+ * src / dst / rows / cols are HOST arrays of n entries (read at launch time; the pointers travel in the kernel arguments).
+ * The K-contiguous backward operands (W2^T, Wqkv^T, W1^T: autograd of attention.py:60-62 / module.py:74-78) of all encoder
+ * blocks, rebuilt after every optimizer step. */
+int mtmp_transpose_batch(int elem_bytes, const void* const* src, void* const* dst, const int* rows, const int* cols, int n,
+                         void* stream);
+
+/* Valid-key counts of the three streams in one launch (mbt_encoder.py:703-714): plain = len + 1 (CLS), stream txt_idx's
+ * 3 -> 0; fused = plain + n_bott.  len_*: int64 [B] or NULL (unmasked stream: rows left untouched); out: int32 [2][3][B]. */
+int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const long long* len_t, int* out, int B, int n_bott,
+                        int txt_idx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

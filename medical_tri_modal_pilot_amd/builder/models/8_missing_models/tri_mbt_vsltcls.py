@@ -117,6 +117,9 @@ class TRI_MBT_VSLTCLS(nn.Module):
             n_layers=self.num_layers, n_head=self.num_heads, d_model=self.model_dim, d_ff=self.model_dim * 4,
             dropout=self.dropout, vsltonly=self.args.mbt_only_vslt, pe_maxlen=2500,
             use_pe=[vslt_pe, False, True], mask=[True, img_mask, True], compute_dtype=self.compute_dtype)
+        # forward() reads nothing of the encoder's result but the vital-sign stream's CLS row (reference :248), so the last
+        # layer's image / text blocks are dead code on this path: the encoder neither runs them nor prepares their weights
+        self.fusion_transformer.first_stream_output_only = True
         # ---- classifier (reference :147-158)
         classifier_dim = self.model_dim if self.args.vslt_type == "QIE" else self.model_dim * 2
         self.rmse_layer = nn.Linear(classifier_dim, 1, bias=True)

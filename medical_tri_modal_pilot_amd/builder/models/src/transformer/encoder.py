@@ -101,7 +101,11 @@ class TransformerEncoderLayer(nn.Module):
                 stale.append((blk, key, parts))
         if stale:
             with torch.no_grad():
-                w2t, wqkvt, w1t = (torch.stack([p[j] for _, _, p in stale]).transpose(1, 2).contiguous() for j in (3, 0, 2))
+                if stale[0][2][0].is_cuda:         # one launch for the three transposes of every stale block
+                    ts = ops.transpose_batch([p[j].contiguous() for _, _, p in stale for j in (3, 0, 2)])
+                    w2t, wqkvt, w1t = ts[0::3], ts[1::3], ts[2::3]
+                else:
+                    w2t, wqkvt, w1t = (torch.stack([p[j] for _, _, p in stale]).transpose(1, 2).contiguous() for j in (3, 0, 2))
             for i, (blk, key, parts) in enumerate(stale):
                 blk._fused, blk._fused_key = parts + (w2t[i], wqkvt[i], w1t[i]), key
         return [blk._fused for blk in blocks]

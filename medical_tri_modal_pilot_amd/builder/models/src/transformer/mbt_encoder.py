@@ -94,7 +94,11 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         dev = enc_outputs[0].device
         B = enc_outputs[0].size(0)
         dt = self.compute_dtype
-        lens = self.key_lengths(varying_lengths, dev)
+        # valid-key counts: one HIP launch when the lengths are int64 device tensors (ops.stream_lengths), else key_lengths()
+        raw = [varying_lengths[m] if self.mask[m] else None for m in range(self.n_modality)]
+        one_launch = (dev.type == "cuda" and self.n_modality == 3 and any(v is not None for v in raw) and
+                      all(v is None or (torch.is_tensor(v) and v.is_cuda and v.dtype == torch.int64 and v.dim() == 1) for v in raw))
+        lens = None if one_launch else self.key_lengths(varying_lengths, dev)
         if fusion_idx is not None:
             self.fusion_idx = fusion_idx
         # stream input: [CLS | tokens] -> nn.LayerNorm (+ sinusoid PE) -> dropout  (:697-729)
@@ -122,8 +126,12 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             streams.append(self.dropout(y).to(dt))
         # (no join here when the inputs live on the side streams: ops.FusionStackFn issues each modality's first layer
         #  on that same stream and joins at the first bottleneck exchange)
-        kv_plain = [None if l is None else l.to(torch.int32).contiguous() for l in lens]
-        kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
+        if one_launch:
+            kv_plain, kv_fused = ops.stream_lengths([None if v is None else v.contiguous() for v in raw], self.bottlenecks_n,
+                                                    self.txt_idx)
+        else:
+            kv_plain = [None if l is None else l.to(torch.int32).contiguous() for l in lens]
+            kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
         missing = missing.to(dev).long()
         n_pre = min(max(self.fusion_idx, 0), self.n_layers)
         for li in range(n_pre):                                               # uni-modal layers (:734-737)
@@ -134,7 +142,14 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         # fusion layers: one explicit-buffer autograd node (ops.FusionStackFn); the streams carry the
         # bottleneck tokens in rows 0..3 of their own buffer: [bottleneck | CLS | tokens] (:745)
         fl = list(self.layer_stacks)[n_pre:]
-        all_fused = iter(type(fl[0][0]).fused_weights_of([layer for layers in fl for layer in layers], dt))
+        # first_stream_output_only (set by a model that reads nothing but stream 0's output, e.g. its CLS row): the LAST layer's
+        # other blocks feed nothing -- they are not run and their derived weights are not prepared (their outputs read as zeros)
+        first_only = (bool(getattr(self, "first_stream_output_only", False)) and not self.resbottle and fused_in
+                      and self.vsltonly != 1)
+        skip_last = first_only or (self.vsltonly == 1 and fused_in and not self.resbottle)     # (vsltonly: ops.FusionStackFn skips them too)
+        dead = lambda li, m: skip_last and li == len(fl) - 1 and m > 0
+        all_fused = iter(type(fl[0][0]).fused_weights_of(
+            [layer for li, layers in enumerate(fl) for m, layer in enumerate(layers) if not dead(li, m)], dt))
         # graph_segments (set by the trainer for staged hipGraph + DDP steps): cut the fusion layers into chained
         # ops.FusionStackFn nodes at these layer counts; segment_boundaries then holds the three stream buffers
         # between consecutive nodes (the tensors the staged backward is cut at).
@@ -149,18 +164,18 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             seg = fl[bounds[si]:bounds[si + 1]]
             final = si == len(bounds) - 2
             params, fused, seeds, p = [], [], [], 0.0
-            for layers in seg:
+            for lj, layers in enumerate(seg):
                 frow, srow = [], []
-                for layer in layers:
+                for m, layer in enumerate(layers):
                     params += layer.param_list()
-                    frow.append(next(all_fused))
+                    frow.append(None if dead(bounds[si] + lj, m) else next(all_fused))
                     p, sd = layer.dropout_args()
                     srow.append(sd)
                 fused.append(frow)
                 seeds.append(srow)
             sinks = [[layer.grad_sink() for layer in layers] for layers in seg] if torch.is_grad_enabled() else None
             cfg = dict(n_layers=len(seg), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
-                       prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True,
+                       prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True, first_only=first_only and final,
                        missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev))
             out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(zs[0], zs[1], zs[2], self.bottlenecks, *params, cfg)
             zs = (out_v, out_i, out_t)

@@ -663,6 +663,87 @@ extern "C" int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, v
     return MTMP_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Batched 2-D transposes in ONE launch: dst_i[cols_i][rows_i] = src_i[rows_i][cols_i]^T for up to TB_MAX matrices of 16- or
+// 32-bit elements.  The encoder layers' K-contiguous backward operands (W2^T, Wqkv^T, W1^T of every block, rebuilt after
+// each optimizer step) were three stack + strided-copy pairs of ~30 us on the critical path of every step; the pointers travel
+// by value in the kernel arguments, so a captured hipGraph needs no device-side table.
+constexpr int TB_MAX = 64;
+struct TransposeBatch { const void* src[TB_MAX]; void* dst[TB_MAX]; int rows[TB_MAX], cols[TB_MAX]; };
+template <typename E>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch t) {
+    __shared__ E tile[64][65];
+    const int b = blockIdx.y, R = t.rows[b], C = t.cols[b];
+    const int tiles_c = (C + 63) / 64, tiles = ((R + 63) / 64) * tiles_c;
+    const E* src = static_cast<const E*>(t.src[b]);
+    E* dst = static_cast<E*>(t.dst[b]);
+    for (int w = blockIdx.x; w < tiles; w += gridDim.x) {
+        const int r0 = (w / tiles_c) * 64, c0 = (w % tiles_c) * 64;
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + ty + 4 * i, c = c0 + tx;
+            if (r < R && c < C) tile[ty + 4 * i][tx] = src[(size_t)r * C + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + ty + 4 * i, r = r0 + tx;
+            if (r < R && c < C) dst[(size_t)c * R + r] = tile[tx][ty + 4 * i];
+        }
+        __syncthreads();
+    }
+}
+// elem_bytes: 2 or 4; src / dst / rows / cols: HOST arrays of n entries (read here, at launch time).
+extern "C" int mtmp_transpose_batch(int elem_bytes, const void* const* src, void* const* dst, const int* rows, const int* cols,
+                                    int n, void* stream) {
+    MTMP_CHECK_ARG(src && dst && rows && cols && n > 0 && (elem_bytes == 2 || elem_bytes == 4), "mtmp_transpose_batch: bad argument");
+    for (int base = 0; base < n; base += TB_MAX) {
+        TransposeBatch t;
+        const int m = min(TB_MAX, n - base);
+        int max_tiles = 1;
+        for (int i = 0; i < TB_MAX; ++i) {
+            const int k = base + (i < m ? i : 0);
+            MTMP_CHECK_ARG(src[k] && dst[k] && rows[k] > 0 && cols[k] > 0, "mtmp_transpose_batch: bad entry %d", k);
+            t.src[i] = src[k]; t.dst[i] = dst[k]; t.rows[i] = rows[k]; t.cols[i] = cols[k];
+            max_tiles = max(max_tiles, ((rows[k] + 63) / 64) * ((cols[k] + 63) / 64));
+        }
+        dim3 grid(min(max_tiles, 64), m);
+        if (elem_bytes == 2) hipLaunchKernelGGL(transpose_batch_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, t);
+        else                 hipLaunchKernelGGL(transpose_batch_kernel<unsigned>, grid, dim3(256), 0, (hipStream_t)stream, t);
+        MTMP_CHECK_LAUNCH("mtmp_transpose_batch");
+    }
+    return MTMP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Valid-key counts of the three streams in one launch (mbt_encoder.py:703-714): plain = length + 1 (the CLS token), the text
+// stream's 3 -> 0 (an absent report); fused = plain + n_bott (the bottleneck prefix).  out: int32 [2][3][B] (plain | fused);
+// a NULL length pointer leaves that stream's rows untouched (an unmasked stream has no count).  Replaces ~14 one-element-wide
+// torch kernels in front of the fusion stack.
+__global__ void stream_lengths_kernel(const long long* lv, const long long* li, const long long* lt, int* out, int B, int n_bott,
+                                      int txt_idx) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const long long* src[3] = {lv, li, lt};
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if (!src[m]) continue;
+        int v = (int)src[m][b] + 1;
+        if (m == txt_idx && v == 3) v = 0;
+        out[m * B + b] = v;
+        out[(3 + m) * B + b] = v + n_bott;
+    }
+}
+extern "C" int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const long long* len_t, int* out, int B,
+                                   int n_bott, int txt_idx, void* stream) {
+    MTMP_CHECK_ARG(out && B > 0 && (len_v || len_i || len_t), "mtmp_stream_lengths: bad argument (B=%d)", B);
+    hipLaunchKernelGGL(stream_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, len_v, len_i, len_t, out, B,
+                       n_bott, txt_idx);
+    MTMP_CHECK_LAUNCH("mtmp_stream_lengths");
+    return MTMP_OK;
+}
+
 // Diagnostic: one lane stores the 100 MHz wall clock into *slot.  Launched between the kernels of a step (also inside a
 // captured hipGraph, where HIP events cannot be timed) to get an un-profiled per-stream timeline (tools/dbg/timeline.py).
 __global__ void mark_kernel(unsigned long long* slot) { *slot = wall_clock64(); }

@@ -114,6 +114,39 @@ def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, wa
     return (y, xn, stats, None) if want_signs else (y, xn, stats)
 
 
+def stream_lengths(lens, n_bott, txt_idx):
+    """lens: three int64 [B] CUDA tensors or None (unmasked stream).  Returns (plain, fused): lists of int32 [B] | None with
+    plain = len + 1 (CLS; stream txt_idx: 3 -> 0) and fused = plain + n_bott -- one launch (mbt_encoder.py:703-714)."""
+    ref = next(l for l in lens if l is not None)
+    _gpu(*lens)
+    if any(l is not None and (l.dtype != torch.int64 or not l.is_contiguous() or l.numel() != ref.numel()) for l in lens):
+        raise ValueError("stream_lengths: contiguous int64 tensors of one length")
+    B = ref.numel()
+    out = torch.empty(2, 3, B, dtype=torch.int32, device=ref.device)
+    call("mtmp_stream_lengths", _p(lens[0]), _p(lens[1]), _p(lens[2]), _p(out), B, int(n_bott), int(txt_idx), _stream())
+    pick = lambda k: [None if lens[m] is None else out[k, m] for m in range(3)]
+    return pick(0), pick(1)
+
+
+def transpose_batch(mats):
+    """[m.t().contiguous() for m in mats] (2-D, contiguous, one 16- or 32-bit dtype) in ONE launch; the results are views of
+    one buffer."""
+    _gpu(*mats)
+    m0 = mats[0]
+    if any(m.dim() != 2 or not m.is_contiguous() or m.dtype != m0.dtype for m in mats) or m0.element_size() not in (2, 4):
+        raise ValueError("transpose_batch: contiguous 2-D tensors of one 16- or 32-bit dtype")
+    n = len(mats)
+    buf = torch.empty(sum(m.numel() for m in mats), dtype=m0.dtype, device=m0.device)
+    outs, off = [], 0
+    for m in mats:
+        outs.append(buf[off:off + m.numel()].view(m.shape[1], m.shape[0]))
+        off += m.numel()
+    PV, IV = ctypes.c_void_p * n, ctypes.c_int * n
+    call("mtmp_transpose_batch", m0.element_size(), PV(*[m.data_ptr() for m in mats]), PV(*[o.data_ptr() for o in outs]),
+         IV(*[m.shape[0] for m in mats]), IV(*[m.shape[1] for m in mats]), n, _stream())
+    return outs
+
+
 def gemm_nt_signs(a2d, w, signs, gate_scale=1.0):
     """y[M,N] = signs ? (a[M,256] w[N,256]^T) * gate_scale : 0 (bf16; signs from ln_gemm(..., want_signs=True))."""
     _gpu(a2d, w, signs)
@@ -721,6 +754,8 @@ class FusionStackFn(torch.autograd.Function):
         gradient all-reduce of the later layers overlaps the backward of the earlier ones (ddp.GradReducer, staged mode).
       n_streams (default 3): 2 = the two-stream encoder (BimodalTransformerEncoder_MBT, mbt_encoder.py:519-634): xt is
         None, layer_params hold two blocks per layer, and ``missing`` carries table rows 1 (mean of both) / 3 (stream 0).
+      first_only: the caller reads stream 0's output only (mbt_encoder.py ``first_stream_output_only``): the last layer
+        runs stream 0 alone, exactly like vsltonly == 1 does; the other two outputs are zeros.
       bott_rows_unused: the caller never reads rows 0..3 of the outputs (mbt_encoder.py slices them off), so with
         vsltonly == 0 and no gradient for the image / text outputs the last layer's image / text blocks get no
         backward at all (in the reference their gradient is None, not zero).
@@ -756,7 +791,7 @@ class FusionStackFn(torch.autograd.Function):
         saved, active = [], []
         prev_bott = bott.expand(B, -1, -1).float().contiguous() if cfg["resbottle"] else None
         for li in range(L):
-            last = final and cfg["vsltonly"] == 1 and li == L - 1
+            last = final and (cfg["vsltonly"] == 1 or cfg.get("first_only")) and li == L - 1
             ms = [0] if last else list(range(n_s))
             outs = [None, None, None]
             row = [None, None, None]
@@ -833,7 +868,8 @@ class FusionStackFn(torch.autograd.Function):
         d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
         for li in range(n_run - 1, -1, -1):
             ms = active[li]
-            if not ((final and cfg["vsltonly"] == 1 and li == L - 1) or (skip_last_exchange and li == n_run - 1)):
+            if not ((final and (cfg["vsltonly"] == 1 or cfg.get("first_only")) and li == L - 1)
+                    or (skip_last_exchange and li == n_run - 1)):
                 # this layer's outputs went through an exchange before feeding layer li+1: rows 0..3 of the three
                 # gradient buffers are summed and redistributed by the exchange weights, in place (one kernel)
                 d_out_prev = torch.empty(B, NB, D_MODEL, dtype=torch.float32, device=dev) if cfg["resbottle"] else None

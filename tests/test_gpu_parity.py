@@ -144,6 +144,15 @@ def test_ln_gemm_and_gemm_nt(ops, dt):
     check(f"gemm_nt[{str(dt)[6:]}].y", y.float(), yr, TOL[dt] if dt == torch.float32 else 2e-2)
 
 
+def test_transpose_batch(ops):
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for dt in (torch.bfloat16, torch.float32):
+        mats = [torch.randn(r, c, generator=g, device=DEV).to(dt) for r, c in
+                [(768, 256), (256, 1024), (1024, 256), (70, 33), (1, 5), (65, 64)] * 12]        # 72 matrices: two launches
+        outs = ops.transpose_batch(mats)
+        assert all(torch.equal(o, m.t()) and o.is_contiguous() for o, m in zip(outs, mats))
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M", [4990, 20001, 33000])
 def test_row_panel_kernels_multi_panel(ops, dt, M):
