@@ -241,6 +241,12 @@ int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, 
                                  const long long* missing, int resbottle, const float* d_prev_in, float* d_prev_out,
                                  void* stream);
 
+/* y[M,N] = act(LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias) with nn.LayerNorm semantics: norm1 -> qkv and norm2 -> mlp.0
+ * (+ GELU) of the 384-wide Swin blocks (swin_transformer.py:428-449, :115-225) in one launch each.  bf16 only (dtype 1),
+ * C = 384, N % 64 == 0; act: 0 none, 2 exact GELU; W bf16, ln_w / ln_b / bias fp32 (bias may be NULL). */
+int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias, void* y,
+                       long long M, int C, int N, float eps, int act, void* stream);
+
 /* Batched 2-D transposes in one launch: dst[i] [cols[i]][rows[i]] = src[i] [rows[i]][cols[i]]^T, elements of elem_bytes = 2 | 4.
  * src / dst / rows / cols are HOST arrays of n entries (read at launch time; the pointers travel in the kernel arguments).
  * The K-contiguous backward operands (W2^T, Wqkv^T, W1^T: autograd of attention.py:60-62 / module.py:74-78) of all encoder

@@ -430,11 +430,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 // staging round trip) is issued between the MFMAs of the other: [MFMA g1(j) | epilogue g0(j)] -> s_waitcnt vmcnt(4) (DMA(j+1)
 // is older than exactly the four row-piece stores of the last two epilogues) -> barrier -> DMA(j+2) -> [MFMA g0(j+1) |
 // epilogue g1(j)].
-struct PanelDma {
+// K = row length (contraction index): 256 (the fusion layers' d_model) or 384 (Swin stage 3, one workgroup per CU: 96 KiB of panels).
+template <int K = 256> struct PanelDmaK {
     static constexpr int NP = 64, G = 2, FS = 40, LPT = 4, PASSES = 2, MAXP = 16;   // MAXP panels (1024 features) per workgroup
-    static constexpr unsigned panel_bytes = NP * 512, stage_off = 2 * panel_bytes, bias_off = stage_off + 4 * 32 * FS * 2;
+    static constexpr int KC = K / 16, ROWB = 2 * K;                // 16-wide k-steps; bytes per weight row
+    static constexpr int ND = NP * ROWB / 1024 / 4;               // 1 KiB DMA pieces per wave and panel
+    static constexpr unsigned panel_bytes = NP * ROWB, group_bytes = 32 * ROWB, stage_off = 2 * panel_bytes,
+                              bias_off = stage_off + 4 * 32 * FS * 2;
     static constexpr size_t lds_bytes = bias_off + MAXP * NP * 4;
+    static_assert(K % 128 == 0 && (NP * ROWB) % 4096 == 0, "row-panel kernel: K must be a multiple of 128");
 };
+using PanelDma = PanelDmaK<256>;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // (m0 is "reserved"; naming it as clobbered is exactly the point)
 MTMP_DEV void dma16(unsigned voff, const void* sbase, unsigned lds_off) {
@@ -451,10 +457,13 @@ template <int N> MTMP_DEV void gwait1(unsigned& a) { asm volatile("s_waitcnt vmc
 // dH = dY W2 gated by the saved hidden activation (y = h > 0 ? y * gate_scale : 0, autograd of module.py:77-79) reads those
 // bits instead of h itself -- the same kernel geometry, so a lane needs exactly the 16 bits its forward twin wrote: 4 MB of
 // gate traffic per launch at config 2 instead of 132 MB.  No LayerNorm in GATE mode (p.gamma == nullptr).
-template <bool RELU, bool DROP, bool GATE, bool SIGNS>
-__global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
+// K / TORCH_LN / GELU: the same kernel as the frozen image encoder's LayerNorm + Linear (+ exact GELU) for the 384-wide stage
+// (swin_transformer.py:428-449: nn.LayerNorm -- biased variance, eps inside the root -- in front of qkv / mlp.0).
+template <bool RELU, bool DROP, bool GATE, bool SIGNS, int K = 256, bool TORCH_LN = false, bool GELU = false>
+__global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     using T = bf16;
-    using P = PanelDma;
+    using P = PanelDmaK<K>;
+    constexpr int KC = P::KC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, half = lane >> 5;
@@ -467,15 +476,19 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     if (j0 >= j1) return;
     const int m_wave = blockIdx.x * BM + wave * 32;
     const int row = min(m_wave + r, p.M - 1);
-    // DMA slot of this lane: instruction i of wave w fills panel rows 16w + 2i + (lane >> 5); LDS position lane & 31 of that row
-    // takes global chunk (lane & 31) ^ (row & 15)
-    unsigned dsrc[8];
+    // DMA slot of this lane: piece i of wave w fills LDS bytes [1024 (ND w + i), +1024) of the panel image, i.e. 16-byte slot
+    // q = 64 (ND w + i) + lane = position q % (K/8) of panel row q / (K/8), which takes global chunk position ^ (row & 15)
+    // (K = 256: rows 16w + 2i + (lane >> 5), position lane & 31)
+    unsigned dsrc[P::ND];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dsrc[i] = (unsigned)(16 * wave + 2 * i + half) * 512u + 16u * (unsigned)(r ^ (2 * i + half));
+    for (int i = 0; i < P::ND; ++i) {
+        const unsigned q = 64u * (unsigned)(P::ND * wave + i) + (unsigned)lane, prow = q / (K / 8), pos = q % (K / 8);
+        dsrc[i] = prow * (unsigned)P::ROWB + 16u * (pos ^ (prow & 15u));
+    }
     auto panel_dma = [&](int j, int buf) {
-        const char* src = reinterpret_cast<const char*>(p.w + (size_t)j * P::NP * 256);
+        const char* src = reinterpret_cast<const char*>(p.w + (size_t)j * P::NP * K);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dma16(dsrc[i], src, lds0 + buf * P::panel_bytes + (unsigned)(8 * wave + i) * 1024u);
+        for (int i = 0; i < P::ND; ++i) dma16(dsrc[i], src, lds0 + buf * P::panel_bytes + (unsigned)(P::ND * wave + i) * 1024u);
     };
 #ifdef MTMP_STAMP
     unsigned long long ts0, ts1, ts2;
@@ -483,40 +496,42 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
 #endif
     panel_dma(j0, 0);
     if (p.gamma) {
-        sG[tid] = p.gamma[tid];
-        sG[256 + tid] = p.beta[tid];
+        for (int i = tid; i < K; i += 256) {
+            sG[i] = p.gamma[i];
+            sG[K + i] = p.beta[i];
+        }
     }
     for (int i = tid; i < (j1 - j0) * P::NP; i += 256) sB[i] = p.bias ? p.bias[j0 * P::NP + i] : 0.f;
     // ---- LayerNorm prologue, in registers: lane (r, half) holds k = 16c + 8*half + j of row r
-    Frag<T> af[16];
+    Frag<T> af[KC];
     const T* arow = p.a + (size_t)row * p.lda + 8 * half;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) af[c] = frag_load<T>(arow + 16 * c);
+    for (int c = 0; c < KC; ++c) af[c] = frag_load<T>(arow + 16 * c);
     if constexpr (!GATE) {
         float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
+        for (int c = 0; c < KC; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
         s1 += __shfl_xor(s1, 32, 64);
-        const float mean = s1 * (1.0f / 256.0f);
+        const float mean = s1 * (1.0f / K);
         float s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
+        for (int c = 0; c < KC; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
         s2 += __shfl_xor(s2, 32, 64);
-        const float sigma = sqrtf(s2 * (1.0f / 255.0f));         // torch.std: Bessel-corrected
-        const float rs = 1.0f / (sigma + p.eps);
+        // the fusion layers' LayerNorm: torch.std (Bessel-corrected), eps added to it; nn.LayerNorm: biased variance, eps inside
+        const float rs = TORCH_LN ? rsqrtf(s2 * (1.0f / K) + p.eps) : 1.0f / (sqrtf(s2 * (1.0f / (K - 1))) + p.eps);
         __syncthreads();                                         // sG ready
         if (p.gamma) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
+            for (int c = 0; c < KC; ++c) {
                 const int k = 16 * c + 8 * half;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
-                if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
+                    af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[K + k + j]));
+                if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * K + k, af[c]);
             }
             if (p.stats && half == 0 && blockIdx.y == 0) {
                 p.stats[2 * (size_t)row] = mean;
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     // immediate offsets on eight per-lane addresses
     const char* rd[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) rd[c] = smem_raw + r * 512 + 16 * ((2 * c + half) ^ (r & 15));
+    for (int c = 0; c < 8; ++c) rd[c] = smem_raw + r * P::ROWB + 16 * ((2 * c + half) ^ (r & 15));
     panel_dma(min(j0 + 1, j1 - 1), 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // panels j0, j0 + 1 landed (this wave's share)
     __syncthreads();                                             // ... everyone's; sB written; sG dead (sS may be written)
@@ -579,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
                 if (RELU) v[i] = relu1(v[i]);
                 if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
             }
+            if (GELU) v[i] = gelu<T>(v[i]);
             if (GATE)          // bit 15 - (4 i4 + i) of the lane's 16: all ones or zero, and-ed onto the scaled value
                 v[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[i] * p.gate_scale) &
                                                      __builtin_amdgcn_sbfe((int)gate_bits, 15 - (4 * i4 + i), 1));
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
                      auto gw_tag) {
         constexpr bool EPI = decltype(epi_tag)::value, PEND = decltype(pend_tag)::value;
         constexpr int GW = decltype(gw_tag)::value;
-        const size_t cur = (size_t)(((jm - j0) & 1) * P::panel_bytes + gm * 16384);
+        const size_t cur = (size_t)(((jm - j0) & 1) * P::panel_bytes + gm * P::group_bytes);
         const int n0 = je * P::NP;
         if (GATE) gload_u16(gnext, signs_ptr(jm, gm));
 #pragma unroll
@@ -604,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (jm - j0) * P::NP + 32 * gm + 8 * i4 + 4 * half);
             acc[gm][4 * i4] = v[0]; acc[gm][4 * i4 + 1] = v[1]; acc[gm][4 * i4 + 2] = v[2]; acc[gm][4 * i4 + 3] = v[3];
         }
-        Frag<T> b[16];
+        Frag<T> b[KC];
 #pragma unroll
         for (int c = 0; c < 8; ++c) b[c].v = *reinterpret_cast<const bf16x8*>(rd[c] + cur);
         u32x4_t dr[P::PASSES];
@@ -616,16 +632,16 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
         if (GATE && EPI) gwait1<GW>(gcur);
         unsigned fld[4], sign_bits = 0;
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
+        for (int s8 = 0; s8 < KC / 2; ++s8) {                     // (K = 256: eight slices, all of them carry epilogue work)
             __builtin_amdgcn_sched_barrier(0);
-            if (s8 < 4) {
-                b[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd[2 * s8] + cur + 256);
-                b[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd[2 * s8 + 1] + cur + 256);
+            if (2 * s8 + 8 < KC) {
+                b[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd[(2 * s8) & 7] + cur + ((8 + 2 * s8) >> 3) * 256);
+                b[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd[(2 * s8 + 1) & 7] + cur + ((9 + 2 * s8) >> 3) * 256);
             }
             mma<T>(acc[gm], b[2 * s8], af[2 * s8]);
             mma<T>(acc[gm], b[2 * s8 + 1], af[2 * s8 + 1]);
             if (PEND && s8 == 0) drain_store(dr, jp, gp);
-            if (EPI) {
+            if (EPI && s8 < 8) {
                 const int i4 = s8 >> 1;
                 if ((s8 & 1) == 0) {
                     const int col = n0 + 32 * ge + 8 * i4 + 4 * half;
@@ -633,8 +649,8 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
                 } else {
                     piece(ge, i4, fld, gcur, sign_bits);
                 }
-                constexpr int NV = DROP ? 9 : 3;
-                if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                constexpr int NV = DROP || GELU ? 9 : 3;
+                if (2 * s8 + 8 < KC) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -676,6 +692,9 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     // the top of the B phase before) are older than S + 8 + G, a B phase's than S + G.
     constexpr int NST = P::PASSES + NS, WDMA = 2 * (NG + NST), WA = NST + 8 + NG, WB = NST + NG;
     unsigned g0bits = 0, g1bits = 0;                             // gate bits of the g = 0 / g = 1 group in flight
+#ifdef MTMP_STAMP
+    TSTAMP(ts1)
+#endif
     phase(j0, 0, 0, 0, No{}, 0, 0, No{}, g0bits, g1bits, template_int<0>{});
     if (j0 < j1 - 1) {
         phase(j0, 1, j0, 0, Yes{}, 0, 0, No{}, g1bits, g0bits, template_int<NG>{});
@@ -1124,6 +1143,29 @@ int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, int gate, hipStream_t st) {
     MTMP_CHECK_LAUNCH("mtmp_ln_gemm");
     return MTMP_OK;
 }
+// nn.LayerNorm + Linear (+ exact GELU) over 384-wide rows: the row-panel kernel with K = 384, one workgroup per CU
+int launch_ln_linear_384(GemmArgs<bf16> a, int gelu, hipStream_t st) {
+    using P = PanelDmaK<384>;
+    const void* f = gelu ? (const void*)ln_gemm_dma_kernel<false, false, false, false, 384, true, true>
+                         : (const void*)ln_gemm_dma_kernel<false, false, false, false, 384, true, false>;
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
+        mtmp_set_error("mtmp_ln_linear_act: cannot raise dynamic LDS to %zu", P::lds_bytes);
+        return MTMP_ERR_LAUNCH;
+    }
+    const int mtiles = (a.M + BM - 1) / BM, npanels = a.N / P::NP;
+    int nsplit = 256 / mtiles;                               // ~ one workgroup per CU
+#ifdef MTMP_LN384_NSPLIT
+    nsplit = MTMP_LN384_NSPLIT;                              // (diagnostic builds)
+#endif
+    nsplit = nsplit < 1 ? 1 : (nsplit > npanels ? npanels : nsplit);
+    const int need = (npanels + P::MAXP - 1) / P::MAXP;
+    if (nsplit < need) nsplit = need;
+    dim3 grid(mtiles, nsplit);
+    if (gelu) hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, 384, true, true>), grid, dim3(256), P::lds_bytes, st, a);
+    else      hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, 384, true, false>), grid, dim3(256), P::lds_bytes, st, a);
+    MTMP_CHECK_LAUNCH("mtmp_ln_linear_act");
+    return MTMP_OK;
+}
 template <typename T>
 int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
     const size_t sm = Panel<T>::lds_bytes;
@@ -1399,6 +1441,19 @@ extern "C" int mtmp_gemm_nt_signs(int dtype, const void* a, const void* w, void*
     GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, nullptr, nullptr, (bf16*)y, nullptr, nullptr, nullptr, nullptr, M, N, 256, lda, ldy,
                      0, 0.f, 0.f, 0u, nullptr, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs};
     return launch_ln_gemm_dma(g, 0, 1, (hipStream_t)stream);
+}
+
+// y[M,N] = act(LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias), nn.LayerNorm semantics (biased variance, eps inside the
+// root): norm1 -> qkv and norm2 -> mlp.0 (+ GELU) of the 384-wide Swin blocks (swin_transformer.py:428-449) in one launch
+// each.  bf16 (dtype 1), C = 384, N % 64 == 0; act: 0 none, 2 exact GELU; bias may be NULL.
+extern "C" int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias,
+                                  void* y, long long M, int C, int N, float eps, int act, void* stream) {
+    MTMP_CHECK_ARG(x && ln_w && ln_b && w && y, "mtmp_ln_linear_act: null pointer");
+    MTMP_CHECK_ARG(dtype == 1 && C == 384 && M > 0 && M < (1ll << 31) && N > 0 && N % 64 == 0 && (act == 0 || act == 2),
+                   "mtmp_ln_linear_act: bf16, C = 384, N %% 64 == 0, act 0 | 2 only (dtype=%d C=%d N=%d act=%d)", dtype, C, N, act);
+    GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, ln_w, ln_b, nullptr, nullptr, (int)M, N, C, C, N, 0, eps,
+                     0.f, 0u, nullptr, nullptr, 1.f, 0, nullptr, 1};
+    return launch_ln_linear_384(a, act == 2, (hipStream_t)stream);
 }
 
 // Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32

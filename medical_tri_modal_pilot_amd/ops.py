@@ -210,16 +210,28 @@ def swin_mlp(x2d, ln_w, ln_b, eps, w1, b1, w2, b2, row_scale=None, rows_per_scal
 
 # measured on 64 images: C = 96: 53 us against 16 + 69 us for mtmp_layernorm_rows + mtmp_gemm_nt; C = 192: 68 us against
 # 11 + 39 us (every wave re-reads the 221 KB weight from L2) -- so only the first stage takes the fused launch
+# Widths at which the Swin blocks take the fused norm1 -> qkv launch / the fused norm2 -> mlp.0 -> GELU launch.  384 (stage 3,
+# mtmp_ln_linear_act) is built and tested but NOT routed: per launch it beats layernorm_rows + gemm_nt (20 vs 27 us, 24 vs 32 us
+# at half batch), per encoder forward it does not (1773-1803 vs 1754-1810 us over the four split / un-split combinations,
+# tools/dbg/swin_tail_ab.py): 9 us of its 20 are the LayerNorm prologue of a workgroup that holds a whole CU.
 SWIN_LN_LINEAR_WIDTHS = (96,)
+SWIN_LN_FC1_WIDTHS = ()
 
 
-def swin_ln_linear(x2d, ln_w, ln_b, eps, w, bias):
-    """x2d [M,C] bf16 -> LayerNorm(x2d) w^T + bias [M,N] in one launch (mtmp_swin_ln_linear; C = 96 or 192)."""
+def swin_ln_linear(x2d, ln_w, ln_b, eps, w, bias, act=None):
+    """x2d [M,C] bf16 -> act(LayerNorm(x2d) w^T + bias) [M,N] in one launch: mtmp_swin_ln_linear (C = 96 or 192, no activation)
+    or the row-panel kernel mtmp_ln_linear_act (C = 384; act None | "gelu")."""
     _gpu(x2d)
     x2d = _c(x2d)
     M, C = x2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
+    if C == 384:
+        call("mtmp_ln_linear_act", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), ACT[act],
+             _stream())
+        return y
+    if act is not None:
+        raise ValueError("swin_ln_linear: an activation needs C = 384")
     call("mtmp_swin_ln_linear", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), _stream())
     return y
 

@@ -642,6 +642,29 @@ def test_swin_ln_linear_fused_vs_chain_and_torch(ops, C, rows):
         check(t + ".vs_torch_fp32", y.float(), ref, 2e-2)
 
 
+@pytest.mark.parametrize("rows", [6272, 12544, 777, 40000])
+def test_ln_linear_act_384_vs_chain_and_torch(ops, rows):
+    """mtmp_ln_linear_act (nn.LayerNorm + Linear (+ GELU) of the 384-wide Swin blocks on the row-panel kernel) against
+    mtmp_layernorm_rows + mtmp_gemm_nt and fp32 torch: the encoder's half / full batch row counts, a ragged count and one that
+    runs every panel in one workgroup."""
+    C = 384
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    bf = torch.bfloat16
+    x = (torch.randn(rows, C, generator=g, device=DEV) * 1.5 + 0.2).to(bf)
+    lw, lb = 1 + 0.1 * torch.randn(C, generator=g, device=DEV), 0.1 * torch.randn(C, generator=g, device=DEV)
+    for N, act in ((3 * C, None), (4 * C, "gelu")):
+        w, b = (torch.randn(N, C, generator=g, device=DEV) * C ** -0.5).to(bf), 0.1 * torch.randn(N, generator=g, device=DEV)
+        for bias in (b, None):
+            y = ops.swin_ln_linear(x, lw, lb, 1e-5, w, bias, act=act)
+            chain = ops.gemm_nt(ops.layernorm_rows(x, lw, lb, 1e-5), w, bias, act=act)
+            ref = torch.nn.functional.layer_norm(x.float(), (C,), lw, lb, 1e-5) @ w.float().t() + (0 if bias is None else bias)
+            if act == "gelu":
+                ref = torch.nn.functional.gelu(ref)
+            t = f"ln_linear_act[rows={rows},N={N},bias={bias is not None}]"
+            check(t + ".vs_chain", y.float(), chain.float(), 1e-2)
+            check(t + ".vs_torch_fp32", y.float(), ref, 2e-2)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_swin_train_mode_stochastic_depth_vs_oracle(ops, dtype, monkeypatch):
     """model.train() re-activates the frozen encoder's row-mode StochasticDepth (2_train.py:128 overrides the .eval() of

@@ -81,6 +81,16 @@ def main():
                                   seed=3, want_signs=True)
         rec("gemm_nt.dH_signs[M,1024,256]", timeit(lambda: ops.gemm_nt_signs(dy, w2t, sg, 1.0 / 0.9), a.rounds), 2.0 * M * 1024 * 256,
             2.0 * M * (256 + 1024) + M * 128)
+    if want("swin3"):               # stage-3 projections of the image encoder at half batch (32 images x 196 tokens, C = 384)
+        C, rows = 384, 6272
+        xs = R(rows, C)
+        lw, lb = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        for n, act in ((3 * C, None), (4 * C, "gelu")):
+            w, b = R(n, C) * 0.05, torch.zeros(n, device=DEV)
+            rec(f"swin3.ln_linear[{rows},{n},{C}].{act}", timeit(lambda: ops.swin_ln_linear(xs, lw, lb, 1e-5, w, b, act=act), a.rounds),
+                2.0 * rows * n * C)
+            rec(f"swin3.chain[{rows},{n},{C}].{act}", timeit(lambda: ops.gemm_nt(ops.layernorm_rows(xs, lw, lb, 1e-5), w, b, act=act),
+                                                          a.rounds), 2.0 * rows * n * C)
     # ---- LN-fused GEMMs
     if want("ln_gemm"):
         x = R(M, 256)

@@ -8,7 +8,7 @@ import bench
 from medical_tri_modal_pilot_amd.builder.models import get_model
 
 dev = torch.device("cuda", 0)
-args = bench.make_args("bf16", 0.1)
+args = bench.make_args("full", "bf16", 0.1, 1, 0, False)
 torch.manual_seed(0)
 enc = get_model(args)(args).to(dev).img_encoder
 img = torch.randn(64, 1, 224, 224, device=dev)

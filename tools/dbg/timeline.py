@@ -17,10 +17,10 @@ _run, _step = G.GraphedTrainStep.run, O.FusedAdamW.step
 count = {"k": 0}
 
 
-def run(self, inputs, fn, params=None):
+def run(self, inputs, fn, params=None, **kw):
     ops.mark("step.s")
     ops.mark("step.s%d" % (count["k"] % 2))          # per-parity copies: the idle time between two steps
-    out = _run(self, inputs, fn, params)
+    out = _run(self, inputs, fn, params, **kw)
     ops.mark("graph.e")
     return out
 
@@ -49,6 +49,6 @@ def report():
         print("%9.1f us  %s" % (v - t0, k), file=sys.stderr)
 
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "20", "--warmup", "8", "--probe-steps", "0"] + sys.argv[1:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "20", "--warmup", "8", "--probe-launches", "0"] + sys.argv[1:]
 import runpy
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
