@@ -247,6 +247,11 @@ int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, 
 int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias, void* y,
                        long long M, int C, int N, float eps, int act, void* stream);
 
+/* Up to 16 device-to-device copies in one launch: dst[i] <- src[i] (bytes[i] bytes, both 16-byte aligned); round16[i] != 0: the
+ * buffer holds fp32 values and is written as float(half(x)) -- the fp16 round trip the reference applies to its event / time
+ * inputs (trainer.py:26-27, 2_train.py:164).  All arrays are HOST arrays of n entries, read at launch time. */
+int mtmp_copy_batch(const void* const* src, void* const* dst, const long long* bytes, const int* round16, int n, void* stream);
+
 /* Batched 2-D transposes in one launch: dst[i] [cols[i]][rows[i]] = src[i] [rows[i]][cols[i]]^T, elements of elem_bytes = 2 | 4.
  * src / dst / rows / cols are HOST arrays of n entries (read at launch time; the pointers travel in the kernel arguments).
  * The K-contiguous backward operands (W2^T, Wqkv^T, W1^T: autograd of attention.py:60-62 / module.py:74-78) of all encoder

@@ -49,6 +49,24 @@ def missing_to_num(missing: torch.Tensor, fullmodal_definition: str = "txt1_img1
     return inverse[tmpl.shape[0]:].type(torch.LongTensor), missing
 
 
+_MISSING_MEMO = {}
+
+
+def _missing_ids(args, missing, device):
+    """missing flags -> pattern ids on `device` (reference trainer.py:53-77, 99-104), bounds-checked."""
+    missing_num, _ = missing_to_num(missing, args.fullmodal_definition)
+    if args.input_types == "vslt_txt":                                        # trainer.py:99-104
+        missing_num[missing_num == 2] = 0
+        missing_num[missing_num == 3] = 1
+    elif args.input_types == "vslt_img":
+        missing_num[missing_num == 1] = 0
+        missing_num[missing_num == 3] = 1
+    if missing_num.numel() and (int(missing_num.max()) > 3 or int(missing_num.min()) < 0):
+        # the reference gathers all_bottleneck_stack[missing, idx_order] from FOUR candidates (mbt_encoder.py:768-776)
+        raise IndexError(f"modality pattern id {int(missing_num.max())} is out of bounds for the 4 bottleneck candidates")
+    return missing_num.to(device, non_blocking=True)
+
+
 def _use_graph(args, flow_type, device, optimizer, scaler) -> bool:
     return (flow_type == "train" and int(getattr(args, "hip_graph", 0)) == 1 and torch.device(device).type == "cuda"
             and hasattr(optimizer, "flat") and scaler is None)
@@ -126,8 +144,20 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
                     seq_lengths=None, x_img=None, x_txt=None, txt_lengths=None, imgtxt_time=None, missing=None,
                     reports_tokens=None, reports_lengths=None, criterion_aux=None):
     img_time, txt_time = imgtxt_time
-    img_time = img_time.half().float().to(device, non_blocking=True)          # fp16 rounding, trainer.py:26-27
-    txt_time = txt_time.half().float().to(device, non_blocking=True)
+    # fp16 rounding of the event / time inputs (trainer.py:26-27, 2_train.py:164).  A device-resident fp32 tensor of a step
+    # that will be replayed from a hipGraph is rounded by the copy into the graph's static buffers instead
+    # (GraphedTrainStep.run round_fp16): two eager launches per tensor less in front of every step.
+    deferred = set()
+    defer_ok = flow_type == "train" and _use_graph(args, flow_type, device, optimizer, scaler) and output_lengths is None
+
+    def fp16_round(t, key):
+        if (defer_ok and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+                and torch.device(device).index in (None, t.device.index)):
+            deferred.add(key)
+            return t
+        return t.half().float().to(device, non_blocking=True)
+    img_time = fp16_round(img_time, "img_time")
+    txt_time = fp16_round(txt_time, "txt_time")
     cu_seqlens = None
     if isinstance(train_x, PackedTieBatch):
         # Ragged batch (builder/data): the events travel packed, there is nothing to trim; the padded
@@ -145,22 +175,20 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         max_len = int(torch.max(input_lengths))                               # ragged trim, trainer.py:41-42
         if _use_graph(args, flow_type, device, optimizer, scaler):
             max_len = min(train_x.shape[1], -(-max_len // GRAPH_LEN_BUCKET) * GRAPH_LEN_BUCKET)
-        data = train_x[:, :max_len, :].half().float().to(device, non_blocking=True)   # 2_train.py:164
+        data = fp16_round(train_x[:, :max_len, :], "data")                    # 2_train.py:164
     if "rmse" in args.auxiliary_loss_type:
         final_target = train_y[0].float().to(device, non_blocking=True)
     else:
         final_target = train_y.float().to(device, non_blocking=True)
-    missing_num, _ = missing_to_num(missing, args.fullmodal_definition)
-    if args.input_types == "vslt_txt":                                        # trainer.py:99-104
-        missing_num[missing_num == 2] = 0
-        missing_num[missing_num == 3] = 1
-    elif args.input_types == "vslt_img":
-        missing_num[missing_num == 1] = 0
-        missing_num[missing_num == 3] = 1
-    if missing_num.numel() and (int(missing_num.max()) > 3 or int(missing_num.min()) < 0):
-        # the reference gathers all_bottleneck_stack[missing, idx_order] from FOUR candidates (mbt_encoder.py:768-776)
-        raise IndexError(f"modality pattern id {int(missing_num.max())} is out of bounds for the 4 bottleneck candidates")
-    missing_num = missing_num.to(device, non_blocking=True)
+    # A device-resident `missing` costs a D2H copy + host sync + H2D copy per step here (the pattern ids are host logic, as in
+    # the reference).  The very same tensor (storage, version counter) handed in again maps to the very same ids: keep the last.
+    mkey = ((missing.data_ptr(), missing._version, tuple(missing.shape), missing.dtype, str(missing.device), str(device),
+             args.fullmodal_definition, args.input_types) if missing.is_cuda else None)
+    if mkey is not None and _MISSING_MEMO.get("key") == mkey:
+        missing_num = _MISSING_MEMO["value"]
+    else:
+        missing_num = _missing_ids(args, missing, device)
+        _MISSING_MEMO.update(key=mkey, value=missing_num if mkey is not None else None)
     static_x = static_x.permute(1, 0)
     age = static_x[1].float().to(device, non_blocking=True)
     gender = static_x[0].float().to(device, non_blocking=True)
@@ -213,10 +241,10 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
                 step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
                 step_loss.backward()
                 return step_loss.detach()
-            loss = gs.run(inputs, fwd_bwd, optimizer.flat.params, reducer=red)
+            loss = gs.run(inputs, fwd_bwd, optimizer.flat.params, reducer=red, round_fp16=deferred)
         else:
             loss = gs.run(inputs, _staged_step(model, enc, optimizer, criterion, run_model, bounds),
-                          optimizer.flat.params, reducer=red)
+                          optimizer.flat.params, reducer=red, round_fp16=deferred)
         optimizer.step()
         scheduler.step(iteration)
         logger.log_lr(scheduler.get_lr()[0], iteration)

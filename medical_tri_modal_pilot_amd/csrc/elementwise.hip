@@ -5,6 +5,7 @@
 // parameter gradients are accumulated in registers over a grid-stride loop and combined through
 // a [blocks][cols] partial slab + a second pass (bitwise reproducible, no float atomics in HBM).
 #include "common.cuh"
+#include <hip/hip_fp16.h>
 
 namespace {
 
@@ -713,6 +714,62 @@ extern "C" int mtmp_transpose_batch(int elem_bytes, const void* const* src, void
         else                 hipLaunchKernelGGL(transpose_batch_kernel<unsigned>, grid, dim3(256), 0, (hipStream_t)stream, t);
         MTMP_CHECK_LAUNCH("mtmp_transpose_batch");
     }
+    return MTMP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Up to CB_MAX device-to-device copies in ONE launch, optionally rounding fp32 data through fp16 on the way
+// (x.half().float(): the reference stores its event / time inputs as fp16, trainer.py:26-27, 2_train.py:164).  The replayed
+// training step copies its eleven input tensors into the graph's static buffers with this: a dozen ~10 us eager launches on the
+// host's critical path between two steps become one.  Pointers travel by value in the kernel arguments.
+constexpr int CB_MAX = 16;
+struct CopyBatch { const void* src[CB_MAX]; void* dst[CB_MAX]; long long bytes[CB_MAX]; int round16[CB_MAX]; };
+__global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatch t) {
+    const int b = blockIdx.y;
+    const long long n16 = t.bytes[b] >> 4;
+    const uint4* s = static_cast<const uint4*>(t.src[b]);
+    uint4* d = static_cast<uint4*>(t.dst[b]);
+    const bool r16 = t.round16[b] != 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+        uint4 v = s[i];
+        if (r16) {
+            float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = __half2float(__float2half_rn(f[k]));
+            v = uint4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+        }
+        d[i] = v;
+    }
+    if (blockIdx.x == 0) {                                       // tail (< 16 bytes; whole floats when rounding)
+        const long long done = n16 << 4, rest = t.bytes[b] - done;
+        const char* sc = static_cast<const char*>(t.src[b]) + done;
+        char* dc = static_cast<char*>(t.dst[b]) + done;
+        if (r16) {
+            if ((long long)threadIdx.x * 4 < rest)
+                reinterpret_cast<float*>(dc)[threadIdx.x] = __half2float(__float2half_rn(reinterpret_cast<const float*>(sc)[threadIdx.x]));
+        } else if (threadIdx.x < rest) {
+            dc[threadIdx.x] = sc[threadIdx.x];
+        }
+    }
+}
+// src / dst / bytes / round16: HOST arrays of n <= 16 entries; src and dst 16-byte aligned; round16[i] != 0: buffer i holds
+// fp32 values (bytes % 4 == 0), written as float(half(x)).
+extern "C" int mtmp_copy_batch(const void* const* src, void* const* dst, const long long* bytes, const int* round16, int n,
+                               void* stream) {
+    MTMP_CHECK_ARG(src && dst && bytes && round16 && n > 0 && n <= CB_MAX, "mtmp_copy_batch: bad argument (n=%d)", n);
+    CopyBatch t;
+    long long most = 0;
+    for (int i = 0; i < CB_MAX; ++i) {
+        const int k = i < n ? i : 0;
+        MTMP_CHECK_ARG(src[k] && dst[k] && bytes[k] > 0 && ((uintptr_t)src[k] & 15) == 0 && ((uintptr_t)dst[k] & 15) == 0 &&
+                           (!round16[k] || bytes[k] % 4 == 0), "mtmp_copy_batch: bad entry %d", k);
+        t.src[i] = src[k]; t.dst[i] = dst[k]; t.bytes[i] = bytes[k]; t.round16[i] = round16[k];
+        most = most > bytes[k] ? most : bytes[k];
+    }
+    const long long blocks = (most / 16 + 255) / 256;
+    dim3 grid((unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks)), n);
+    hipLaunchKernelGGL(copy_batch_kernel, grid, dim3(256), 0, (hipStream_t)stream, t);
+    MTMP_CHECK_LAUNCH("mtmp_copy_batch");
     return MTMP_OK;
 }
 

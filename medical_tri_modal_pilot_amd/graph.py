@@ -106,14 +106,20 @@ class GraphedTrainStep:
         return carry["loss"]
 
     def run(self, inputs: Dict[str, torch.Tensor], fn: Union[Callable, List[Callable]], params=None,
-            reducer=None) -> torch.Tensor:
+            reducer=None, round_fp16=()) -> torch.Tensor:
         """fn(inputs) -> scalar loss tensor (zero_grad + forward + backward with no host sync), or a list of stage
         callables stage(inputs, carry) of which one stores carry["loss"] (see the module docstring).
-        reducer: ddp.GradReducer in staged mode, or None.  Returns the loss tensor of this step (a static buffer when
-        replayed)."""
+        reducer: ddp.GradReducer in staged mode, or None.  round_fp16: keys of fp32 inputs the step must see as
+        x.half().float() (the reference's fp16 storage of its event / time inputs): the rounding rides on the copy into the
+        graph's static buffers instead of costing two eager launches per tensor in front of every step.  Returns the loss
+        tensor of this step (a static buffer when replayed)."""
         stages = self._stages(fn)
+        round_fp16 = frozenset(round_fp16)
+
+        def rounded():                     # eager paths: the plain tensor ops
+            return {k: (v.half().float() if k in round_fp16 else v) for k, v in inputs.items()}
         if self.disabled:
-            return self._eager_on_side_stream(inputs, stages, reducer)
+            return self._eager_on_side_stream(rounded(), stages, reducer)
         key = self.signature(inputs) + (len(stages),)
         ent = self.entries.get(key)
         if ent is None:
@@ -124,9 +130,9 @@ class GraphedTrainStep:
         if "graphs" not in ent:
             if ent["seen"] < self.warmup:
                 ent["seen"] += 1
-                return self._eager_on_side_stream(inputs, stages, reducer)
+                return self._eager_on_side_stream(rounded(), stages, reducer)
             try:
-                self._capture(ent, inputs, stages, reducer)
+                self._capture(ent, rounded(), stages, reducer)
             except Exception as e:                      # noqa: BLE001
                 self.entries.clear()
                 torch.cuda.synchronize(self.device)
@@ -136,25 +142,28 @@ class GraphedTrainStep:
                 self.disabled = True
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
                               "continuing with eager launches (--hip-graph-fallback 1)")
-                return self._eager_on_side_stream(inputs, stages, reducer)
+                return self._eager_on_side_stream(rounded(), stages, reducer)
         cur = torch.cuda.current_stream(self.device)
         fresh = ent.pop("fresh", False)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):           # replay on the capture stream, joined to the caller's by events
             if not fresh:
-                # one multi-tensor copy for all same-device inputs (a dozen small D2D copy_ calls cost ~120 us of host
-                # time per step, all of it GPU-idle time right after the previous step's loss.item())
-                dst, src = [], []
+                # ONE launch for all same-device inputs (ops.copy_batch, fp16 rounding included): a dozen D2D copy_ calls and
+                # six cast launches cost ~250 us of host time per step, all of it GPU-idle time right after the previous
+                # step's loss.item()
+                dst, src, r16 = [], [], []
                 for k, v in inputs.items():
-                    d = ent["static"][k]
-                    if v.device == d.device and v.dtype == d.dtype and v.numel() > 0:
+                    d, r = ent["static"][k], k in round_fp16
+                    if v.numel() > 0 and ops.copy_batch_ok(d, v, r):
                         dst.append(d)
                         src.append(v)
+                        r16.append(r)
                     elif v.numel() > 0:
-                        d.copy_(v, non_blocking=True)
+                        d.copy_(v.half().float() if r else v, non_blocking=True)
                     v.record_stream(self.stream)
-                if dst:
-                    torch._foreach_copy_(dst, src)
+                for i in range(0, len(dst), ops.COPY_BATCH_MAX):
+                    j = i + ops.COPY_BATCH_MAX
+                    ops.copy_batch(dst[i:j], src[i:j], r16[i:j])
             for g, ids in zip(ent["graphs"], ent["ready"]):
                 g.replay()
                 if reducer is not None and ids:

@@ -114,6 +114,28 @@ def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, wa
     return (y, xn, stats, None) if want_signs else (y, xn, stats)
 
 
+COPY_BATCH_MAX = 16
+
+
+def copy_batch_ok(d, s, r=False):
+    """Can the pair (dst, src) go through copy_batch?  (same device / dtype / element count, contiguous, 16-byte aligned)"""
+    return (d.is_cuda and d.device == s.device and d.dtype == s.dtype and d.numel() == s.numel() and d.numel() > 0
+            and d.is_contiguous() and s.is_contiguous() and d.data_ptr() % 16 == 0 and s.data_ptr() % 16 == 0
+            and (not r or d.dtype == torch.float32))
+
+
+def copy_batch(dsts, srcs, round16=None):
+    """dsts[i].copy_(srcs[i]) for up to COPY_BATCH_MAX pairs that pass copy_batch_ok in ONE launch; round16[i]: fp32 pair i is
+    written as srcs[i].half().float()."""
+    n = len(dsts)
+    round16 = [False] * n if round16 is None else list(round16)
+    if n == 0 or n > COPY_BATCH_MAX or not all(copy_batch_ok(d, s, r) for d, s, r in zip(dsts, srcs, round16)):
+        raise ValueError("copy_batch: 1..%d pairs that pass copy_batch_ok" % COPY_BATCH_MAX)
+    PV, LV, IV = ctypes.c_void_p * n, ctypes.c_longlong * n, ctypes.c_int * n
+    call("mtmp_copy_batch", PV(*[s.data_ptr() for s in srcs]), PV(*[d.data_ptr() for d in dsts]),
+         LV(*[d.numel() * d.element_size() for d in dsts]), IV(*[int(bool(r)) for r in round16]), n, _stream())
+
+
 def stream_lengths(lens, n_bott, txt_idx):
     """lens: three int64 [B] CUDA tensors or None (unmasked stream).  Returns (plain, fused): lists of int32 [B] | None with
     plain = len + 1 (CLS; stream txt_idx: 3 -> 0) and fused = plain + n_bott -- one launch (mbt_encoder.py:703-714)."""

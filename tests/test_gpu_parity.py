@@ -144,6 +144,18 @@ def test_ln_gemm_and_gemm_nt(ops, dt):
     check(f"gemm_nt[{str(dt)[6:]}].y", y.float(), yr, TOL[dt] if dt == torch.float32 else 2e-2)
 
 
+def test_copy_batch(ops):
+    g = torch.Generator(device=DEV).manual_seed(11)
+    srcs = [torch.randn(n, generator=g, device=DEV) * 300 for n in (64 * 1000 * 3, 64, 7, 1, 4099)]
+    srcs += [torch.randint(0, 1000, (64,), generator=g, device=DEV), torch.randn(5, 3, generator=g, device=DEV).to(torch.bfloat16)]
+    dsts = [torch.full_like(s, 7) for s in srcs]
+    r16 = [True, True, False, True, True, False, False]
+    ops.copy_batch(dsts, srcs, r16)
+    for d, s, r in zip(dsts, srcs, r16):
+        assert torch.equal(d, s.half().float() if r else s)
+    assert not ops.copy_batch_ok(dsts[0][1:], srcs[0][1:])           # not 16-byte aligned: the caller falls back to copy_()
+
+
 def test_transpose_batch(ops):
     g = torch.Generator(device=DEV).manual_seed(3)
     for dt in (torch.bfloat16, torch.float32):

@@ -43,6 +43,6 @@ def report():
             print("%-12s median %.1f us (n=%d)" % (k, 1e6 * st.median(v[10:]), len(v) - 10), file=sys.stderr)
 
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "30", "--warmup", "10", "--probe-steps", "0"]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "30", "--warmup", "10", "--probe-launches", "0"]
 import runpy
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
