@@ -1020,11 +1020,17 @@ MTMP_DEV void tr_mma(f32x16 (&acc)[2][2], const bf16* sY, const bf16* sX, int wn
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs<bf16> p) {
+// NG = 1: 256 threads, two workgroups per CU.  NG = 2 (large M): 512 threads = two GROUPS of four waves that share the output
+// tile and split every 128-token step between them (each group is the NG = 1 workgroup on its own 64 tokens and its own half
+// of the LDS); at the end group 1 hands its accumulators over through LDS and group 0 writes ONE partial slab: the same eight
+// waves per CU, half the slabs -- the split-M partials (33 MB written here and read again by tn_reduce_kernel per launch at
+// config 2, against 132-165 MB of operands) were a fifth of this HBM-bound kernel's traffic.
+template <int NG>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(TnArgs<bf16> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    bf16* sm = reinterpret_cast<bf16*>(smem_raw);          // [2 stages][dY | X][TT][LDG]
-    constexpr int MAT = TT * LDG, STAGE = 2 * MAT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    constexpr int MAT = TT * LDG, GRP = 2 * MAT, STAGE = NG * GRP;
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
+    bf16* sm = reinterpret_cast<bf16*>(smem_raw) + grp * GRP;   // [2 stages][NG groups][dY | X][TT][LDG]
     const int tn = p.N / 128, tk = p.K / 128;
     int w = xcd_remap(blockIdx.x, gridDim.x);
     const int split = w / (tn * tk);
@@ -1032,18 +1038,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs<bf16> p) {
     const int n0 = (w / tk) * 128, k0 = (w % tk) * 128;
     const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
-    const int nsteps = m_end > m_lo ? (m_end - m_lo + TT - 1) / TT : 0;
+    constexpr int ST = NG * TT;                            // tokens per step (all groups)
+    const int nsteps = m_end > m_lo ? (m_end - m_lo + ST - 1) / ST : 0;
+    const int mg = m_lo + grp * TT;                        // this group's first token
     f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const bool bias_blk = (k0 == 0);
     TrRegs y0, x0, y1, x1;
     // steps past the end fetch clamped rows with ok = 0: their tiles are all zero
-    tr_fetch(y0, p.dy, p.ldy, m_lo, m_end, n0, tid);           tr_fetch(x0, p.x, p.ldx, m_lo, m_end, k0, tid);
-    tr_fetch(y1, p.dy, p.ldy, m_lo + TT, m_end, n0, tid);      tr_fetch(x1, p.x, p.ldx, m_lo + TT, m_end, k0, tid);
+    tr_fetch(y0, p.dy, p.ldy, mg, m_end, n0, tid);             tr_fetch(x0, p.x, p.ldx, mg, m_end, k0, tid);
+    tr_fetch(y1, p.dy, p.ldy, mg + ST, m_end, n0, tid);        tr_fetch(x1, p.x, p.ldx, mg + ST, m_end, k0, tid);
     if (nsteps > 0) {
         tr_commit(sm, y0, tid); tr_commit(sm + MAT, x0, tid);
         if (bias_blk) tr_csum(csum, y0);
-        tr_fetch(y0, p.dy, p.ldy, m_lo + 2 * TT, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, m_lo + 2 * TT, m_end, k0, tid);
+        tr_fetch(y0, p.dy, p.ldy, mg + 2 * ST, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, mg + 2 * ST, m_end, k0, tid);
     }
     __syncthreads();
     for (int s = 0; s < nsteps; s += 2) {
@@ -1051,36 +1059,60 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tr_kernel(TnArgs<bf16> p) {
         tr_mma(acc, sm, sm + MAT, wn, wk, lane);
         tr_commit(sm + STAGE, y1, tid); tr_commit(sm + STAGE + MAT, x1, tid);
         if (bias_blk) tr_csum(csum, y1);
-        tr_fetch(y1, p.dy, p.ldy, m_lo + (s + 3) * TT, m_end, n0, tid); tr_fetch(x1, p.x, p.ldx, m_lo + (s + 3) * TT, m_end, k0, tid);
+        tr_fetch(y1, p.dy, p.ldy, mg + (s + 3) * ST, m_end, n0, tid); tr_fetch(x1, p.x, p.ldx, mg + (s + 3) * ST, m_end, k0, tid);
         __syncthreads();
         if (s + 1 >= nsteps) break;
         // odd step: multiply stage 1, stage 0 <- y0/x0 (step s+2), refill with step s+4
         tr_mma(acc, sm + STAGE, sm + STAGE + MAT, wn, wk, lane);
         tr_commit(sm, y0, tid); tr_commit(sm + MAT, x0, tid);
         if (bias_blk) tr_csum(csum, y0);
-        tr_fetch(y0, p.dy, p.ldy, m_lo + (s + 4) * TT, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, m_lo + (s + 4) * TT, m_end, k0, tid);
+        tr_fetch(y0, p.dy, p.ldy, mg + (s + 4) * ST, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, mg + (s + 4) * ST, m_end, k0, tid);
         __syncthreads();
     }
+    if constexpr (NG == 2) {
+        // group 1 -> LDS [64 accumulator registers][256 threads] (64 KiB, over the dead tiles) -> group 0 adds
+        float* xch = reinterpret_cast<float*>(smem_raw);
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) xch[((i * 2 + j) * 16 + t) * 256 + tid] = acc[i][j][t];
+        }
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) acc[i][j][t] += xch[((i * 2 + j) * 16 + t) * 256 + tid];
+        }
+    }
     float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
+    if (grp == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
-                out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + wk + 32 * j + r] = acc[i][j][t];
+                for (int t = 0; t < 16; ++t)
+                    out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + wk + 32 * j + r] = acc[i][j][t];
+    }
     if (bias_blk) {
-        // thread (rg, ch) holds partial sums of columns 8ch..8ch+7 over its rows: 16 row groups -> LDS -> one sum
+        // thread (rg, ch) holds partial sums of columns 8ch..8ch+7 over its rows: 16 NG row groups -> LDS -> one sum
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem_raw);   // [16][128]
+        float* red = reinterpret_cast<float*>(smem_raw);   // [16 NG][128]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid >> 4) * 128 + 8 * (tid & 15) + e] = csum[e];
+        for (int e = 0; e < 8; ++e) red[(grp * 16 + (tid >> 4)) * 128 + 8 * (tid & 15) + e] = csum[e];
         __syncthreads();
-        if (tid < 128) {
-            float s = 0.f;
+        if (threadIdx.x < 128) {
+            float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) s += red[g * 128 + tid];
-            out[(size_t)p.N * p.K + n0 + tid] = s;
+            for (int g = 0; g < 16 * NG; ++g) sum += red[g * 128 + threadIdx.x];
+            out[(size_t)p.N * p.K + n0 + threadIdx.x] = sum;
         }
     }
 }
@@ -1369,19 +1401,26 @@ int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStr
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
                    hipStream_t st) {
-    constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernel, 2 workgroups per CU
-    const int splits = tn_splits(M, N, K, TR ? 512 : 640);
+    constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernel, eight waves per CU
+    // two token groups per workgroup (half the partial slabs) once the split count is not what limits the grid
+    const bool two = TR && tn_splits(M, N, K, 256) * 8 * TK <= M;
+    const int splits = tn_splits(M, N, K, two ? 256 : (TR ? 512 : 640));
     int rps = (M + splits - 1) / splits;
     rps = (rps + TK - 1) / TK * TK;
     TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
-    const size_t sm = TR ? (size_t)4 * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
-    const void* fn = TR ? (const void*)gemm_tn_tr_kernel : (const void*)gemm_tn_kernel<T>;
+    const size_t sm = TR ? (size_t)(two ? 8 : 4) * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
+    const void* fn = TR ? (two ? (const void*)gemm_tn_tr_kernel<2> : (const void*)gemm_tn_tr_kernel<1>) : (const void*)gemm_tn_kernel<T>;
     if (sm > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
         mtmp_set_error("mtmp_gemm_tn: cannot raise dynamic LDS to %zu", sm);
         return MTMP_ERR_LAUNCH;
     }
-    if constexpr (TR) hipLaunchKernelGGL(gemm_tn_tr_kernel, dim3(splits * (N / 128) * (K / 128)), dim3(256), sm, st, a);
-    else hipLaunchKernelGGL(gemm_tn_kernel<T>, dim3(splits * (N / 128) * (K / 128)), dim3(256), sm, st, a);
+    const dim3 grid(splits * (N / 128) * (K / 128));
+    if constexpr (TR) {
+        if (two) hipLaunchKernelGGL(gemm_tn_tr_kernel<2>, grid, dim3(512), sm, st, a);
+        else     hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(256), sm, st, a);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(256), sm, st, a);
+    }
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn");
     const size_t nk = (size_t)N * K, cols = nk + N;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, ws, splits, cols, dw, db, nk);
