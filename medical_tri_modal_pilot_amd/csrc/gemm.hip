@@ -453,7 +453,7 @@ MTMP_DEV void gload_u16(unsigned& d, const void* ptr) { asm volatile("global_loa
 template <int N> MTMP_DEV void gwait1(unsigned& a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(N) : "memory"); }
 
 // SIGNS (forward, with RELU): besides y the kernel writes one bit per output, "y > 0", 16 bits per lane and 32-feature group in
-// the lane's own accumulator order: signs[((2 j + g) M + row) 2 + half] for panel j, group g.  GATE (backward): the FFN's
+// the lane's own accumulator order (rows through swz23): signs[((2 j + g) M + row) 2 + half] for panel j, group g.  GATE (backward): the FFN's
 // dH = dY W2 gated by the saved hidden activation (y = h > 0 ? y * gate_scale : 0, autograd of module.py:77-79) reads those
 // bits instead of h itself -- the same kernel geometry, so a lane needs exactly the 16 bits its forward twin wrote: 4 MB of
 // gate traffic per launch at config 2 instead of 132 MB.  No LayerNorm in GATE mode (p.gamma == nullptr).
@@ -545,9 +545,13 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     const int tok = lane / P::LPT, ch = lane % P::LPT;           // store phase: this lane's token (+ 16 per pass), 16 B chunk
     // reader: row 32g + r, k-step c -> chunk (2c + half) ^ (r & 15); the XOR only touches chunk bits 0-3, so c >> 3 and g are
     // immediate offsets on eight per-lane addresses
+    // (rows through swz23, common.cuh: accumulator registers 8s..8s+7 of a lane then hold 8 CONSECUTIVE features, 16s + 8 half + j
+    //  -- 16-byte pieces for the staging tile, and exactly the k-step-s operand fragment of a product that consumes this one)
     const char* rd[8];
+    const int rs = swz23(r);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) rd[c] = smem_raw + r * P::ROWB + 16 * ((2 * c + half) ^ (r & 15));
+    for (int c = 0; c < 8; ++c) rd[c] = smem_raw + rs * P::ROWB + 16 * ((2 * c + half) ^ (rs & 15));
+    auto ucol = [&](int i4) { return 16 * (i4 >> 1) + 8 * half + 4 * (i4 & 1); };   // first feature of registers 4 i4 .. 4 i4 + 3
     panel_dma(min(j0 + 1, j1 - 1), 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // panels j0, j0 + 1 landed (this wave's share)
     __syncthreads();                                             // ... everyone's; sB written; sG dead (sS may be written)
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
                 v[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[i] * p.gate_scale) &
                                                      __builtin_amdgcn_sbfe((int)gate_bits, 15 - (4 * i4 + i), 1));
         }
-        store4<T>(sS + r * P::FS + 8 * i4 + 4 * half, v[0], v[1], v[2], v[3]);
+        store4<T>(sS + r * P::FS + ucol(i4), v[0], v[1], v[2], v[3]);
     };
     // One phase = the 16 MFMAs of accumulator group gm of panel jm, issued in eight slices of two; between them (EPI) the
     // epilogue of group ge of panel je, cut into eight pieces of vector work: per 4 features [mask hash] and [ReLU / select /
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         if (GATE) gload_u16(gnext, signs_ptr(jm, gm));
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (jm - j0) * P::NP + 32 * gm + 8 * i4 + 4 * half);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sB + (jm - j0) * P::NP + 32 * gm + ucol(i4));
             acc[gm][4 * i4] = v[0]; acc[gm][4 * i4 + 1] = v[1]; acc[gm][4 * i4 + 2] = v[2]; acc[gm][4 * i4 + 3] = v[3];
         }
         Frag<T> b[KC];
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
             if (EPI && s8 < 8) {
                 const int i4 = s8 >> 1;
                 if ((s8 & 1) == 0) {
-                    const int col = n0 + 32 * ge + 8 * i4 + 4 * half;
+                    const int col = n0 + 32 * ge + ucol(i4);
                     if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
                 } else {
                     piece(ge, i4, fld, gcur, sign_bits);
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         unsigned sign_bits = 0;
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
-            const int col = n0 + 32 * g + 8 * i4 + 4 * half;
+            const int col = n0 + 32 * g + ucol(i4);
             unsigned fld[4];
             if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
             piece(g, i4, fld, gcur, sign_bits);
