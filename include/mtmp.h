@@ -247,6 +247,17 @@ int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, 
 int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias, void* y,
                        long long M, int C, int N, float eps, int act, void* stream);
 
+/* The position-wise FFN of an encoder layer in one launch (bf16, d_model 256, d_ff 1024):
+ *   h[M,1024] = drop1(relu(LN(x) w1^T + b1)),  out[M,256] = x + drop2(h w2^T + b2)
+ * -- module.py:138-144 (custom LayerNorm), module.py:74-80 (the two k = 1 convolutions, ReLU, both dropouts) and the residual
+ * of encoder.py:32.  Also written: h (the backward's dW2 operand), xn = LN(x) [M,256], stats[M,2] = (mean, 1/(std+eps)) and, when
+ * signs != NULL, the sign bits of h (mtmp_sign_bits_bytes(M, 1024) bytes, mtmp_gemm_nt_signs' gate).  w1 [1024,256], w2 [256,1024]
+ * bf16; gamma, beta, b1, b2 fp32.  Dropout masks: keep(seed1 ^ *seed_dev, row*1024+col) and keep(seed2 ^ *seed_dev, row*256+col),
+ * the ones mtmp_ln_gemm / mtmp_gemm_nt draw.  out must not alias x. */
+int mtmp_ffn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
+                 const float* b2, void* out, void* h, void* xn, float* stats, void* signs, int M, int ldx, float eps, float drop_p,
+                 unsigned seed1, unsigned seed2, const unsigned* seed_dev, void* stream);
+
 /* Up to 16 device-to-device copies in one launch: dst[i] <- src[i] (bytes[i] bytes, both 16-byte aligned); round16[i] != 0: the
  * buffer holds fp32 values and is written as float(half(x)) -- the fp16 round trip the reference applies to its event / time
  * inputs (trainer.py:26-27, 2_train.py:164).  All arrays are HOST arrays of n entries, read at launch time. */

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 #pragma unroll
     for (int c = 0; c < 16; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
+        for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 = fmaf(d, d, s2); }
     s2 += __shfl_xor(s2, 32, 64);
     const float sigma = sqrtf(s2 * (1.0f / 255.0f));             // torch.std: Bessel-corrected
     const float rs = 1.0f / (sigma + p.eps);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
 #pragma unroll
         for (int c = 0; c < KC; ++c)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 += d * d; }
+            for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 = fmaf(d, d, s2); }
         s2 += __shfl_xor(s2, 32, 64);
         // the fusion layers' LayerNorm: torch.std (Bessel-corrected), eps added to it; nn.LayerNorm: biased variance, eps inside
         const float rs = TORCH_LN ? rsqrtf(s2 * (1.0f / K) + p.eps) : 1.0f / (sqrtf(s2 * (1.0f / (K - 1))) + p.eps);
@@ -718,11 +718,383 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         phase(j0, 1, j0, 0, Yes{}, 0, 0, No{}, g1bits, g0bits, template_int<NG>{});
     }
     epi_alone(j1 - 1, 1, j1 - 1, 0, g1bits);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the repeated last DMA must not outlive the workgroup's LDS)
 #ifdef MTMP_STAMP
     TSTAMP(ts2)
     if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
         g_stamp_lng[2 * blockIdx.x] = ts1 - ts0;
         g_stamp_lng[2 * blockIdx.x + 1] = ts2 - ts1;
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// The position-wise FFN of an encoder layer in ONE kernel (bf16): out = x + drop2(relu-drop1(LN(x) W1^T + b1) W2^T + b2)
+// (module.py:138-144, :74-80, encoder.py:32).  The 4 x 256-wide hidden activation h is still written (the backward's dW2 operand)
+// and its sign bits too, but it is never read back: as two launches the step moved 198 + 198 MB here, fused it moves 231 MB.
+// Structure = the row-panel kernel with a second product chained behind every panel: a workgroup owns 128 rows (32 per wave, the
+// normalised rows as 16 register fragments); per panel of 64 hidden units
+//   1. H^T panel = W1[panel] xn^T (+ b1): 2 x 16 MFMAs, W1 rows through swz23, so that after ReLU / dropout the accumulator
+//      registers 8s..8s+7 ARE the k-step-s operand fragments of the second product (common.cuh) -- no LDS round trip between the
+//      two GEMMs; the same values go through the wave's staging tile to h (64-byte row pieces);
+//   2. out^T += W2[:, panel] H panel: 8 output tiles x 4 k-steps = 32 MFMAs, accumulated over the 16 panels in 128 registers.
+// Both weight panels ([64][256] of W1, [256][64] of W2, 32 KiB each) arrive by LDS-DMA into chunk-permuted unpadded rows, double
+// buffered: 128 KiB of LDS, one workgroup per CU, one wave per SIMD (<= 512 registers).
+struct FfnFwdArgs {
+    const bf16* x; const float* gamma; const float* beta; const bf16* w1; const float* b1; const bf16* w2; const float* b2;
+    bf16* out; bf16* h; bf16* xn; float* stats; unsigned short* signs;
+    int M, ldx;
+    float eps, drop_p;
+    unsigned seed1, seed2;
+    const unsigned* seed_dev;
+};
+struct FfnLds {
+    static constexpr unsigned w1_off = 0, w2_off = 65536, stage_off = 131072, b1_off = stage_off + 4 * 32 * 40 * 2, b2_off = b1_off + 4096;
+    static constexpr size_t bytes = b2_off + 1024;
+};
+template <bool DROP>
+__global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(FfnFwdArgs p) {
+    using T = bf16;
+    using L = FfnLds;
+    constexpr int FS = 40, NPAN = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, half = lane >> 5;
+    T* sS = reinterpret_cast<T*>(smem_raw + L::stage_off) + wave * 32 * FS;       // wave-private [32][FS]
+    float* sG = reinterpret_cast<float*>(smem_raw + L::stage_off);                // gamma|beta, prologue only (aliases sS)
+    float* sB1 = reinterpret_cast<float*>(smem_raw + L::b1_off);
+    float* sB2 = reinterpret_cast<float*>(smem_raw + L::b2_off);
+    const int m_wave = blockIdx.x * BM + wave * 32;
+    const int row = min(m_wave + r, p.M - 1);
+    // DMA slots.  W1 panel: as ln_gemm_dma_kernel (slot q -> row q / 32, position q % 32 takes chunk position ^ (row & 15)).
+    // W2 panel [256 rows][8 chunks of 16 B]: slot q -> row q / 8, position q % 8 takes chunk position ^ ((row >> 1) & 7).
+    unsigned d1[8], d2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned q = 64u * (unsigned)(8 * wave + i) + (unsigned)lane;
+        d1[i] = (q >> 5) * 512u + 16u * ((q & 31u) ^ ((q >> 5) & 15u));
+        d2[i] = (q >> 3) * 2048u + 16u * ((q & 7u) ^ ((q >> 4) & 7u));
+    }
+    // piece i (0..7) of this wave's share of the W1 / W2 panel j
+    auto dma_w1 = [&](int j, int i) {
+        dma16(d1[i], reinterpret_cast<const char*>(p.w1 + (size_t)j * 64 * 256),
+              lds0 + L::w1_off + (unsigned)(j & 1) * 32768u + (unsigned)(8 * wave + i) * 1024u);
+    };
+    auto dma_w2 = [&](int j, int i) {
+        dma16(d2[i], reinterpret_cast<const char*>(p.w2 + (size_t)j * 64),
+              lds0 + L::w2_off + (unsigned)(j & 1) * 32768u + (unsigned)(8 * wave + i) * 1024u);
+    };
+#ifdef MTMP_STAMP
+    unsigned long long ts0, ts1, ts2, ts3;
+    TSTAMP(ts0)
+#endif
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_w1(0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_w2(0, i);
+    sG[tid] = p.gamma[tid];
+    sG[256 + tid] = p.beta[tid];
+    for (int i = tid; i < 1024; i += 256) sB1[i] = p.b1[i];
+    sB2[tid] = p.b2[tid];
+    // ---- LayerNorm prologue (module.py:138-144: torch.std, eps added to it), lane (r, half) holds k = 16c + 8 half + j of row r
+    Frag<T> af[16];
+    const T* arow = p.x + (size_t)row * p.ldx + 8 * half;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) af[c] = frag_load<T>(arow + 16 * c);
+    {
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.0f / 256.0f);
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 = fmaf(d, d, s2); }
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rs = 1.0f / (sqrtf(s2 * (1.0f / 255.0f)) + p.eps);
+        __syncthreads();                                         // sG ready
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = 16 * c + 8 * half;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
+            if (p.xn) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
+        }
+        if (p.stats && half == 0) {
+            p.stats[2 * (size_t)row] = mean;
+            p.stats[2 * (size_t)row + 1] = rs;
+        }
+    }
+    const unsigned thr = dropout_threshold(p.drop_p);
+    const float keep_scale = 1.0f / (1.0f - p.drop_p);
+    const unsigned sdev = (p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u;
+    const unsigned seed1 = p.seed1 ^ sdev, seed2 = p.seed2 ^ sdev;
+    const int tok = lane >> 2, ch = lane & 3;                    // store phase: this lane's token (+ 16 per pass), 16 B chunk
+    const int rs_ = swz23(r);
+    const char* rd1[8];                                          // W1 panel: row 32g + swz23(r), k-step c
+#pragma unroll
+    for (int c = 0; c < 8; ++c) rd1[c] = smem_raw + L::w1_off + rs_ * 512 + 16 * ((2 * c + half) ^ (rs_ & 15));
+    const char* rd2[4];                                          // W2 panel: row 32t + swz23(r), k-step ks of the panel
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd2[ks] = smem_raw + L::w2_off + rs_ * 128 + 16 * ((2 * ks + half) ^ ((rs_ >> 1) & 7));
+    auto ucol = [&](int i4) { return 16 * (i4 >> 1) + 8 * half + 4 * (i4 & 1); };
+    auto tile_store = [&](T* base, int ld, int col0, const u32x4_t (&d)[2]) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int t = tok + 16 * ps;
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(base + (size_t)min(m_wave + t, p.M - 1) * ld + col0) + 16 * ch) = d[ps];
+        }
+    };
+    auto tile_load = [&](u32x4_t (&d)[2]) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            d[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + (tok + 16 * ps) * FS) + 16 * ch);
+    };
+    f32x16 acc2[8], acc1[2];
+    Frag<T> hf[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc2[t] = f32x16{0};
+    // A panel is walked in four segments of 16 MFMAs, each cut into eight slices of two (sched_barrier(0) between slices, as in
+    // ln_gemm_dma_kernel) that carry the vector work of ANOTHER accumulator group:
+    //   S1  H group 0                     | drain of the previous panel's group-1 tile
+    //   S2  H group 1                     | ReLU / dropout / sign bits / park of group 0     -> operand fragments hf[0..1]
+    //   S3  out += W2[:, units 0..31] H   | the same for group 1; drain of the group-0 tile  -> hf[2..3]
+    //   S4  out += W2[:, units 32..63] H  | (next iteration's S1 drains the group-1 tile)
+    // One staging tile per wave is enough: a wave's LDS instructions execute in order, and a tile is drained (read) in the
+    // first slice of the segment whose later slices park the next one.
+    unsigned fld[4], sign_bits = 0;
+    auto bias_init = [&](int j, int g) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sB1 + 64 * j + 32 * g + ucol(i4));
+            acc1[g][4 * i4] = v[0]; acc1[g][4 * i4 + 1] = v[1]; acc1[g][4 * i4 + 2] = v[2]; acc1[g][4 * i4 + 3] = v[3];
+        }
+    };
+    // vector piece s8 (0..7) of the hidden group g of panel j: even = mask hash of 4 units, odd = select / sign / park
+    auto h_piece = [&](int j, int g, int s8) {
+        const int i4 = s8 >> 1;
+        if ((s8 & 1) == 0) {
+            if (DROP) dropout_fields4(seed1, ((unsigned)row * 1024u + (unsigned)(64 * j + 32 * g + ucol(i4))) >> 2, fld);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = acc1[g][4 * i4 + i];
+            unsigned long long lm = __builtin_amdgcn_ballot_w64(v > 0.f);
+            if (DROP) lm &= __builtin_amdgcn_ballot_w64(fld[i] >= thr);
+            const float sv = DROP ? v * keep_scale : v;
+            asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %2, %3\n\tv_addc_co_u32_e64 %1, vcc, %1, %1, %3"
+                : "=&v"(v), "+v"(sign_bits) : "v"(sv), "s"(lm) : "vcc");
+            acc1[g][4 * i4 + i] = v;
+        }
+        store4<T>(sS + r * FS + ucol(i4), acc1[g][4 * i4], acc1[g][4 * i4 + 1], acc1[g][4 * i4 + 2], acc1[g][4 * i4 + 3]);
+    };
+    auto h_finish = [&](int j, int g) {                          // after piece 7: sign bits out, operand fragments
+        if (p.signs) p.signs[((size_t)(2 * j + g) * p.M + row) * 2 + half] = (unsigned short)sign_bits;
+        sign_bits = 0;
+        hf[2 * g] = frag_from_acc<T>(acc1[g], 0);
+        hf[2 * g + 1] = frag_from_acc<T>(acc1[g], 1);
+    };
+    auto h_drain = [&](int j, int g) {                           // staging tile -> h rows (64-byte pieces)
+        u32x4_t dr[2];
+        wave_lds_handover();
+        tile_load(dr);
+        wave_lds_handover();
+        tile_store(p.h, 1024, 64 * j + 32 * g, dr);
+    };
+    constexpr int NV = DROP ? 9 : 4;
+    // segment of the first product: group g of panel j; VP: the pieces of group vg; DR: first drain the tile (dj, dg)
+    auto seg1 = [&](int j, int g, auto vp_tag, int vg, auto dr_tag, int dj, int dg, auto dma_tag) {
+        constexpr bool VP = decltype(vp_tag)::value, DR = decltype(dr_tag)::value, DMA = decltype(dma_tag)::value;
+        const size_t cur = (size_t)((j & 1) * 32768 + g * 16384);
+        bias_init(j, g);
+        Frag<T> b[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c].v = *reinterpret_cast<const bf16x8*>(rd1[c] + cur);
+        if (DR) h_drain(dj, dg);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s8 < 4) {
+                b[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd1[2 * s8] + cur + 256);
+                b[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd1[2 * s8 + 1] + cur + 256);
+            }
+            mma<T>(acc1[g], b[2 * s8], af[2 * s8]);
+            if (DMA) dma_w1(j + 1, s8);                          // one piece of the next W1 panel per slice
+            mma<T>(acc1[g], b[2 * s8 + 1], af[2 * s8 + 1]);
+            if (VP) {
+                h_piece(j, vg, s8);
+                if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV + 2, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (VP) h_finish(j, vg);
+    };
+    // segment of the second product: k-steps 2 q, 2 q + 1 of panel j (the units of hidden group q) into all eight output tiles
+    auto seg2 = [&](int j, int q, auto vp_tag, int vg, auto dr_tag, int dg, auto dma_tag) {
+        constexpr bool VP = decltype(vp_tag)::value, DR = decltype(dr_tag)::value, DMA = decltype(dma_tag)::value;
+        const size_t cur = (size_t)((j & 1) * 32768);
+        Frag<T> a[16];                                           // fragment m = 8 (ks & 1) + t
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a[m].v = *reinterpret_cast<const bf16x8*>(rd2[2 * q] + cur + m * 4096);
+        if (DR) h_drain(j, dg);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s8 < 4) {
+                a[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd2[2 * q + 1] + cur + (2 * s8) * 4096);
+                a[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd2[2 * q + 1] + cur + (2 * s8 + 1) * 4096);
+            }
+            const int m0 = 2 * s8, m1 = 2 * s8 + 1;
+            mma<T>(acc2[m0 & 7], a[m0], hf[2 * q + (m0 >> 3)]);
+            if (DMA) dma_w2(j + 1, s8);                          // one piece of the next W2 panel per slice
+            mma<T>(acc2[m1 & 7], a[m1], hf[2 * q + (m1 >> 3)]);
+            if (VP) {
+                h_piece(j, vg, s8);
+                if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NV + 2, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (VP) h_finish(j, vg);
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    // Vector-memory operations of one iteration in issue order (sg = 1 with sign bits, else 0):
+    //   S1: 2 h stores (drain), 8 W1(j+1) pieces | S2: sg sign store | barrier B | S3: 2 h stores, sg | S4: 8 W2(j+1) pieces | barrier A
+    // W1(j+1) is waited for at barrier A of the next iteration: 2 + 2 sg + 8 operations are younger; W2(j+1) at its barrier B:
+    // 2 + 8 + sg are younger.  (Iterations 0 and 1 have issued less and wait with vmcnt(0).)
+    const int nsig = p.signs ? 1 : 0;
+#ifdef MTMP_STAMP
+    TSTAMP(ts1)
+#endif
+#ifdef MTMP_FFN_SPREAD_DMA          // (measured: 6.8 k cycles per panel against 5.2 k -- a DMA piece between two MFMAs costs more than up front)
+    for (int j = 0; j < NPAN; ++j) {
+        if (j < 2)     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nsig) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __syncthreads();                                         // A: W1(j) landed for everyone; the panels j - 1 are free
+        if (j == 0)            seg1(j, 0, No{}, 0, No{}, 0, 0, Yes{});
+        else if (j + 1 < NPAN) seg1(j, 0, No{}, 0, Yes{}, j - 1, 1, Yes{});
+        else                   seg1(j, 0, No{}, 0, Yes{}, j - 1, 1, No{});      // (no panel left to fetch)
+        seg1(j, 1, Yes{}, 0, No{}, 0, 0, No{});
+        if (j < 2)     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nsig) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __syncthreads();                                         // B: W2(j) landed for everyone
+        seg2(j, 0, Yes{}, 1, Yes{}, 0, No{});
+        if (j + 1 < NPAN) seg2(j, 1, No{}, 0, No{}, 0, Yes{});
+        else              seg2(j, 1, No{}, 0, No{}, 0, No{});
+    }
+#else
+    // Both panels of j + 1 are requested right behind the barrier: the 4 h stores and 2 sg sign stores of an iteration are the
+    // only younger operations when they are waited for.
+#ifdef MTMP_STAMP
+    unsigned long long tq0, tq1, tq2, tq3, tq4, tq5, sA = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#endif
+    for (int j = 0; j < NPAN; ++j) {
+#ifdef MTMP_STAMP
+        TSTAMP(tq0)
+#endif
+        if (j < 2)     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nsig) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __syncthreads();                                         // panel j landed for everyone; the panels j - 1 are free
+        if (j + 1 < NPAN) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma_w1(j + 1, i);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dma_w2(j + 1, i);
+        }
+#ifdef MTMP_STAMP
+        TSTAMP(tq1)
+#endif
+        if (j == 0) seg1(j, 0, No{}, 0, No{}, 0, 0, No{});
+        else        seg1(j, 0, No{}, 0, Yes{}, j - 1, 1, No{});
+#ifdef MTMP_STAMP
+        TSTAMP(tq2)
+#endif
+        seg1(j, 1, Yes{}, 0, No{}, 0, 0, No{});
+#ifdef MTMP_STAMP
+        TSTAMP(tq3)
+#endif
+        seg2(j, 0, Yes{}, 1, Yes{}, 0, No{});
+#ifdef MTMP_STAMP
+        TSTAMP(tq4)
+#endif
+        seg2(j, 1, No{}, 0, No{}, 0, No{});
+#ifdef MTMP_STAMP
+        TSTAMP(tq5)
+        sA += tq1 - tq0; s1 += tq2 - tq1; s2 += tq3 - tq2; s3 += tq4 - tq3; s4 += tq5 - tq4;
+#endif
+    }
+#ifdef MTMP_STAMP
+    if (tid == 0 && blockIdx.x == 7) {
+        g_stamp_tn[0] = sA; g_stamp_tn[1] = s1; g_stamp_tn[2] = s2; g_stamp_tn[3] = s3; g_stamp_tn[4] = s4;
+    }
+#endif
+#endif
+    h_drain(NPAN - 1, 1);
+#ifdef MTMP_STAMP
+    TSTAMP(ts2)
+#endif
+    // ---- epilogue: + b2, drop2, round, + residual (the un-normalised input row), 32 features at a time
+    u32x4_t rv[8][2];                                            // the residual row pieces of all eight tiles, requested up front
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps)
+            rv[t][ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(
+                            p.x + (size_t)min(m_wave + tok + 16 * ps, p.M - 1) * p.ldx + 32 * t) + 16 * ch);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int col = 32 * t + ucol(i4);
+            unsigned fld[4];
+            if (DROP) dropout_fields4(seed2, ((unsigned)row * 256u + (unsigned)col) >> 2, fld);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + col);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = acc2[t][4 * i4 + i] + bv[i];
+                if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
+            }
+            store4<T>(sS + r * FS + ucol(i4), v[0], v[1], v[2], v[3]);
+        }
+        u32x4_t dr[2];
+        wave_lds_handover();
+        tile_load(dr);
+        wave_lds_handover();
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const bf16x8 ov = __builtin_bit_cast(bf16x8, dr[ps]), xv = __builtin_bit_cast(bf16x8, rv[t][ps]);
+            bf16x8 yv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) yv[i] = from_f32<T>(to_f32(ov[i]) + to_f32(xv[i]));
+            dr[ps] = __builtin_bit_cast(u32x4_t, yv);
+        }
+        tile_store(p.out, 256, 32 * t, dr);
+    }
+#ifdef MTMP_STAMP
+    TSTAMP(ts3)
+    if (tid == 0 && blockIdx.x < 512) {
+        g_stamp_lng[4 * blockIdx.x] = ts1 - ts0;
+        g_stamp_lng[4 * blockIdx.x + 1] = ts2 - ts1;
+        g_stamp_lng[4 * blockIdx.x + 2] = ts3 - ts2;
+        g_stamp_lng[4 * blockIdx.x + 3] = ts0;
     }
 #endif
 }
@@ -1497,6 +1869,30 @@ extern "C" int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, c
     GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, ln_w, ln_b, nullptr, nullptr, (int)M, N, C, C, N, 0, eps,
                      0.f, 0u, nullptr, nullptr, 1.f, 0, nullptr, 1};
     return launch_ln_linear_384(a, act == 2, (hipStream_t)stream);
+}
+
+// out[M,256] = x + drop2(h W2^T + b2),  h[M,1024] = drop1(relu(LN(x) W1^T + b1)): module.py:138-144, :74-80 and the residual of
+// encoder.py:32 in one launch (bf16, d_model 256 / d_ff 1024).  Also written: h (dW2's operand), xn = LN(x), stats (mean,
+// 1/(std+eps)) and the sign bits of h (mtmp_gemm_nt_signs' gate; may be NULL).  out must not alias x.
+extern "C" int mtmp_ffn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
+                            const void* w2, const float* b2, void* out, void* h, void* xn, float* stats, void* signs, int M, int ldx,
+                            float eps, float drop_p, unsigned seed1, unsigned seed2, const unsigned* seed_dev, void* stream) {
+    MTMP_CHECK_ARG(x && gamma && beta && w1 && b1 && w2 && b2 && out && h && x != out, "mtmp_ffn_fwd: null pointer / aliasing");
+    MTMP_CHECK_ARG(dtype == 1, "mtmp_ffn_fwd: bf16 only (dtype %d)", dtype);
+    MTMP_CHECK_ARG(M > 0 && ldx >= 256 && ldx % 8 == 0 && drop_p >= 0.f && drop_p < 1.f && (double)M * 1024 < 4294967296.0,
+                   "mtmp_ffn_fwd: bad shape M=%d ldx=%d drop_p=%f", M, ldx, drop_p);
+    FfnFwdArgs a{(const bf16*)x, gamma, beta, (const bf16*)w1, b1, (const bf16*)w2, b2, (bf16*)out, (bf16*)h, (bf16*)xn, stats,
+                 (unsigned short*)signs, M, ldx, eps, drop_p, seed1, seed2, seed_dev};
+    const void* f = drop_p > 0.f ? (const void*)ffn_fwd_kernel<true> : (const void*)ffn_fwd_kernel<false>;
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FfnLds::bytes) != hipSuccess) {
+        mtmp_set_error("mtmp_ffn_fwd: cannot raise dynamic LDS to %zu", FfnLds::bytes);
+        return MTMP_ERR_LAUNCH;
+    }
+    const dim3 grid((M + BM - 1) / BM);
+    if (drop_p > 0.f) hipLaunchKernelGGL(ffn_fwd_kernel<true>, grid, dim3(256), FfnLds::bytes, (hipStream_t)stream, a);
+    else              hipLaunchKernelGGL(ffn_fwd_kernel<false>, grid, dim3(256), FfnLds::bytes, (hipStream_t)stream, a);
+    MTMP_CHECK_LAUNCH("mtmp_ffn_fwd");
+    return MTMP_OK;
 }
 
 // Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32

@@ -150,6 +150,25 @@ def stream_lengths(lens, n_bott, txt_idx):
     return pick(0), pick(1)
 
 
+def ffn_fwd(x2d, gamma, beta, w1, b1, w2, b2, drop_p=0.0, seeds=(0, 0), want_signs=True):
+    """The layer's FFN in one launch (bf16): returns (out = x + drop2(h w2^T + b2), h = drop1(relu(LN(x) w1^T + b1)), xn, stats,
+    sign bits of h | None) -- mtmp_ffn_fwd; the same masks and roundings as ln_gemm(relu, drop) followed by gemm_nt(res, drop)."""
+    _gpu(x2d, w1, w2)
+    if x2d.dtype != torch.bfloat16:
+        raise TypeError("ffn_fwd: bf16 only")
+    M = x2d.shape[0]
+    dev = x2d.device
+    out = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=dev)
+    h = torch.empty(M, 4 * D_MODEL, dtype=x2d.dtype, device=dev)
+    xn = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=dev)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=dev)
+    signs = torch.empty(_lib.lib().mtmp_sign_bits_bytes(M, 4 * D_MODEL), dtype=torch.uint8, device=dev) if want_signs else None
+    call("mtmp_ffn_fwd", _dt(x2d), _p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), _p(h), _p(xn), _p(stats),
+         _p(signs), M, x2d.stride(0), LN_EPS, float(drop_p), int(seeds[0]) & 0xFFFFFFFF, int(seeds[1]) & 0xFFFFFFFF, _p(_seed_word),
+         _stream())
+    return out, h, xn, stats, signs
+
+
 def transpose_batch(mats):
     """[m.t().contiguous() for m in mats] (2-D, contiguous, one 16- or 32-bit dtype) in ONE launch; the results are views of
     one buffer."""
@@ -653,6 +672,15 @@ class StreamInputFn(torch.autograd.Function):
 PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, c2
 
 
+# The FFN half of a layer as ONE launch (mtmp_ffn_fwd) instead of mtmp_ln_gemm_signs + mtmp_gemm_nt (bit-identical results).
+# Built, tested (tests/test_gpu_parity.py::test_ffn_fwd_fused_equals_two_launches), NOT routed: 137 us against 138-147 us back to
+# back, but 160 us per launch inside the step against ~128 us for the pair (main-queue kernel time of a profiled replay 7.60 vs
+# 7.37 ms): one workgroup per CU (128 KiB of weight panels, 350 registers) runs the 503 row blocks in two rounds and shares the
+# CU with nothing; its panel loop sits at 5.2 k cycles per 64 MFMAs (tools/dbg/stamp_ffn.py).
+FUSED_FFN_FWD = False
+FUSED_FFN_MIN_ROWS = 32768
+
+
 def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T, wqkv^T, w1^T) in compute dtype.
     Returns (out [B,N,256], saved tuple)."""
@@ -665,8 +693,11 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     qkv = qkv.view(B, N, 3 * D)
     o, r1, lse = attn_fwd(qkv, kv_len, res=z)
     r1_2 = r1.view(M, D)
-    h, xn2, st2, hsign = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
-    out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
+    if FUSED_FFN_FWD and z.dtype == torch.bfloat16 and M >= FUSED_FFN_MIN_ROWS:
+        out, h, xn2, st2, hsign = ffn_fwd(r1_2, g2, b2, w1c, c1, w2c, c2, drop_p=drop_p, seeds=seeds)
+    else:
+        h, xn2, st2, hsign = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
+        out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
     saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds, hsign)
     return out.view(B, N, D), saved
 

@@ -144,6 +144,29 @@ def test_ln_gemm_and_gemm_nt(ops, dt):
     check(f"gemm_nt[{str(dt)[6:]}].y", y.float(), yr, TOL[dt] if dt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("M", [300, 4990, 33000])
+def test_ffn_fwd_fused_equals_two_launches(ops, M):
+    """mtmp_ffn_fwd against mtmp_ln_gemm_signs + mtmp_gemm_nt on the same inputs and seeds: the same masks and roundings, so
+    h, xn, stats and the sign bits must agree bit for bit and out to the last bf16 ulp of a differently ordered fp32 sum."""
+    g = torch.Generator(device=DEV).manual_seed(M)
+    bf = torch.bfloat16
+    x = (torch.randn(M, 256, generator=g, device=DEV) * 2 + 0.3).to(bf)
+    gam, bet = 1 + 0.1 * torch.randn(256, generator=g, device=DEV), 0.1 * torch.randn(256, generator=g, device=DEV)
+    w1, b1 = (torch.randn(1024, 256, generator=g, device=DEV) / 16).to(bf), 0.1 * torch.randn(1024, generator=g, device=DEV)
+    w2, b2 = (torch.randn(256, 1024, generator=g, device=DEV) / 32).to(bf), 0.1 * torch.randn(256, generator=g, device=DEV)
+    for p_drop in (0.0, 0.1):
+        h0, xn0, st0, sg0 = ops.ln_gemm(x, gam, bet, w1, b1, 1024, relu=True, drop_p=p_drop, seed=11, want_signs=True)
+        out0 = ops.gemm_nt(h0, w2, b2, res2d=x, drop_p=p_drop, seed=12)
+        out1, h1, xn1, st1, sg1 = ops.ffn_fwd(x, gam, bet, w1, b1, w2, b2, drop_p=p_drop, seeds=(11, 12))
+        t = f"ffn_fwd[M={M},p={p_drop}]"
+        assert torch.equal(xn1, xn0) and torch.allclose(st1, st0, rtol=1e-6, atol=0), t
+        assert torch.equal(h1, h0), t + ": hidden activation"
+        assert torch.equal(sg1, sg0), t + ": sign bits"
+        check(t + ".out", out1.float(), out0.float(), 1e-2)
+        frac = (out1 != out0).float().mean().item()
+        assert frac < 0.05, f"{t}: {frac:.3f} of the outputs differ"
+
+
 def test_copy_batch(ops):
     g = torch.Generator(device=DEV).manual_seed(11)
     srcs = [torch.randn(n, generator=g, device=DEV) * 300 for n in (64 * 1000 * 3, 64, 7, 1, 4099)]
