@@ -672,6 +672,12 @@ class StreamInputFn(torch.autograd.Function):
 PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, c2
 
 
+# Order in which a layer's streams are issued (capture order = the order a replayed graph hands work to the hardware queues).
+# Measured inside one box (tools/dbg/ab_order.sh, ms/step): vital-sign stream first 9.23-9.37; text, image, vital-sign in the
+# backward only 9.38-9.39; side streams first both ways 9.51-9.65.
+STREAM_ISSUE_ORDER_FWD = (0, 1, 2)
+STREAM_ISSUE_ORDER_BWD = (0, 1, 2)
+
 # The FFN half of a layer as ONE launch (mtmp_ffn_fwd) instead of mtmp_ln_gemm_signs + mtmp_gemm_nt (bit-identical results).
 # Built, tested (tests/test_gpu_parity.py::test_ffn_fwd_fused_equals_two_launches), NOT routed: 137 us against 138-147 us back to
 # back, but 160 us per launch inside the step against ~128 us for the pair (main-queue kernel time of a profiled replay 7.60 vs
@@ -863,7 +869,7 @@ class FusionStackFn(torch.autograd.Function):
             if streams is not None and len(ms) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-            for m in ms:
+            for m in [q for q in STREAM_ISSUE_ORDER_FWD if q in ms]:
                 P = params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER]
                 if streams is not None and m > 0:
                     s = streams[m - 1]
@@ -944,7 +950,7 @@ class FusionStackFn(torch.autograd.Function):
             if streams is not None and len(ms) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-            for m in ms:
+            for m in [q for q in STREAM_ISSUE_ORDER_BWD if q in ms]:
                 sink = cfg["sinks"][li][m] if cfg.get("sinks") else None
                 if streams is not None and m > 0:
                     s = streams[m - 1]
