@@ -15,8 +15,11 @@ random-init weights.  Weak scaling: every rank runs its own batch of 64; gradien
 (ddp.GradReducer; under hipGraph replay the step is cut into 3 graphs and the buckets of one go out beside the next).
 
 Timing: W warm-up steps, then K steps bracketed by barrier + torch.cuda.synchronize(); every step ends in the
-reference's loss.item(), so per-step host times are exact step times.  ms_per_step is the MEDIAN of the K steps
-(MAX over ranks), value = global batch / that; the mean over the bracketed region is reported beside it.
+reference's loss hand-over (the trainer returns the step's loss as a Python float).  Under hipGraph replay that value leaves the
+device right behind the forward pass (GraphedTrainStep.publish_loss / wait_loss), so the host prepares and enqueues step k+1
+while step k's backward is still running: a single step's host time is no longer its device time, and ms_per_step is the
+bracketed region's wall time / K (MAX over ranks), value = global batch / that; the median of the per-step host times is
+reported beside it (ms_per_step_median_host).
 
 The JSON line also carries
   roofline      -- the dominant kernel (key-masked attention forward, vslt stream): algorithmic FLOPs 4*B*H*N^2*64 per
@@ -214,6 +217,18 @@ def main():
         return raw_item(self)
 
     torch.Tensor.item = timed_item
+    # graph-mode steps hand their loss over through GraphedTrainStep.wait_loss (no .item()): same stop-watch there
+    from medical_tri_modal_pilot_amd import graph as _graph
+    raw_wait = _graph.GraphedTrainStep.wait_loss
+
+    def timed_wait(self, *a_, **k_):
+        if enq["on"] and enq["t0"] > 0:
+            enq["sum"] += time.perf_counter() - enq["t0"]
+            enq["n"] += 1
+            enq["t0"] = 0.0
+        return raw_wait(self, *a_, **k_)
+
+    _graph.GraphedTrainStep.wait_loss = timed_wait
 
     def step(it):
         enq["t0"] = time.perf_counter()
@@ -239,6 +254,7 @@ def main():
     dt = time.perf_counter() - t0
     enq["on"] = False
     torch.Tensor.item = raw_item
+    _graph.GraphedTrainStep.wait_loss = raw_wait
     host_ms = 1e3 * enq["sum"] / max(1, enq["n"])
     med = statistics.median(per_step)
     gs = getattr(model, "_mtmp_graph_step", None)
@@ -305,9 +321,8 @@ def main():
             rocprof_us, rocprof_src = tj.get("rocprof_avg_us"), tj.get("rocprof_source")
         out = {
             "metric": "tri-modal training samples/s (fwd+bwd+AdamW step, per-GPU batch %d)" % B_PER_GPU,
-            "value": world * B_PER_GPU / med, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": 1e3 * med, "ms_per_step_mean": 1e3 * dt / a.steps,
-            "value_from_mean": world * B_PER_GPU * a.steps / dt,
+            "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_median_host": 1e3 * med,
             "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "graphs_per_step": n_graphs,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",

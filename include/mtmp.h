@@ -258,6 +258,11 @@ int mtmp_ffn_fwd(int dtype, const void* x, const float* gamma, const float* beta
                  const float* b2, void* out, void* h, void* xn, float* stats, void* signs, int M, int ldx, float eps, float drop_p,
                  unsigned seed1, unsigned seed2, const unsigned* seed_dev, void* stream);
 
+/* pair[0] <- bit pattern of *value (fp32), pair[1] += 1 (both uint32, device memory): a scalar and a sequence number published
+ * together.  The training step copies the pair to pinned host memory right behind its loss (2_train.py:76, trainer.py:128), so the
+ * reference's `loss.item()` hands the value over when the forward pass is done instead of when the whole step has drained. */
+int mtmp_publish_scalar(const float* value, unsigned* pair, void* stream);
+
 /* Up to 16 device-to-device copies in one launch: dst[i] <- src[i] (bytes[i] bytes, both 16-byte aligned); round16[i] != 0: the
  * buffer holds fp32 values and is written as float(half(x)) -- the fp16 round trip the reference applies to its event / time
  * inputs (trainer.py:26-27, 2_train.py:164).  All arrays are HOST arrays of n entries, read at launch time. */

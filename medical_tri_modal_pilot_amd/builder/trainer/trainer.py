@@ -113,6 +113,9 @@ def _staged_step(model, enc, optimizer, criterion, run_model, bounds):
         optimizer.zero_grad()
         step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
         carry["loss"] = step_loss.detach()
+        gs_ = getattr(model, "_mtmp_graph_step", None)
+        if gs_ is not None:
+            gs_.publish_loss(step_loss)
         bnds = carry["bnds"] = list(enc.segment_boundaries)
         if len(bnds) != n_stage - 1:          # the encoder did not cut (torch input chain, resbottle, ...): one backward
             carry["bnds"] = []
@@ -239,6 +242,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
             def fwd_bwd(t):
                 optimizer.zero_grad()
                 step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
+                gs.publish_loss(step_loss)           # the host takes the value from here (gs.wait_loss below)
                 step_loss.backward()
                 return step_loss.detach()
             loss = gs.run(inputs, fwd_bwd, optimizer.flat.params, reducer=red, round_fp16=deferred)
@@ -248,6 +252,10 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         optimizer.step()
         scheduler.step(iteration)
         logger.log_lr(scheduler.get_lr()[0], iteration)
+        # The reference's loss.item() (trainer.py:128), without waiting for the backward and the optimizer step that are still
+        # running: the value was copied to pinned memory right behind the forward pass.  What the caller enqueues next is
+        # stream-ordered behind this step as always; only the host no longer idles the GPU between two steps.
+        return model, gs.wait_loss()
     elif flow_type == "train":
         if red is not None:
             red.staged = False

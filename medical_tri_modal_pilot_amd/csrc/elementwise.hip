@@ -801,6 +801,19 @@ extern "C" int mtmp_stream_lengths(const long long* len_v, const long long* len_
     return MTMP_OK;
 }
 
+// pair[0] <- bits of *value, pair[1] += 1: a scalar (the step's loss) and a sequence number, published together so that the host
+// can take the value from pinned memory as soon as THIS point of the stream is reached (graph.py, GraphedTrainStep.publish_loss).
+__global__ void publish_scalar_kernel(const float* value, unsigned* pair) {
+    pair[0] = __float_as_uint(*value);
+    pair[1] = pair[1] + 1u;
+}
+extern "C" int mtmp_publish_scalar(const float* value, unsigned* pair, void* stream) {
+    MTMP_CHECK_ARG(value && pair, "mtmp_publish_scalar: null pointer");
+    hipLaunchKernelGGL(publish_scalar_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, value, pair);
+    MTMP_CHECK_LAUNCH("mtmp_publish_scalar");
+    return MTMP_OK;
+}
+
 // Diagnostic: one lane stores the 100 MHz wall clock into *slot.  Launched between the kernels of a step (also inside a
 // captured hipGraph, where HIP events cannot be timed) to get an un-profiled per-stream timeline (tools/dbg/timeline.py).
 __global__ void mark_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
