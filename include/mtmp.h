@@ -258,6 +258,16 @@ int mtmp_ffn_fwd(int dtype, const void* x, const float* gamma, const float* beta
                  const float* b2, void* out, void* h, void* xn, float* stats, void* signs, int M, int ldx, float eps, float drop_p,
                  unsigned seed1, unsigned seed2, const unsigned* seed_dev, void* stream);
 
+/* Deferred reductions: mtmp_gemm_tn with dw == NULL (and db == NULL) and mtmp_gemm_lnbwd with dgamma_dbeta == NULL leave their
+ * partial slabs in ws -- [mtmp_gemm_tn_slab_rows(dtype,M,N,K)][N K + N] and [mtmp_gemm_lnbwd_slab_rows(M)][512] floats -- and
+ * mtmp_reduce_batch sums up to 8 such slabs in ONE launch: out_a[i][c] = sum_r slab[i][r][c] for c < split[i], the remaining
+ * columns go to out_b[i] (may be NULL).  The gradient reductions of one encoder layer's backward (autograd of attention.py:60-62,
+ * module.py:74-78, :138-144): seven launches become one.  All arrays are HOST arrays of n entries. */
+int mtmp_gemm_tn_slab_rows(int dtype, int M, int N, int K);
+int mtmp_gemm_lnbwd_slab_rows(int M);
+int mtmp_reduce_batch(const float* const* slab, const int* rows, const long long* cols, float* const* out_a, const long long* split,
+                      float* const* out_b, int n, void* stream);
+
 /* pair[0] <- bit pattern of *value (fp32), pair[1] += 1 (both uint32, device memory): a scalar and a sequence number published
  * together.  The training step copies the pair to pinned host memory right behind its loss (2_train.py:76, trainer.py:128), so the
  * reference's `loss.item()` hands the value over when the forward pass is done instead of when the whole step has drained. */

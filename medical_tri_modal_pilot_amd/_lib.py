@@ -27,6 +27,9 @@ SIGNATURES = {
     "mtmp_gemm_nt_signs": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_void_p]),
     "mtmp_ln_linear_act": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_int, c_void_p]),
     "mtmp_ffn_fwd": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_float, c_float, c_uint, c_uint, c_void_p, c_void_p]),
+    "mtmp_gemm_tn_slab_rows": (c_int, [c_int] * 4),
+    "mtmp_gemm_lnbwd_slab_rows": (c_int, [c_int]),
+    "mtmp_reduce_batch": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),
     "mtmp_publish_scalar": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mtmp_copy_batch": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_stream_lengths": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),

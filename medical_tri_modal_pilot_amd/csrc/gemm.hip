@@ -1511,6 +1511,42 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, int s
     }
 }
 
+// Several slab reductions in ONE launch: out_e[c] = sum_r slab_e[r][c] for up to RB_MAX entries (blockIdx.y); columns below
+// split_e go to a_e, the rest to b_e (the weight / bias gradient of a split-M product share a slab row).  A layer's backward
+// produced seven of these reductions (3 weight gradients, 2 x 2 levels of LayerNorm gamma / beta partials): seven launches of
+// 5-13 us each on the vital-sign stream, and worse on the image / text streams, whose launches wait for a free CU.
+constexpr int RB_MAX = 8;
+struct ReduceBatch { const float* slab[RB_MAX]; float* a[RB_MAX]; float* b[RB_MAX]; long long cols[RB_MAX], split[RB_MAX]; int rows[RB_MAX]; };
+__global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch t) {
+    __shared__ float part[4][64];
+    const int e = blockIdx.y;
+    const long long cols = t.cols[e];
+    const int rows = t.rows[e], rl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const float* slab = t.slab[e];
+    for (long long c0 = (long long)blockIdx.x * 64; c0 < cols; c0 += (long long)gridDim.x * 64) {
+        const long long c = c0 + cl;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (c < cols) {
+            int q = rl;
+            for (; q + 12 < rows; q += 16) {                      // four independent loads in flight per row lane
+                s0 += slab[(size_t)q * cols + c];
+                s1 += slab[(size_t)(q + 4) * cols + c];
+                s2 += slab[(size_t)(q + 8) * cols + c];
+                s3 += slab[(size_t)(q + 12) * cols + c];
+            }
+            for (; q < rows; q += 4) s0 += slab[(size_t)q * cols + c];
+        }
+        __syncthreads();
+        part[rl][cl] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (rl == 0 && c < cols) {
+            const float s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+            if (c < t.split[e]) t.a[e][c] = s;
+            else if (t.b[e]) t.b[e][c - t.split[e]] = s;
+        }
+    }
+}
+
 int tn_splits(int M, int N, int K, int target_wgs) {
     const int tiles = (N / 128) * (K / 128);
     int s = target_wgs / tiles;
@@ -1769,18 +1805,25 @@ int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStr
     a.slab = ws;
     hipLaunchKernelGGL(gemm_lnbwd_kernel<T>, dim3(nb), dim3(256), sm, st, a);
     MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd");
+    if (!dgamma_dbeta) return MTMP_OK;                        // partials only: the caller reduces them (mtmp_reduce_batch)
     launch_slab_reduce(ws, nb, 512, ws + (size_t)nb * 512, dgamma_dbeta, st);
     MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd(reduce)");
     return MTMP_OK;
 }
 
+// partial slabs the launch writes (rows of the [splits][N K + N] workspace); two: bf16 kernel with two token groups
+int tn_launch_splits(bool tr, int M, int N, int K, bool* two_out) {
+    // two token groups per workgroup (half the partial slabs) once the split count is not what limits the grid
+    const bool two = tr && tn_splits(M, N, K, 256) * 8 * TK <= M;
+    if (two_out) *two_out = two;
+    return tn_splits(M, N, K, two ? 256 : (tr ? 512 : 640));
+}
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
                    hipStream_t st) {
     constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernel, eight waves per CU
-    // two token groups per workgroup (half the partial slabs) once the split count is not what limits the grid
-    const bool two = TR && tn_splits(M, N, K, 256) * 8 * TK <= M;
-    const int splits = tn_splits(M, N, K, two ? 256 : (TR ? 512 : 640));
+    bool two;
+    const int splits = tn_launch_splits(TR, M, N, K, &two);
     int rps = (M + splits - 1) / splits;
     rps = (rps + TK - 1) / TK * TK;
     TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
@@ -1798,6 +1841,7 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
         hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(256), sm, st, a);
     }
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn");
+    if (!dw) return MTMP_OK;                                  // partials only: the caller reduces them (mtmp_reduce_batch)
     const size_t nk = (size_t)N * K, cols = nk + N;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, ws, splits, cols, dw, db, nk);
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn(reduce)");
@@ -1933,7 +1977,7 @@ extern "C" int mtmp_gemm_lnbwd_ws_floats(int M) { return ((M + 127) / 128 + RED_
 extern "C" int mtmp_gemm_lnbwd(int dtype, const void* dy, const void* wt, const void* z, int ldz, const float* stats,
                                const float* gamma, const void* d_res, int ldr, void* dz, float* dgamma_dbeta, float* ws,
                                int M, int K, int ldy, float eps, void* stream) {
-    MTMP_CHECK_ARG(dy && wt && z && stats && gamma && dz && dgamma_dbeta && ws, "mtmp_gemm_lnbwd: null pointer");
+    MTMP_CHECK_ARG(dy && wt && z && stats && gamma && dz && ws, "mtmp_gemm_lnbwd: null pointer");
     MTMP_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0 && ldy >= K && ldy % 8 == 0 && ldz >= 256 && ldz % 4 == 0 &&
                        (!d_res || (ldr >= 256 && ldr % 4 == 0)), "mtmp_gemm_lnbwd: bad shape M=%d K=%d ldy=%d ldz=%d", M, K, ldy, ldz);
     hipStream_t st = (hipStream_t)stream;
@@ -1951,6 +1995,30 @@ extern "C" int mtmp_gemm_lnbwd(int dtype, const void* dy, const void* wt, const 
     return MTMP_ERR_ARG;
 }
 
+// Deferred reductions.  mtmp_gemm_tn with dw == NULL and mtmp_gemm_lnbwd with dgamma_dbeta == NULL leave their partial slabs in
+// ws -- [mtmp_gemm_tn_slab_rows][N K + N] and [mtmp_gemm_lnbwd_slab_rows][512] floats -- and mtmp_reduce_batch sums up to 8 such
+// slabs in one launch: out_a[i][c] = sum_r slab[i][r][c] for c < split[i], out_b[i][c - split[i]] for the rest (out_b[i] may be
+// NULL).  All arrays are HOST arrays of n entries.
+extern "C" int mtmp_gemm_tn_slab_rows(int dtype, int M, int N, int K) { return tn_launch_splits(dtype == 1, M, N, K, nullptr); }
+extern "C" int mtmp_gemm_lnbwd_slab_rows(int M) { return (M + 127) / 128; }
+extern "C" int mtmp_reduce_batch(const float* const* slab, const int* rows, const long long* cols, float* const* out_a,
+                                 const long long* split, float* const* out_b, int n, void* stream) {
+    MTMP_CHECK_ARG(slab && rows && cols && out_a && split && out_b && n > 0 && n <= RB_MAX, "mtmp_reduce_batch: bad argument (n=%d)", n);
+    ReduceBatch t;
+    long long most = 0;
+    for (int i = 0; i < RB_MAX; ++i) {
+        const int k = i < n ? i : 0;
+        MTMP_CHECK_ARG(slab[k] && out_a[k] && rows[k] > 0 && cols[k] > 0 && split[k] >= 0 && split[k] <= cols[k] &&
+                           (split[k] == cols[k] || out_b[k] || true), "mtmp_reduce_batch: bad entry %d", k);
+        t.slab[i] = slab[k]; t.a[i] = out_a[k]; t.b[i] = out_b[k]; t.cols[i] = cols[k]; t.split[i] = split[k]; t.rows[i] = rows[k];
+        most = most > cols[k] ? most : cols[k];
+    }
+    const long long blocks = (most + 63) / 64;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), n), dim3(256), 0, (hipStream_t)stream, t);
+    MTMP_CHECK_LAUNCH("mtmp_reduce_batch");
+    return MTMP_OK;
+}
+
 extern "C" long long mtmp_gemm_tn_ws_floats(int M, int N, int K) {
     return (long long)tn_splits(M, N, K, 640) * ((long long)N * K + N);   // upper bound over both dtypes' split counts
 }
@@ -1960,7 +2028,7 @@ extern "C" long long mtmp_gemm_tn_ws_floats(int M, int N, int K) {
 // k=1 Conv1d layers of attention.py:60-62 and module.py:74-78.
 extern "C" int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N,
                             int K, int ldy, int ldx, void* stream) {
-    MTMP_CHECK_ARG(dy && x && dw && ws, "mtmp_gemm_tn: null pointer");
+    MTMP_CHECK_ARG(dy && x && ws && (dw || !db), "mtmp_gemm_tn: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && ldy >= N && ldx >= K && ldy % 8 == 0 &&
                        ldx % 8 == 0, "mtmp_gemm_tn: bad shape M=%d N=%d K=%d ldy=%d ldx=%d", M, N, K, ldy, ldx);
     hipStream_t st = (hipStream_t)stream;

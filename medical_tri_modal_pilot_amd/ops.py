@@ -288,9 +288,15 @@ def swin_window_attn(qkv, table, heads, shift):
     return out
 
 
-def gemm_tn(dy2d, x2d, want_bias=True, out=None):
+REDUCE_BATCH_MAX = 8
+DEFER_REDUCTIONS = True        # layer_backward: one mtmp_reduce_batch per layer and stream instead of seven reduction launches
+
+
+def gemm_tn(dy2d, x2d, want_bias=True, out=None, defer=None):
     """(dW[N,K], db[N] | None) in fp32: dW = dy^T x, db = column sums of dy (split over the M tokens).
-    out=(dw, db): write into these fp32 buffers (slices of the flat gradient) instead of allocating."""
+    out=(dw, db): write into these fp32 buffers (slices of the flat gradient) instead of allocating.
+    defer: a list -- the split-M partials are left in the workspace and the reduction is appended to it; dW / db hold the result
+    only after reduce_batch(defer) (one launch for all of a layer's reductions)."""
     _gpu(dy2d, x2d)
     M, N = dy2d.shape
     K = x2d.shape[1]
@@ -300,9 +306,25 @@ def gemm_tn(dy2d, x2d, want_bias=True, out=None):
         dw = torch.empty(N, K, dtype=torch.float32, device=dy2d.device)
         db = torch.empty(N, dtype=torch.float32, device=dy2d.device) if want_bias else None
     ws = torch.empty(_lib.lib().mtmp_gemm_tn_ws_floats(M, N, K), dtype=torch.float32, device=dy2d.device)
+    if defer is not None:
+        call("mtmp_gemm_tn", _dt(dy2d), _p(dy2d), _p(x2d), None, None, _p(ws), M, N, K, dy2d.stride(0), x2d.stride(0), _stream())
+        defer.append((ws, _lib.lib().mtmp_gemm_tn_slab_rows(_dt(dy2d), M, N, K), N * K + N, dw, N * K, db))
+        return dw, db
     call("mtmp_gemm_tn", _dt(dy2d), _p(dy2d), _p(x2d), _p(dw), _p(db), _p(ws), M, N, K, dy2d.stride(0),
          x2d.stride(0), _stream())
     return dw, db
+
+
+def reduce_batch(pending):
+    """The deferred reductions of gemm_tn / gemm_lnbwd (entries (slab, rows, cols, out_a, split, out_b)), eight per launch."""
+    for i in range(0, len(pending), REDUCE_BATCH_MAX):
+        ch = pending[i:i + REDUCE_BATCH_MAX]
+        n = len(ch)
+        PV, IV, LV = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
+        call("mtmp_reduce_batch", PV(*[e[0].data_ptr() for e in ch]), IV(*[e[1] for e in ch]), LV(*[e[2] for e in ch]),
+             PV(*[e[3].data_ptr() for e in ch]), LV(*[e[4] for e in ch]),
+             PV(*[None if e[5] is None else e[5].data_ptr() for e in ch]), n, _stream())
+    del pending[:]
 
 
 def attn_fwd(qkv, kv_len, res=None):
@@ -344,17 +366,20 @@ def ln_bwd(z2d, stats, gamma, dy2d, d_res2d=None, gb_out=None):
     return dz, gb[:D_MODEL], gb[D_MODEL:]
 
 
-def gemm_lnbwd(dy2d, wt, z2d, stats, gamma, d_res2d=None, gb_out=None):
+def gemm_lnbwd(dy2d, wt, z2d, stats, gamma, d_res2d=None, gb_out=None, defer=None):
     """-> (dz[M,256], dgamma[256], dbeta[256]): dz = LNbackward(dy wt^T; z, stats, gamma) (+ d_res) in ONE launch
     (mtmp_gemm_lnbwd: the dX GEMM of the LayerNorm-fed projection with the LayerNorm backward as its epilogue).
-    dy2d [M,K]; wt [256,K] = W^T of the projection; gb_out: fp32[512] destination for (dgamma | dbeta)."""
+    dy2d [M,K]; wt [256,K] = W^T of the projection; gb_out: fp32[512] destination for (dgamma | dbeta); defer: as gemm_tn."""
     _gpu(dy2d, wt, z2d)
     M, K = dy2d.shape
     dz = torch.empty(M, D_MODEL, dtype=z2d.dtype, device=z2d.device)
     gb = gb_out if gb_out is not None else torch.empty(2 * D_MODEL, dtype=torch.float32, device=z2d.device)
     ws = torch.empty(_lib.lib().mtmp_gemm_lnbwd_ws_floats(M), dtype=torch.float32, device=z2d.device)
     call("mtmp_gemm_lnbwd", _dt(z2d), _p(dy2d), _p(wt), _p(z2d), z2d.stride(0), _p(stats), _p(gamma), _p(d_res2d),
-         0 if d_res2d is None else d_res2d.stride(0), _p(dz), _p(gb), _p(ws), M, K, dy2d.stride(0), LN_EPS, _stream())
+         0 if d_res2d is None else d_res2d.stride(0), _p(dz), None if defer is not None else _p(gb), _p(ws), M, K, dy2d.stride(0),
+         LN_EPS, _stream())
+    if defer is not None:
+        defer.append((ws, _lib.lib().mtmp_gemm_lnbwd_slab_rows(M), 2 * D_MODEL, gb, 2 * D_MODEL, None))
     return dz, gb[:D_MODEL], gb[D_MODEL:]
 
 
@@ -746,20 +771,23 @@ def layer_backward(saved, d_out, sink=None):
     # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
     dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
     direct = sink is not None and sink.usable()
-    dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None)       # [256,1024], [256]
+    red = [] if DEFER_REDUCTIONS else None        # this layer's seven gradient reductions, issued as ONE launch at the end
+    dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None, defer=red)       # [256,1024], [256]
     # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue: from the forward's sign bits
     # (bf16: M N / 8 bytes of gate instead of re-reading h) or, in the fp32 build, from h itself
     if hsign is not None:
         dh = gemm_nt_signs(dy2, w2t, hsign, 1.0 / (1.0 - p))
     else:
         dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
-    dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None)      # [1024,256], [1024]
+    dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None, defer=red)      # [1024,256], [1024]
     # dXn2 = dH W1 and the backward of LN2 (+ the residual gradient) in one launch; the M x 256 product stays in LDS
-    dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D), st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None)
+    dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D), st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None, defer=red)
     # ---- attention: r1 = z + o  ->  d_o = dr1
     dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
-    dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None)   # [768,256], [768]
-    dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z.view(M, D), st1, g1, d_res2d=dr1, gb_out=sink.gb1 if direct else None)
+    dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None, defer=red)   # [768,256], [768]
+    dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z.view(M, D), st1, g1, d_res2d=dr1, gb_out=sink.gb1 if direct else None, defer=red)
+    if red:
+        reduce_batch(red)
     if direct:
         sink.flat.mark_ready(sink.idx)
         return dz.view(B, N, D), None

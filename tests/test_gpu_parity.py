@@ -167,6 +167,32 @@ def test_ffn_fwd_fused_equals_two_launches(ops, M):
         assert frac < 0.05, f"{t}: {frac:.3f} of the outputs differ"
 
 
+def test_reduce_batch_deferred_gradient_reductions(ops):
+    """gemm_tn / gemm_lnbwd with their reductions deferred into ONE mtmp_reduce_batch launch against the immediate form."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    bf = torch.bfloat16
+    for M in (3456, 20033, 64320):
+        dy = torch.randn(M, 768, generator=g, device=DEV).to(bf)
+        x = torch.randn(M, 256, generator=g, device=DEV).to(bf)
+        dh = torch.randn(M, 1024, generator=g, device=DEV).to(bf)
+        z = (torch.randn(M, 256, generator=g, device=DEV) * 2).to(bf)
+        gam = 1 + 0.1 * torch.randn(256, generator=g, device=DEV)
+        st = torch.stack([z.float().mean(-1), 1 / (z.float().std(-1) + 1e-6)], 1).contiguous()
+        w1t = (torch.randn(256, 1024, generator=g, device=DEV) / 32).to(bf)
+        dw0, db0 = ops.gemm_tn(dy, x)
+        dv0, _ = ops.gemm_tn(dh, x, want_bias=False)
+        dz0, dg0, dbt0 = ops.gemm_lnbwd(dh, w1t, z, st, gam)
+        red = []
+        dw1, db1 = ops.gemm_tn(dy, x, defer=red)
+        dv1, _ = ops.gemm_tn(dh, x, want_bias=False, defer=red)
+        dz1, dg1, dbt1 = ops.gemm_lnbwd(dh, w1t, z, st, gam, defer=red)
+        assert len(red) == 3
+        ops.reduce_batch(red)
+        assert red == [] and torch.equal(dz1, dz0)
+        for name, a, b in (("dw", dw1, dw0), ("db", db1, db0), ("dv", dv1, dv0), ("dgamma", dg1, dg0), ("dbeta", dbt1, dbt0)):
+            check(f"reduce_batch[M={M}].{name}", a, b, 1e-5)
+
+
 def test_copy_batch(ops):
     g = torch.Generator(device=DEV).manual_seed(11)
     srcs = [torch.randn(n, generator=g, device=DEV) * 300 for n in (64 * 1000 * 3, 64, 7, 1, 4099)]
