@@ -289,6 +289,7 @@ def swin_window_attn(qkv, table, heads, shift):
 
 
 REDUCE_BATCH_MAX = 8
+LATE_REDUCTIONS = True         # FusionStackFn.backward: that launch goes out behind the NEXT bottleneck exchange
 DEFER_REDUCTIONS = True        # layer_backward: one mtmp_reduce_batch per layer and stream instead of seven reduction launches
 
 
@@ -760,8 +761,9 @@ class GradSink:
         return self.ok and self.flat.claim(self.idx)
 
 
-def layer_backward(saved, d_out, sink=None):
-    """d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
+def layer_backward(saved, d_out, sink=None, late=None):
+    """late: a list -- the layer's reduction launch is not issued here but handed back through it (see the end of this function).
+    d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
     in PARAMS order; weights as 2-D [out,in])) -- or (dz, None) when the gradients went straight into
     the flat gradient buffer through `sink`."""
     z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds, hsign = saved
@@ -786,10 +788,16 @@ def layer_backward(saved, d_out, sink=None):
     dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
     dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None, defer=red)   # [768,256], [768]
     dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z.view(M, D), st1, g1, d_res2d=dr1, gb_out=sink.gb1 if direct else None, defer=red)
-    if red:
-        reduce_batch(red)
+    if late is not None and red:
+        # the caller issues this layer's reduction (and marks the gradients ready) later on this stream -- behind the next
+        # bottleneck exchange, which needs dz but none of the parameter gradients (FusionStackFn.backward)
+        late.append((red, sink if direct else None))
+    else:
+        if red:
+            reduce_batch(red)
+        if direct:
+            sink.flat.mark_ready(sink.idx)
     if direct:
-        sink.flat.mark_ready(sink.idx)
         return dz.view(B, N, D), None
     grads = (dg1, db1, dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
              dg2, db2, dw1, dc1, dw2, dc2)
@@ -965,6 +973,17 @@ class FusionStackFn(torch.autograd.Function):
             dz[0][:, NB, :] += d_cls.to(dt)
         pgrads = [None] * len(pshapes)
         d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
+        # A layer's gradient reductions (one mtmp_reduce_batch launch per stream) are issued one layer LATE, on the same stream:
+        # the bottleneck exchange in between needs the streams' dz but none of their parameter gradients, and it is the image /
+        # text streams' last launches that the vital-sign stream waits for there.
+        late = [[], [], []]
+
+        def flush_late(m):
+            for red, sk in late[m]:
+                reduce_batch(red)
+                if sk is not None:
+                    sk.flat.mark_ready(sk.idx)
+            del late[m][:]
         for li in range(n_run - 1, -1, -1):
             ms = active[li]
             if not ((final and (cfg["vsltonly"] == 1 or cfg.get("first_only")) and li == L - 1)
@@ -985,11 +1004,13 @@ class FusionStackFn(torch.autograd.Function):
                     s.wait_event(ev)
                     with torch.cuda.stream(s):
                         mark(f"b{li}.m{m}.s")
-                        nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
+                        flush_late(m)                   # the layer above's reductions: behind this layer's exchange
+                        nxt[m], g = layer_backward(saved[li][m], dz[m], sink, late=late[m] if LATE_REDUCTIONS else None)
                         mark(f"b{li}.m{m}.e")
                 else:
                     mark(f"b{li}.m{m}.s")
-                    nxt[m], g = layer_backward(saved[li][m], dz[m], sink)
+                    flush_late(m)
+                    nxt[m], g = layer_backward(saved[li][m], dz[m], sink, late=late[m] if LATE_REDUCTIONS else None)
                     mark(f"b{li}.m{m}.e")
                 base = (li * n_s + m) * PARAMS_PER_LAYER
                 if g is not None:
@@ -1004,6 +1025,14 @@ class FusionStackFn(torch.autograd.Function):
                 for m in range(1, n_s):
                     nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
             dz = nxt
+        for m in range(3):                  # the first layer's reductions
+            if late[m]:
+                if streams is not None and m > 0:
+                    with torch.cuda.stream(streams[m - 1]):
+                        flush_late(m)
+                    cur.wait_stream(streams[m - 1])
+                else:
+                    flush_late(m)
         if cfg.get("prebuilt"):            # the bottleneck rows' gradient flows on through the stream-input nodes
             d_bott = None if d_prev_bott is None else d_prev_bott.sum(0, keepdim=True)
             return (dz[0], dz[1], dz[2], d_bott, *pgrads, None)
