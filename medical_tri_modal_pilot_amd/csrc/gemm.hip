@@ -1430,21 +1430,40 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
         tr_fetch(y0, p.dy, p.ldy, mg + 2 * ST, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, mg + 2 * ST, m_end, k0, tid);
     }
     __syncthreads();
+    // (ablation builds, tools/dbg/ablate_tn.sh: results are wrong by design, only the timing is read)
+#ifdef MTMP_TN_NOMMA
+#define TN_MMA(...)
+#else
+#define TN_MMA(...) tr_mma(__VA_ARGS__)
+#endif
+#ifdef MTMP_TN_NOCOMMIT
+#define TN_COMMIT(...)
+#else
+#define TN_COMMIT(...) tr_commit(__VA_ARGS__)
+#endif
+#ifdef MTMP_TN_NOFETCH
+#define TN_FETCH(...)
+#else
+#define TN_FETCH(...) tr_fetch(__VA_ARGS__)
+#endif
     for (int s = 0; s < nsteps; s += 2) {
         // even step: multiply stage 0, stage 1 <- registers y1/x1 (step s+1), refill them with step s+3
-        tr_mma(acc, sm, sm + MAT, wn, wk, lane);
-        tr_commit(sm + STAGE, y1, tid); tr_commit(sm + STAGE + MAT, x1, tid);
+        TN_MMA(acc, sm, sm + MAT, wn, wk, lane);
+        TN_COMMIT(sm + STAGE, y1, tid); TN_COMMIT(sm + STAGE + MAT, x1, tid);
         if (bias_blk) tr_csum(csum, y1);
-        tr_fetch(y1, p.dy, p.ldy, mg + (s + 3) * ST, m_end, n0, tid); tr_fetch(x1, p.x, p.ldx, mg + (s + 3) * ST, m_end, k0, tid);
+        TN_FETCH(y1, p.dy, p.ldy, mg + (s + 3) * ST, m_end, n0, tid); TN_FETCH(x1, p.x, p.ldx, mg + (s + 3) * ST, m_end, k0, tid);
         __syncthreads();
         if (s + 1 >= nsteps) break;
         // odd step: multiply stage 1, stage 0 <- y0/x0 (step s+2), refill with step s+4
-        tr_mma(acc, sm + STAGE, sm + STAGE + MAT, wn, wk, lane);
-        tr_commit(sm, y0, tid); tr_commit(sm + MAT, x0, tid);
+        TN_MMA(acc, sm + STAGE, sm + STAGE + MAT, wn, wk, lane);
+        TN_COMMIT(sm, y0, tid); TN_COMMIT(sm + MAT, x0, tid);
         if (bias_blk) tr_csum(csum, y0);
-        tr_fetch(y0, p.dy, p.ldy, mg + (s + 4) * ST, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, mg + (s + 4) * ST, m_end, k0, tid);
+        TN_FETCH(y0, p.dy, p.ldy, mg + (s + 4) * ST, m_end, n0, tid); TN_FETCH(x0, p.x, p.ldx, mg + (s + 4) * ST, m_end, k0, tid);
         __syncthreads();
     }
+#undef TN_MMA
+#undef TN_COMMIT
+#undef TN_FETCH
     if constexpr (NG == 2) {
         // group 1 -> LDS [64 accumulator registers][256 threads] (64 KiB, over the dead tiles) -> group 0 adds
         float* xch = reinterpret_cast<float*>(smem_raw);
@@ -1491,6 +1510,237 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
             out[(size_t)p.N * p.K + n0 + threadIdx.x] = sum;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Large-M form of the product above: tiles by LDS-DMA (global_load_lds_dwordx4), loader waves and matrix waves, 128 x 256 output
+// tile per workgroup.
+// What bounded gemm_tn_tr_kernel<2> at config 2 (tools/dbg/ablate_tn.sh, tools/dbg/stamp_tn.py, tools/dbg/pmc_tn.sh; 48 us + 5.5 us
+// of reduce): every wave ran the same sequence -- fetch, ds_write_b128 commit (a 64 KiB step costs ~830 LDS cycles), 16 MFMAs --
+// between two barriers, and each of those blocks the in-order wave while it queues, so a step cost the SUM of its parts (~4000
+// cycles against 1024 of MFMA; matrix pipe 28 % busy, no LDS bank conflicts, clock 2.1 GHz) and removing any one part removed
+// only that part.  A first DMA version with eight identical waves (no commits, five stages in flight) ran at exactly the same
+// speed: the waves stood ~500 cycles per stage in the DMA issue queue with the matrix pipe idle.  And with 128 x 128 tiles the
+// launch moves 396 MB from L2 into the CUs (dY twice, X six times at N = 768), which alone takes 28 us (~14 TB/s, about what
+// LDS-DMA from L2 delivers).
+// Here the roles are split: waves 0-3 (one per SIMD) read fragments and issue MFMAs (64 x 128 of the 128 x 256 tile each, over
+// ALL tokens of a stage: one partial slab per workgroup, no accumulator hand-over; 297 MB from L2), waves 4-7 (their SIMD
+// partners) only issue DMA and wait for it.  A stage is 64 tokens (dY | X[:, 0:128] | X[:, 128:256] tiles of [64][128], unpadded
+// 256-byte rows whose 64-byte blocks are XOR-ed with row & 3 on the SOURCE side -- what makes the 4-rows-by-64-bytes
+// footprint of a ds_read_b64_tr_b16 lane group conflict-free), three stages, one barrier per stage.  Token tail: rows past
+// m_end are fetched from the clamped last row and the dY rows are zeroed in LDS (one stage per launch).  The bias gradient
+// (column sums of dY) rides on the matrix pipe: dY^T x ones for one 32-column block per matrix wave (+12 % MFMAs; from LDS with
+// vector adds it cost 7 us of the launch wherever it was placed).
+constexpr int DT = 64, DNS = 3;                            // tokens per stage; stages
+constexpr int DTILE = DT * 256, DSTAGE = 3 * DTILE;        // bytes: one [DT][128] bf16 tile; a stage = dY | X lo | X hi
+constexpr int DPW = 12;                                    // DMA pieces per loader wave and stage
+MTMP_DEV Frag<bf16> frag_tr_at(const char* a) {            // lane's 8-byte piece in token rows r and r + 4 of a 256-byte-row image
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * 256));
+    Frag<bf16> f;
+    f.v = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+    return f;
+}
+template <int N> MTMP_DEV void tn_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+MTMP_DEV void tn_wait_stages(int k) {                      // all but the last k stages (DPW pieces each) of this wave have landed
+    if (k >= 2) tn_wait<2 * DPW>();
+    else if (k == 1) tn_wait<DPW>();
+    else tn_wait<0>();
+}
+struct TnChunk { Frag<bf16> a[2], b[4]; };
+#ifdef MTMP_TND_NOBAR                                        // (ablation build: no stage barriers, results wrong)
+#define TND_BARRIER()
+#else
+#define TND_BARRIER() __syncthreads()
+#endif
+__global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
+    const int tid = threadIdx.x & 255, lane = tid & 63, r = lane & 31, half = lane >> 5;
+    const bool loader = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = p.N / 128, tk = p.K / 256;
+    int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = w / (tn * tk);
+    w -= split * tn * tk;
+    const int kt = w % tk, n0 = (w / tk) * 128, k0 = kt * 256;
+    const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
+    const int wn = (wave >> 1) * 64, xt = wave & 1;        // matrix wave: dY columns wn .. wn + 63, X tile xt (128 columns)
+    const int nst = m_end > m_lo ? (m_end - m_lo + DT - 1) / DT : 0;
+    // ---- loader wave `wave`: rows 16 wave .. 16 wave + 15 of the three tiles (four 1 KiB pieces each)
+    const int lr = lane >> 4, lc = (lane & 15) ^ (4 * lr);           // row inside a piece; logical 16-byte chunk this lane fetches
+    const unsigned ycol = (unsigned)(n0 * 2 + lc * 16), xcol = (unsigned)(k0 * 2 + lc * 16);
+    const unsigned ldyb = (unsigned)p.ldy * 2u, ldxb = (unsigned)p.ldx * 2u;
+    auto issue = [&](int st_) {
+#ifdef MTMP_TND_NODMA                                       // (ablation builds, tools/dbg/ablate_tn.sh: timing only, results wrong)
+        return;
+#endif
+        const unsigned dst = lds0 + (unsigned)((st_ % DNS) * DSTAGE + wave * 4096);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned row = (unsigned)min(m_lo + st_ * DT + 16 * wave + 4 * q + lr, m_end - 1);
+            dma16(row * ldyb + ycol, p.dy, dst + q * 1024);
+            dma16(row * ldxb + xcol, p.x, dst + DTILE + q * 1024);
+            dma16(row * ldxb + xcol + 256, p.x, dst + 2 * DTILE + q * 1024);
+        }
+    };
+    // ---- matrix wave: lane (G = lane >> 4, i = lane & 15) reads token rows 8 (G >> 1) + (i >> 2) (+ 4), bytes 32 (G & 1) + 8 (i & 3)
+    const int G = lane >> 4, i16 = lane & 15, sw = 4 * (i16 >> 2);
+    const int rowoff = (8 * (G >> 1) + (i16 >> 2)) * 256 + 32 * (G & 1) + 8 * (i16 & 3);
+    const int aoff0 = rowoff + 16 * ((wn >> 3) ^ sw), aoff1 = rowoff + 16 * (((wn + 32) >> 3) ^ sw);
+    const int xbase = DTILE * (1 + xt) + rowoff;
+    const int boff0 = xbase + 16 * (0 ^ sw), boff1 = xbase + 16 * (4 ^ sw), boff2 = xbase + 16 * (8 ^ sw), boff3 = xbase + 16 * (12 ^ sw);
+    f32x16 acc[2][4] = {{{0}, {0}, {0}, {0}}, {{0}, {0}, {0}, {0}}};
+    // bias gradient (column sums of dY) on the matrix pipe: dY^T x ones for ONE 32-column block of the tile per matrix wave.
+    // Block b = 2 (wn / 64) + ai belongs to K tile b mod min(tk, 4), so the K tiles share the 128 columns.  With one K tile the
+    // two waves of a column half take one block each (ai = xt) over all k-chunks; otherwise they split the chunks of their one
+    // block (xt = 0: chunks 0, 1; xt = 1: chunks 2, 3).
+    const int tkp = min(tk, 4), b0 = 2 * (wn >> 6);
+    const bool own0 = b0 % tkp == kt, own1 = (b0 + 1) % tkp == kt;
+    const int cs_ai = (own0 && own1) ? xt : own0 ? 0 : own1 ? 1 : -1;
+    const bool cs_hi = cs_ai == 1;
+    const bool cs_c01 = cs_ai >= 0 && ((own0 && own1) || xt == 0), cs_c23 = cs_ai >= 0 && ((own0 && own1) || xt == 1);
+    Frag<bf16> ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones.v[j] = (bf16)1.0f;
+    f32x16 acc_cs = {0};
+    auto chunk = [&](int st_, int c) {
+        const char* sb = smem_raw + (st_ % DNS) * DSTAGE + c * 4096;
+        TnChunk f;
+#ifdef MTMP_TND_MMAONLY
+        f.a[0] = f.a[1] = f.b[0] = f.b[1] = f.b[2] = f.b[3] = frag_zero<bf16>();
+        asm volatile("" : "+v"(f.a[0].v), "+v"(f.a[1].v), "+v"(f.b[0].v), "+v"(f.b[1].v), "+v"(f.b[2].v), "+v"(f.b[3].v));
+#elif !defined(MTMP_TND_NOREAD)
+        f.a[0] = frag_tr_at(sb + aoff0); f.b[0] = frag_tr_at(sb + boff0); f.b[1] = frag_tr_at(sb + boff1);
+        f.b[2] = frag_tr_at(sb + boff2); f.b[3] = frag_tr_at(sb + boff3); f.a[1] = frag_tr_at(sb + aoff1);
+#endif
+        return f;
+    };
+    auto mma8 = [&](const TnChunk& f, bool with_cs) {
+#if !defined(MTMP_TND_NOMMA) && !defined(MTMP_TND_NOREAD)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma<bf16>(acc[i][j], f.a[i], f.b[j]);
+#ifndef MTMP_TND_NOCSUM
+        if (with_cs) {
+            Frag<bf16> a;
+            a.v = cs_hi ? f.a[1].v : f.a[0].v;
+            mma<bf16>(acc_cs, a, ones);
+        }
+#endif
+#endif
+    };
+    // stage st_ has landed for every wave (barrier passed): in a tail stage zero the dY rows past m_end (their products and
+    // their column sums vanish), then one more barrier (every thread: row = t >> 3, 32 bytes)
+    auto fix_tail = [&](int st_) {
+        if (st_ < nst && m_lo + (st_ + 1) * DT > m_end) {
+            const int row = (int)threadIdx.x >> 3;
+            if (m_lo + st_ * DT + row >= m_end) {
+                char* d = smem_raw + (st_ % DNS) * DSTAGE + row * 256 + ((int)threadIdx.x & 7) * 32;
+                *reinterpret_cast<u32x4_t*>(d) = u32x4_t{0, 0, 0, 0};
+                *reinterpret_cast<u32x4_t*>(d + 16) = u32x4_t{0, 0, 0, 0};
+            }
+            __syncthreads();
+        }
+    };
+#ifdef MTMP_STAMP
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ta = 0, ta2 = 0, ta3 = 0, tb = 0, s_wait = 0, s_bar = 0, s_work = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    TSTAMP(ts0)
+    // Barrier B(s) publishes stage s (the loaders waited for their pieces of it) and tells the loaders that the matrix waves
+    // are done reading stage s-1, whose buffer takes stage s+DNS-1.  Two loops, one per role, executing the same barriers (no
+    // MFMA shares a control-flow merge with loader code).
+    if (loader) {
+        const int pre = min(nst, DNS);
+        for (int s = 0; s < pre; ++s) issue(s);
+        TSTAMP(ts1)
+        for (int s = 0; s < nst; ++s) {
+            TSTAMP(ta)
+            tn_wait_stages(min(nst - 1, max(DNS - 1, s + DNS - 2)) - s);
+            TSTAMP(ta2)
+            TND_BARRIER();                                 // B(s)
+            TSTAMP(ta3)
+            fix_tail(s);
+            if (s >= 1 && s + DNS - 1 < nst) issue(s + DNS - 1);
+            TSTAMP(tb)
+#ifdef MTMP_STAMP
+            s_wait += ta2 - ta; s_bar += ta3 - ta2; s_work += tb - ta3;
+#endif
+        }
+    } else {
+        TSTAMP(ts1)
+        // one stage: each k-chunk's fragments requested one chunk (8 MFMAs) ahead of its MFMAs (pinned in this order)
+        for (int s = 0; s < nst; ++s) {
+            TSTAMP(ta)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TSTAMP(ta2)
+            TND_BARRIER();                                 // B(s)
+            TSTAMP(ta3)
+            fix_tail(s);
+            const TnChunk f0 = chunk(s, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const TnChunk f1 = chunk(s, 1);
+            mma8(f0, cs_c01);
+            __builtin_amdgcn_sched_barrier(0);
+            const TnChunk f2 = chunk(s, 2);
+            mma8(f1, cs_c01);
+            __builtin_amdgcn_sched_barrier(0);
+            const TnChunk f3 = chunk(s, 3);
+            mma8(f2, cs_c23);
+            __builtin_amdgcn_sched_barrier(0);
+            mma8(f3, cs_c23);
+            TSTAMP(tb)
+#ifdef MTMP_STAMP
+            s_wait += ta2 - ta; s_bar += ta3 - ta2; s_work += tb - ta3;
+#endif
+        }
+    }
+    TSTAMP(ts2)
+    float* red = reinterpret_cast<float*>(smem_raw);       // [2][128 columns] over the dead tiles
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 256) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    if (!loader && cs_ai >= 0 && r == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) red[xt * 128 + wn + 32 * cs_ai + acc_row(t, half)] = acc_cs[t];
+    }
+    __syncthreads();
+    float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
+    if (!loader) {
+#ifdef MTMP_TND_NOSTORE                                     // (ablation build: one store per lane keeps the accumulators alive)
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) keep += acc[i][j][t];
+        out[(size_t)(n0 + wn + acc_row(0, half)) * p.K + k0 + 128 * xt + r] = keep;
+#else
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + 128 * xt + 32 * j + r] = acc[i][j][t];
+#endif
+    } else if (tid < 128 && (tid >> 5) % tkp == kt) {
+        out[(size_t)p.N * p.K + n0 + tid] = red[tid] + red[128 + tid];
+    }
+#ifdef MTMP_STAMP
+    TSTAMP(ts3)
+    if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < 128) {
+        unsigned long long* o = g_stamp_lng + 16 * blockIdx.x + 8 * (threadIdx.x >> 8);
+        o[0] = ts1 - ts0; o[1] = s_wait; o[2] = s_work; o[3] = __builtin_amdgcn_s_memrealtime() - rt0; o[4] = ts3 - ts2; o[5] = ts3 - ts0; o[6] = s_bar; o[7] = nst;
+    }
+#endif
 }
 
 // out[c] = sum_s slab[s][c]; a block owns 64 columns, 4 row-lanes reduce through LDS
@@ -1811,31 +2061,49 @@ int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStr
     return MTMP_OK;
 }
 
-// partial slabs the launch writes (rows of the [splits][N K + N] workspace); two: bf16 kernel with two token groups
-int tn_launch_splits(bool tr, int M, int N, int K, bool* two_out) {
-    // two token groups per workgroup (half the partial slabs) once the split count is not what limits the grid
+// partial slabs the launch writes (rows of the [splits][N K + N] workspace) -- a function of the shape only, the deferred
+// reductions ask for it through mtmp_gemm_tn_slab_rows.  mode: 0 one token group per workgroup, 1 two token groups (half the
+// slabs), 2 the LDS-DMA kernel with 128 x 256 tiles (bf16, large M, K a multiple of 256; -DMTMP_TN_OLD: never)
+int tn_launch_splits(bool tr, int M, int N, int K, int* mode_out) {
+    // two token groups per workgroup / wide tiles once the split count is not what limits the grid
     const bool two = tr && tn_splits(M, N, K, 256) * 8 * TK <= M;
-    if (two_out) *two_out = two;
-    return tn_splits(M, N, K, two ? 256 : (tr ? 512 : 640));
+    int mode = two ? 1 : 0, splits = tn_splits(M, N, K, two ? 256 : (tr ? 512 : 640));
+#ifndef MTMP_TN_OLD
+    if (two && K % 256 == 0) {
+        const int tiles = (N / 128) * (K / 256), max_s = (M + 4 * TK - 1) / (4 * TK);
+        splits = 256 / tiles > max_s ? max_s : 256 / tiles;
+        if (splits < 1) splits = 1;
+        mode = 2;
+    }
+#endif
+    if (mode_out) *mode_out = mode;
+    return splits;
 }
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
                    hipStream_t st) {
-    constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernel, eight waves per CU
-    bool two;
-    const int splits = tn_launch_splits(TR, M, N, K, &two);
+    constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernels, eight waves per CU
+    int mode;
+    const int splits = tn_launch_splits(TR, M, N, K, &mode);
     int rps = (M + splits - 1) / splits;
     rps = (rps + TK - 1) / TK * TK;
     TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
-    const size_t sm = TR ? (size_t)(two ? 8 : 4) * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
-    const void* fn = TR ? (two ? (const void*)gemm_tn_tr_kernel<2> : (const void*)gemm_tn_tr_kernel<1>) : (const void*)gemm_tn_kernel<T>;
+    // the DMA kernel needs 16-byte aligned rows and 32-bit byte offsets; operands that are not get the register-staged kernel
+    // at the same split count
+    const bool dma = mode == 2 && ldy % 8 == 0 && ldx % 8 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 &&
+                     (unsigned long long)M * (unsigned)(ldy > ldx ? ldy : ldx) * 2ull < (1ull << 32);
+    const bool two = mode == 1;
+    const size_t sm = dma ? (size_t)DNS * DSTAGE : TR ? (size_t)(two ? 8 : 4) * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
+    const void* fn = dma ? (const void*)gemm_tn_dma_kernel
+                         : TR ? (two ? (const void*)gemm_tn_tr_kernel<2> : (const void*)gemm_tn_tr_kernel<1>) : (const void*)gemm_tn_kernel<T>;
     if (sm > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
         mtmp_set_error("mtmp_gemm_tn: cannot raise dynamic LDS to %zu", sm);
         return MTMP_ERR_LAUNCH;
     }
-    const dim3 grid(splits * (N / 128) * (K / 128));
+    const dim3 grid(splits * (N / 128) * (K / 128)), grid_w(splits * (N / 128) * (K / 256));
     if constexpr (TR) {
-        if (two) hipLaunchKernelGGL(gemm_tn_tr_kernel<2>, grid, dim3(512), sm, st, a);
+        if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, grid_w, dim3(512), sm, st, a);
+        else if (two) hipLaunchKernelGGL(gemm_tn_tr_kernel<2>, grid, dim3(512), sm, st, a);
         else     hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(256), sm, st, a);
     } else {
         hipLaunchKernelGGL(gemm_tn_kernel<T>, grid, dim3(256), sm, st, a);

@@ -273,6 +273,24 @@ def test_gemm_tn_weight_gradient(ops, dt, M, N, K):
     check(t + ".db", db, dy.double().sum(0), 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(64320, 768, 256), (64320, 256, 1024), (12345, 768, 256), (40001, 256, 768), (20033, 1024, 256),
+                                   (16447, 768, 256)])
+def test_gemm_tn_large_m_dma_tiles(ops, M, N, K):
+    """bf16, large M: the LDS-DMA kernel (two token groups per workgroup): token tails that end inside a stage, a split with no
+    rows at all (M = 12345), K tiles that do not divide the bias share evenly (K = 768), operands that are column windows of wider
+    buffers (row stride > width), against a float64 product of the same bf16 inputs."""
+    g = torch.Generator().manual_seed(M + N)
+    wide_y = torch.randn(M, N + 64, generator=g).to(torch.bfloat16).to(DEV)
+    wide_x = torch.randn(M, K + 128, generator=g).to(torch.bfloat16).to(DEV)
+    for dy, x in ((wide_y[:, :N].contiguous(), wide_x[:, :K].contiguous()), (wide_y[:, 64:], wide_x[:, 128:])):
+        dw, db = ops.gemm_tn(dy, x)
+        t = f"gemm_tn.dma[M={M},N={N},K={K},ld={dy.stride(0)}]"
+        check(t + ".dw", dw, (dy.double().t() @ x.double()).cpu(), 1e-4)
+        check(t + ".db", db, dy.double().sum(0).cpu(), 1e-4)
+        dw2, db2 = ops.gemm_tn(dy, x)
+        assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic (no atomics)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_ln_bwd(ops, dt, golden_dir):
     g = torch.Generator().manual_seed(9)
