@@ -340,7 +340,7 @@ def main():
                                      "idle device, after the timed region"},
         }
         names = {"attn_bwd": "attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (vslt stream; algorithmic flops = 2.5 x forward)",
-                 "gemm_tn": "gemm_tn_tr_kernel + tn_reduce_kernel (vslt-stream QKV weight gradient, M x 768 x 256)"}
+                 "gemm_tn": "gemm_tn_dma_kernel + reduce_batch_kernel (vslt-stream QKV weight gradient, M x 768 x 256)"}
         out["roofline_more"] = []
         for key in ("attn_bwd", "gemm_tn"):
             if key in probe and probe[key][0] > 0:

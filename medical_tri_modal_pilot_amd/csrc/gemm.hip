@@ -1399,7 +1399,7 @@ MTMP_DEV void tr_mma(f32x16 (&acc)[2][2], const bf16* sY, const bf16* sX, int wn
 // NG = 1: 256 threads, two workgroups per CU.  NG = 2 (large M): 512 threads = two GROUPS of four waves that share the output
 // tile and split every 128-token step between them (each group is the NG = 1 workgroup on its own 64 tokens and its own half
 // of the LDS); at the end group 1 hands its accumulators over through LDS and group 0 writes ONE partial slab: the same eight
-// waves per CU, half the slabs -- the split-M partials (33 MB written here and read again by tn_reduce_kernel per launch at
+// waves per CU, half the slabs -- the split-M partials (33 MB written here and read again by the reduce launch per launch at
 // config 2, against 132-165 MB of operands) were a fifth of this HBM-bound kernel's traffic.
 template <int NG>
 __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(TnArgs<bf16> p) {
@@ -1513,27 +1513,33 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
 }
 
 // ---------------------------------------------------------------------------
-// Large-M form of the product above: tiles by LDS-DMA (global_load_lds_dwordx4), loader waves and matrix waves, 128 x 256 output
-// tile per workgroup.
-// What bounded gemm_tn_tr_kernel<2> at config 2 (tools/dbg/ablate_tn.sh, tools/dbg/stamp_tn.py, tools/dbg/pmc_tn.sh; 48 us + 5.5 us
+// Large-M form of the product above: tiles by LDS-DMA (global_load_lds_dwordx4), loader waves and matrix waves.
+// What bounded gemm_tn_tr_kernel<2> at config 2 (tools/dbg/ablate_tn.sh, stamp_tn.py, pmc_tn.sh, prof_tn.sh; 48-52 us + 5.5 us
 // of reduce): every wave ran the same sequence -- fetch, ds_write_b128 commit (a 64 KiB step costs ~830 LDS cycles), 16 MFMAs --
 // between two barriers, and each of those blocks the in-order wave while it queues, so a step cost the SUM of its parts (~4000
-// cycles against 1024 of MFMA; matrix pipe 28 % busy, no LDS bank conflicts, clock 2.1 GHz) and removing any one part removed
-// only that part.  A first DMA version with eight identical waves (no commits, five stages in flight) ran at exactly the same
-// speed: the waves stood ~500 cycles per stage in the DMA issue queue with the matrix pipe idle.  And with 128 x 128 tiles the
-// launch moves 396 MB from L2 into the CUs (dY twice, X six times at N = 768), which alone takes 28 us (~14 TB/s, about what
-// LDS-DMA from L2 delivers).
-// Here the roles are split: waves 0-3 (one per SIMD) read fragments and issue MFMAs (64 x 128 of the 128 x 256 tile each, over
-// ALL tokens of a stage: one partial slab per workgroup, no accumulator hand-over; 297 MB from L2), waves 4-7 (their SIMD
-// partners) only issue DMA and wait for it.  A stage is 64 tokens (dY | X[:, 0:128] | X[:, 128:256] tiles of [64][128], unpadded
-// 256-byte rows whose 64-byte blocks are XOR-ed with row & 3 on the SOURCE side -- what makes the 4-rows-by-64-bytes
-// footprint of a ds_read_b64_tr_b16 lane group conflict-free), three stages, one barrier per stage.  Token tail: rows past
-// m_end are fetched from the clamped last row and the dY rows are zeroed in LDS (one stage per launch).  The bias gradient
-// (column sums of dY) rides on the matrix pipe: dY^T x ones for one 32-column block per matrix wave (+12 % MFMAs; from LDS with
-// vector adds it cost 7 us of the launch wherever it was placed).
-constexpr int DT = 64, DNS = 3;                            // tokens per stage; stages
-constexpr int DTILE = DT * 256, DSTAGE = 3 * DTILE;        // bytes: one [DT][128] bf16 tile; a stage = dY | X lo | X hi
-constexpr int DPW = 12;                                    // DMA pieces per loader wave and stage
+// cycles against 1024 of MFMA; matrix pipe 28 % busy, no LDS bank conflicts, clock 1.9-2.1 GHz) and removing any one part
+// removed only that part.  A first DMA version with eight identical waves (no commits, five stages in flight) ran at exactly the
+// same speed: the waves stood ~500 cycles per stage in the DMA issue queue with the matrix pipe idle.
+// Here the roles are split: waves 0-3 (one per SIMD) read fragments and issue MFMAs (a 64-row block of the tile each, over ALL
+// tokens of a stage: one partial slab per workgroup, no accumulator hand-over), waves 4-7 (their SIMD partners) only issue DMA
+// and wait for it.  A stage is 64 tokens of [64][128] tiles (unpadded 256-byte rows whose 64-byte blocks are XOR-ed with
+// row & 3 on the SOURCE side -- what makes the 4-rows-by-64-bytes footprint of a ds_read_b64_tr_b16 lane group conflict-free),
+// one barrier per stage.  Token tail: rows past m_end are fetched from the clamped last row and the dY rows are zeroed in LDS
+// (one stage per launch).  The bias gradient (column sums of dY) rides on the matrix pipe: dY^T x ones for one 32-column block
+// per matrix wave (+12 % MFMAs; from LDS with vector adds it cost 7 us of the launch wherever it was placed).
+// XT = 1 (shipped): 128 x 128 tiles, five stages of dY | X, matrix waves 64 x 64, 16.5 MB of partial slabs at config 2: 38 / 46 us
+// per launch (kernel trace).  XT = 2 (-DMTMP_TN_WIDE): 128 x 256 tiles, three stages of dY | X lo | X hi, matrix waves 64 x 128:
+// 297 instead of 396 MB from L2 into the CUs and 33 / 40 us per launch -- its pure-MFMA loop (no DMA, no reads, no barriers, no
+// stores) takes 19 us at the 1.88 GHz the chip holds -- but 33 MB of slabs, which the step's HBM-sharing streams pay for
+// (tn_launch_splits below).
+constexpr int DT = 64;                                     // tokens per stage
+constexpr int DTILE = DT * 256;                            // bytes: one [DT][128] bf16 tile
+template <int XT> struct TnDma {
+    static constexpr int DNS = XT == 2 ? 3 : 5;            // stages
+    static constexpr int DSTAGE = (1 + XT) * DTILE;        // a stage = dY | X (lo | hi)
+    static constexpr int DPW = 4 * (1 + XT);               // DMA pieces per loader wave and stage
+    static constexpr int NB = 2 * XT;                      // 32-column X blocks per matrix wave
+};
 MTMP_DEV Frag<bf16> frag_tr_at(const char* a) {            // lane's 8-byte piece in token rows r and r + 4 of a 256-byte-row image
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1545,30 +1551,35 @@ MTMP_DEV Frag<bf16> frag_tr_at(const char* a) {            // lane's 8-byte piec
     return f;
 }
 template <int N> MTMP_DEV void tn_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-MTMP_DEV void tn_wait_stages(int k) {                      // all but the last k stages (DPW pieces each) of this wave have landed
-    if (k >= 2) tn_wait<2 * DPW>();
+template <int DPW> MTMP_DEV void tn_wait_stages(int k) {   // all but the last k stages (DPW pieces each) of this wave have landed
+    if (k >= 4) tn_wait<4 * DPW>();
+    else if (k == 3) tn_wait<3 * DPW>();
+    else if (k == 2) tn_wait<2 * DPW>();
     else if (k == 1) tn_wait<DPW>();
     else tn_wait<0>();
 }
-struct TnChunk { Frag<bf16> a[2], b[4]; };
+template <int NB> struct TnChunk { Frag<bf16> a[2], b[NB]; };
 #ifdef MTMP_TND_NOBAR                                        // (ablation build: no stage barriers, results wrong)
 #define TND_BARRIER()
 #else
 #define TND_BARRIER() __syncthreads()
 #endif
+template <int XT>
 __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
+    constexpr int DNS = TnDma<XT>::DNS, DSTAGE = TnDma<XT>::DSTAGE, DPW = TnDma<XT>::DPW, NB = TnDma<XT>::NB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
     const int tid = threadIdx.x & 255, lane = tid & 63, r = lane & 31, half = lane >> 5;
     const bool loader = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tn = p.N / 128, tk = p.K / 256;
+    const int tn = p.N / 128, tk = p.K / (128 * XT);
     int w = xcd_remap(blockIdx.x, gridDim.x);
     const int split = w / (tn * tk);
     w -= split * tn * tk;
-    const int kt = w % tk, n0 = (w / tk) * 128, k0 = kt * 256;
+    const int kt = w % tk, n0 = (w / tk) * 128, k0 = kt * 128 * XT;
     const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
-    const int wn = (wave >> 1) * 64, xt = wave & 1;        // matrix wave: dY columns wn .. wn + 63, X tile xt (128 columns)
+    const int wn = (wave >> 1) * 64, xt = wave & 1;        // matrix wave: dY columns wn .. wn + 63, X tile xt / X columns 64 xt ..
+    const int kcol = (XT == 2 ? 128 : 64) * xt;            // its first output column inside the tile
     const int nst = m_end > m_lo ? (m_end - m_lo + DT - 1) / DT : 0;
     // ---- loader wave `wave`: rows 16 wave .. 16 wave + 15 of the three tiles (four 1 KiB pieces each)
     const int lr = lane >> 4, lc = (lane & 15) ^ (4 * lr);           // row inside a piece; logical 16-byte chunk this lane fetches
@@ -1584,16 +1595,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
             const unsigned row = (unsigned)min(m_lo + st_ * DT + 16 * wave + 4 * q + lr, m_end - 1);
             dma16(row * ldyb + ycol, p.dy, dst + q * 1024);
             dma16(row * ldxb + xcol, p.x, dst + DTILE + q * 1024);
-            dma16(row * ldxb + xcol + 256, p.x, dst + 2 * DTILE + q * 1024);
+            if constexpr (XT == 2) dma16(row * ldxb + xcol + 256, p.x, dst + 2 * DTILE + q * 1024);
         }
     };
     // ---- matrix wave: lane (G = lane >> 4, i = lane & 15) reads token rows 8 (G >> 1) + (i >> 2) (+ 4), bytes 32 (G & 1) + 8 (i & 3)
     const int G = lane >> 4, i16 = lane & 15, sw = 4 * (i16 >> 2);
     const int rowoff = (8 * (G >> 1) + (i16 >> 2)) * 256 + 32 * (G & 1) + 8 * (i16 & 3);
     const int aoff0 = rowoff + 16 * ((wn >> 3) ^ sw), aoff1 = rowoff + 16 * (((wn + 32) >> 3) ^ sw);
-    const int xbase = DTILE * (1 + xt) + rowoff;
-    const int boff0 = xbase + 16 * (0 ^ sw), boff1 = xbase + 16 * (4 ^ sw), boff2 = xbase + 16 * (8 ^ sw), boff3 = xbase + 16 * (12 ^ sw);
-    f32x16 acc[2][4] = {{{0}, {0}, {0}, {0}}, {{0}, {0}, {0}, {0}}};
+    const int xbase = DTILE * (XT == 2 ? 1 + xt : 1) + rowoff, xc0 = XT == 2 ? 0 : 8 * xt;       // (first 16-byte chunk of the wave's X columns)
+    int boff[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) boff[j] = xbase + 16 * ((xc0 + 4 * j) ^ sw);
+    f32x16 acc[2][NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x16{0};
     // bias gradient (column sums of dY) on the matrix pipe: dY^T x ones for ONE 32-column block of the tile per matrix wave.
     // Block b = 2 (wn / 64) + ai belongs to K tile b mod min(tk, 4), so the K tiles share the 128 columns.  With one K tile the
     // two waves of a column half take one block each (ai = xt) over all k-chunks; otherwise they split the chunks of their one
@@ -1609,22 +1626,26 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
     f32x16 acc_cs = {0};
     auto chunk = [&](int st_, int c) {
         const char* sb = smem_raw + (st_ % DNS) * DSTAGE + c * 4096;
-        TnChunk f;
+        TnChunk<NB> f;
 #ifdef MTMP_TND_MMAONLY
-        f.a[0] = f.a[1] = f.b[0] = f.b[1] = f.b[2] = f.b[3] = frag_zero<bf16>();
-        asm volatile("" : "+v"(f.a[0].v), "+v"(f.a[1].v), "+v"(f.b[0].v), "+v"(f.b[1].v), "+v"(f.b[2].v), "+v"(f.b[3].v));
+        f.a[0] = f.a[1] = frag_zero<bf16>();
+        asm volatile("" : "+v"(f.a[0].v), "+v"(f.a[1].v));
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { f.b[j] = frag_zero<bf16>(); asm volatile("" : "+v"(f.b[j].v)); }
 #elif !defined(MTMP_TND_NOREAD)
-        f.a[0] = frag_tr_at(sb + aoff0); f.b[0] = frag_tr_at(sb + boff0); f.b[1] = frag_tr_at(sb + boff1);
-        f.b[2] = frag_tr_at(sb + boff2); f.b[3] = frag_tr_at(sb + boff3); f.a[1] = frag_tr_at(sb + aoff1);
+        f.a[0] = frag_tr_at(sb + aoff0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) f.b[j] = frag_tr_at(sb + boff[j]);
+        f.a[1] = frag_tr_at(sb + aoff1);
 #endif
         return f;
     };
-    auto mma8 = [&](const TnChunk& f, bool with_cs) {
+    auto mma8 = [&](const TnChunk<NB>& f, bool with_cs) {
 #if !defined(MTMP_TND_NOMMA) && !defined(MTMP_TND_NOREAD)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mma<bf16>(acc[i][j], f.a[i], f.b[j]);
+            for (int j = 0; j < NB; ++j) mma<bf16>(acc[i][j], f.a[i], f.b[j]);
 #ifndef MTMP_TND_NOCSUM
         if (with_cs) {
             Frag<bf16> a;
@@ -1661,7 +1682,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
         TSTAMP(ts1)
         for (int s = 0; s < nst; ++s) {
             TSTAMP(ta)
-            tn_wait_stages(min(nst - 1, max(DNS - 1, s + DNS - 2)) - s);
+            tn_wait_stages<DPW>(min(nst - 1, max(DNS - 1, s + DNS - 2)) - s);
             TSTAMP(ta2)
             TND_BARRIER();                                 // B(s)
             TSTAMP(ta3)
@@ -1682,15 +1703,15 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
             TND_BARRIER();                                 // B(s)
             TSTAMP(ta3)
             fix_tail(s);
-            const TnChunk f0 = chunk(s, 0);
+            const TnChunk<NB> f0 = chunk(s, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const TnChunk f1 = chunk(s, 1);
+            const TnChunk<NB> f1 = chunk(s, 1);
             mma8(f0, cs_c01);
             __builtin_amdgcn_sched_barrier(0);
-            const TnChunk f2 = chunk(s, 2);
+            const TnChunk<NB> f2 = chunk(s, 2);
             mma8(f1, cs_c01);
             __builtin_amdgcn_sched_barrier(0);
-            const TnChunk f3 = chunk(s, 3);
+            const TnChunk<NB> f3 = chunk(s, 3);
             mma8(f2, cs_c23);
             __builtin_amdgcn_sched_barrier(0);
             mma8(f3, cs_c23);
@@ -1718,18 +1739,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) keep += acc[i][j][t];
-        out[(size_t)(n0 + wn + acc_row(0, half)) * p.K + k0 + 128 * xt + r] = keep;
+        out[(size_t)(n0 + wn + acc_row(0, half)) * p.K + k0 + kcol + r] = keep;
 #else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + 128 * xt + 32 * j + r] = acc[i][j][t];
+                    out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + kcol + 32 * j + r] = acc[i][j][t];
 #endif
     } else if (tid < 128 && (tid >> 5) % tkp == kt) {
         out[(size_t)p.N * p.K + n0 + tid] = red[tid] + red[128 + tid];
@@ -1743,24 +1764,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
 #endif
 }
 
-// out[c] = sum_s slab[s][c]; a block owns 64 columns, 4 row-lanes reduce through LDS
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, int splits, size_t cols, float* dw, float* db,
-                                                        size_t nk) {
-    __shared__ float part[4][64];
-    const size_t c = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < cols)
-        for (int q = rl; q < splits; q += 4) s += slab[(size_t)q * cols + c];
-    part[rl][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rl == 0 && c < cols) {
-        s = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-        if (c < nk) dw[c] = s;
-        else if (db) db[c - nk] = s;
-    }
-}
-
 // Several slab reductions in ONE launch: out_e[c] = sum_r slab_e[r][c] for up to RB_MAX entries (blockIdx.y); columns below
 // split_e go to a_e, the rest to b_e (the weight / bias gradient of a split-M product share a slab row).  A layer's backward
 // produced seven of these reductions (3 weight gradients, 2 x 2 levels of LayerNorm gamma / beta partials): seven launches of
@@ -1768,11 +1771,43 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* slab, int s
 constexpr int RB_MAX = 8;
 struct ReduceBatch { const float* slab[RB_MAX]; float* a[RB_MAX]; float* b[RB_MAX]; long long cols[RB_MAX], split[RB_MAX]; int rows[RB_MAX]; };
 __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch t) {
-    __shared__ float part[4][64];
+    __shared__ f32x4 part4[4][64];
     const int e = blockIdx.y;
     const long long cols = t.cols[e];
     const int rows = t.rows[e], rl = threadIdx.x >> 6, cl = threadIdx.x & 63;
     const float* slab = t.slab[e];
+    if ((cols & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
+        // four columns per thread (16-byte loads, four rows in flight per row lane); the slabs are the bulk of a layer's
+        // reduction traffic (3 x 33 MB at config 2) and 4-byte loads kept this launch at ~1.6 TB/s
+        for (long long c0 = (long long)blockIdx.x * 256; c0 < cols; c0 += (long long)gridDim.x * 256) {
+            const long long c = c0 + 4 * cl;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+            if (c < cols) {
+                const float* col = slab + c;
+                int q = rl;
+                for (; q + 12 < rows; q += 16) {
+                    s0 += ld4f(col + (size_t)q * cols);
+                    s1 += ld4f(col + (size_t)(q + 4) * cols);
+                    s2 += ld4f(col + (size_t)(q + 8) * cols);
+                    s3 += ld4f(col + (size_t)(q + 12) * cols);
+                }
+                for (; q < rows; q += 4) s0 += ld4f(col + (size_t)q * cols);
+            }
+            __syncthreads();
+            part4[rl][cl] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            if (rl == 0 && c < cols) {
+                const f32x4 s = (part4[0][cl] + part4[1][cl]) + (part4[2][cl] + part4[3][cl]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (c + i < t.split[e]) t.a[e][c + i] = s[i];
+                    else if (t.b[e]) t.b[e][c + i - t.split[e]] = s[i];
+                }
+            }
+        }
+        return;
+    }
+    float (*part)[64] = reinterpret_cast<float (*)[64]>(&part4[0][0]);
     for (long long c0 = (long long)blockIdx.x * 64; c0 < cols; c0 += (long long)gridDim.x * 64) {
         const long long c = c0 + cl;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -2063,18 +2098,26 @@ int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStr
 
 // partial slabs the launch writes (rows of the [splits][N K + N] workspace) -- a function of the shape only, the deferred
 // reductions ask for it through mtmp_gemm_tn_slab_rows.  mode: 0 one token group per workgroup, 1 two token groups (half the
-// slabs), 2 the LDS-DMA kernel with 128 x 256 tiles (bf16, large M, K a multiple of 256; -DMTMP_TN_OLD: never)
+// slabs), 3 the LDS-DMA kernel with 128 x 128 tiles at the split count of mode 1 (bf16, large M; -DMTMP_TN_OLD: never),
+// 2 the LDS-DMA kernel with 128 x 256 tiles (-DMTMP_TN_WIDE)
 int tn_launch_splits(bool tr, int M, int N, int K, int* mode_out) {
     // two token groups per workgroup / wide tiles once the split count is not what limits the grid
     const bool two = tr && tn_splits(M, N, K, 256) * 8 * TK <= M;
     int mode = two ? 1 : 0, splits = tn_splits(M, N, K, two ? 256 : (tr ? 512 : 640));
 #ifndef MTMP_TN_OLD
+#ifndef MTMP_TN_WIDE
+    if (two && K >= 256) mode = 3;                         // the DMA kernel with 128 x 128 tiles, split count of `two`
+#else
+    // (A/B build: 128 x 256 tiles.  33 / 40 us per launch against 38 / 46 us for the 128 x 128 form alone, but twice the partial-
+    //  slab bytes (33 MB written, and read again by the reduction) in a step whose streams share the HBM: 9.12-9.33 ms/step
+    //  against 9.15-9.18, the register-staged kernel 9.30-9.34, one box)
     if (two && K % 256 == 0) {
         const int tiles = (N / 128) * (K / 256), max_s = (M + 4 * TK - 1) / (4 * TK);
         splits = 256 / tiles > max_s ? max_s : 256 / tiles;
         if (splits < 1) splits = 1;
         mode = 2;
     }
+#endif
 #endif
     if (mode_out) *mode_out = mode;
     return splits;
@@ -2090,11 +2133,12 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
     // the DMA kernel needs 16-byte aligned rows and 32-bit byte offsets; operands that are not get the register-staged kernel
     // at the same split count
-    const bool dma = mode == 2 && ldy % 8 == 0 && ldx % 8 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 &&
+    const bool dma = mode >= 2 && ldy % 8 == 0 && ldx % 8 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 &&
                      (unsigned long long)M * (unsigned)(ldy > ldx ? ldy : ldx) * 2ull < (1ull << 32);
-    const bool two = mode == 1;
-    const size_t sm = dma ? (size_t)DNS * DSTAGE : TR ? (size_t)(two ? 8 : 4) * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
-    const void* fn = dma ? (const void*)gemm_tn_dma_kernel
+    const bool two = mode == 1 || (mode == 3 && !dma);
+    const bool wide = mode == 2;
+    const size_t sm = dma ? (wide ? (size_t)TnDma<2>::DNS * TnDma<2>::DSTAGE : (size_t)TnDma<1>::DNS * TnDma<1>::DSTAGE) : TR ? (size_t)(two ? 8 : 4) * TT * LDG * sizeof(bf16) : (size_t)256 * LDX * sizeof(T);
+    const void* fn = dma ? (wide ? (const void*)gemm_tn_dma_kernel<2> : (const void*)gemm_tn_dma_kernel<1>)
                          : TR ? (two ? (const void*)gemm_tn_tr_kernel<2> : (const void*)gemm_tn_tr_kernel<1>) : (const void*)gemm_tn_kernel<T>;
     if (sm > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
         mtmp_set_error("mtmp_gemm_tn: cannot raise dynamic LDS to %zu", sm);
@@ -2102,7 +2146,8 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     }
     const dim3 grid(splits * (N / 128) * (K / 128)), grid_w(splits * (N / 128) * (K / 256));
     if constexpr (TR) {
-        if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel, grid_w, dim3(512), sm, st, a);
+        if (dma && wide) hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid_w, dim3(512), sm, st, a);
+        else if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, grid, dim3(512), sm, st, a);
         else if (two) hipLaunchKernelGGL(gemm_tn_tr_kernel<2>, grid, dim3(512), sm, st, a);
         else     hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(256), sm, st, a);
     } else {
@@ -2111,7 +2156,12 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn");
     if (!dw) return MTMP_OK;                                  // partials only: the caller reduces them (mtmp_reduce_batch)
     const size_t nk = (size_t)N * K, cols = nk + N;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, ws, splits, cols, dw, db, nk);
+    ReduceBatch t;                                            // the same kernel (and summation order) as the deferred form
+    for (int i = 0; i < RB_MAX; ++i) {
+        t.slab[i] = ws; t.a[i] = dw; t.b[i] = db; t.cols[i] = (long long)cols; t.split[i] = (long long)nk; t.rows[i] = splits;
+    }
+    const size_t blocks = (cols + 255) / 256;
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), 1), dim3(256), 0, st, t);
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn(reduce)");
     return MTMP_OK;
 }
@@ -2281,7 +2331,7 @@ extern "C" int mtmp_reduce_batch(const float* const* slab, const int* rows, cons
         t.slab[i] = slab[k]; t.a[i] = out_a[k]; t.b[i] = out_b[k]; t.cols[i] = cols[k]; t.split[i] = split[k]; t.rows[i] = rows[k];
         most = most > cols[k] ? most : cols[k];
     }
-    const long long blocks = (most + 63) / 64;
+    const long long blocks = (most + 255) / 256;
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), n), dim3(256), 0, (hipStream_t)stream, t);
     MTMP_CHECK_LAUNCH("mtmp_reduce_batch");
     return MTMP_OK;
