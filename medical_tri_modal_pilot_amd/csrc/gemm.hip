@@ -1778,26 +1778,32 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch t) {
     const float* slab = t.slab[e];
     if ((cols & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
         // four columns per thread (16-byte loads, four rows in flight per row lane); the slabs are the bulk of a layer's
-        // reduction traffic (3 x 33 MB at config 2) and 4-byte loads kept this launch at ~1.6 TB/s
-        for (long long c0 = (long long)blockIdx.x * 256; c0 < cols; c0 += (long long)gridDim.x * 256) {
-            const long long c = c0 + 4 * cl;
+        // reduction traffic and 4-byte loads kept this launch at ~1.6 TB/s.  Row lanes per block by the slab's height: the
+        // LayerNorm partials (one row per 128 tokens: 503 rows of 512 columns at config 2) would otherwise be two blocks walking
+        // 126 dependent rounds each -- the longest chain of the launch.
+        const int RL = rows >= 256 ? 64 : rows >= 64 ? 16 : 4, CQ = 256 / RL;
+        const int rl4 = threadIdx.x / CQ, cq = threadIdx.x % CQ;
+        f32x4* part = &part4[0][0];                        // [RL][CQ]
+        for (long long c0 = (long long)blockIdx.x * 4 * CQ; c0 < cols; c0 += (long long)gridDim.x * 4 * CQ) {
+            const long long c = c0 + 4 * cq;
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
             if (c < cols) {
                 const float* col = slab + c;
-                int q = rl;
-                for (; q + 12 < rows; q += 16) {
+                int q = rl4;
+                for (; q + 3 * RL < rows; q += 4 * RL) {
                     s0 += ld4f(col + (size_t)q * cols);
-                    s1 += ld4f(col + (size_t)(q + 4) * cols);
-                    s2 += ld4f(col + (size_t)(q + 8) * cols);
-                    s3 += ld4f(col + (size_t)(q + 12) * cols);
+                    s1 += ld4f(col + (size_t)(q + RL) * cols);
+                    s2 += ld4f(col + (size_t)(q + 2 * RL) * cols);
+                    s3 += ld4f(col + (size_t)(q + 3 * RL) * cols);
                 }
-                for (; q < rows; q += 4) s0 += ld4f(col + (size_t)q * cols);
+                for (; q < rows; q += RL) s0 += ld4f(col + (size_t)q * cols);
             }
             __syncthreads();
-            part4[rl][cl] = (s0 + s1) + (s2 + s3);
+            part[rl4 * CQ + cq] = (s0 + s1) + (s2 + s3);
             __syncthreads();
-            if (rl == 0 && c < cols) {
-                const f32x4 s = (part4[0][cl] + part4[1][cl]) + (part4[2][cl] + part4[3][cl]);
+            if (rl4 == 0 && c < cols) {
+                f32x4 s = part[cq];
+                for (int l = 1; l < RL; ++l) s += part[l * CQ + cq];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (c + i < t.split[e]) t.a[e][c + i] = s[i];
@@ -2160,7 +2166,8 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     for (int i = 0; i < RB_MAX; ++i) {
         t.slab[i] = ws; t.a[i] = dw; t.b[i] = db; t.cols[i] = (long long)cols; t.split[i] = (long long)nk; t.rows[i] = splits;
     }
-    const size_t blocks = (cols + 255) / 256;
+    const int rlanes = splits >= 256 ? 64 : splits >= 64 ? 16 : 4;
+    const size_t blocks = (cols + 4 * (256 / rlanes) - 1) / (4 * (256 / rlanes));
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), 1), dim3(256), 0, st, t);
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn(reduce)");
     return MTMP_OK;
@@ -2331,7 +2338,12 @@ extern "C" int mtmp_reduce_batch(const float* const* slab, const int* rows, cons
         t.slab[i] = slab[k]; t.a[i] = out_a[k]; t.b[i] = out_b[k]; t.cols[i] = cols[k]; t.split[i] = split[k]; t.rows[i] = rows[k];
         most = most > cols[k] ? most : cols[k];
     }
-    const long long blocks = (most + 255) / 256;
+    long long blocks = (most + 255) / 256;
+    for (int i = 0; i < n; ++i) {                          // (tall slabs take more row lanes and fewer columns per block)
+        const int rl = rows[i] >= 256 ? 64 : rows[i] >= 64 ? 16 : 4;
+        const long long need = (cols[i] + 4 * (256 / rl) - 1) / (4 * (256 / rl));
+        blocks = blocks > need ? blocks : need;
+    }
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), n), dim3(256), 0, (hipStream_t)stream, t);
     MTMP_CHECK_LAUNCH("mtmp_reduce_batch");
     return MTMP_OK;
