@@ -281,13 +281,18 @@ class SwinTransformer(nn.Module):
             s1.wait_stream(head)
             with torch.cuda.stream(s0):       # s0 owns the result: nothing allocated on s1 is read by another stream
                 out = torch.empty(n, x.shape[1] // 2, x.shape[2] // 2, 2 * x.shape[3], dtype=x.dtype, device=x.device)   # one merge left
+            # (Under rocprofv3 --kernel-trace the second half starts ~600 us after the first, as if serialised; the step's own
+            #  one-lane mark kernels -- tools/dbg/timeline.py, no profiler attached -- show both halves starting within 0.1 us
+            #  of each other and ending 12 us apart.  Issuing the halves module by module, alternating streams, changes nothing.)
             for k, st in enumerate((s0, s1)):
                 lo, hi = k * n // 2, (k + 1) * n // 2
                 with torch.cuda.stream(st):
+                    ops.mark("swin.tail%d.s" % k)          # (nothing is launched unless marks are enabled)
                     y = x[lo:hi]
                     for mod, sc in tail:
                         y = mod(y) if sc is None else mod(y, tuple(None if v is None else v[lo:hi] for v in sc))
                     ops.layernorm_rows(y, self.norm.weight, self.norm.bias, self.norm.eps, out=out[lo:hi])
+                    ops.mark("swin.tail%d.e" % k)
             s0.wait_stream(s1)
             return out
         return ops.layernorm_rows(x, self.norm.weight, self.norm.bias, self.norm.eps)

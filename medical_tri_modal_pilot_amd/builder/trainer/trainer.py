@@ -244,6 +244,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
                 step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
                 gs.publish_loss(step_loss)           # the host takes the value from here (gs.wait_loss below)
                 step_loss.backward()
+                ops.mark("bwd.e")                    # (tools/dbg/timeline.py; nothing is launched unless marks are enabled)
                 return step_loss.detach()
             loss = gs.run(inputs, fwd_bwd, optimizer.flat.params, reducer=red, round_fp16=deferred)
         else:

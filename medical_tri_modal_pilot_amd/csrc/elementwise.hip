@@ -338,18 +338,34 @@ __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const flo
     for (int v = 0; v < 8; ++v)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
-    for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
-        const int e = tie_event_of_row(cu, t_pad, row);
-        if (e < 0) continue;                                                    // pad row: no event, no gradient
-        const float tau = ev[3 * (size_t)e], val = ev[3 * (size_t)e + 1];
-        const int f = min(max((int)ev[3 * (size_t)e + 2], 0), 19);
-        const f32x4 g = load4<T>(dE + (size_t)row * D + 4 * lane);
-        if (VAL) tie_chain_bwd(cv, val, g, acc, 0);
-        tie_chain_bwd(ct, tau, g, acc, 4);
-        f32x4* tp = reinterpret_cast<f32x4*>(my_tab + f * D + 4 * lane);        // wave-private: plain read-modify-write
-        f32x4 tv = *tp;
-        tv += g;
-        *tp = tv;
+    // Four of the wave's rows are fetched before the first is used: with 80 KiB of LDS per workgroup only eight waves share a
+    // CU, and one dependent global-load round per row (31 rows per wave at config 2) made this a 69 us launch on the step's
+    // tail, where nothing else runs.  Rows are still accumulated in order (same sums).
+    constexpr int PF = 4;
+    const int stride = gridDim.x * 4;
+    for (int row0 = blockIdx.x * 4 + wave; row0 < n; row0 += PF * stride) {
+        int e[PF];
+        float tau[PF], val[PF], ff[PF];
+        f32x4 g[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int row = row0 + k * stride;
+            e[k] = row < n ? tie_event_of_row(cu, t_pad, row) : -1;
+            const size_t eo = 3 * (size_t)max(e[k], 0);
+            tau[k] = ev[eo]; val[k] = ev[eo + 1]; ff[k] = ev[eo + 2];
+            g[k] = load4<T>(dE + (size_t)min(row, n - 1) * D + 4 * lane);
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            if (e[k] < 0) continue;                                             // pad row / past the end: no event, no gradient
+            const int f = min(max((int)ff[k], 0), 19);
+            if (VAL) tie_chain_bwd(cv, val[k], g[k], acc, 0);
+            tie_chain_bwd(ct, tau[k], g[k], acc, 4);
+            f32x4* tp = reinterpret_cast<f32x4*>(my_tab + f * D + 4 * lane);    // wave-private: plain read-modify-write
+            f32x4 tv = *tp;
+            tv += g[k];
+            *tp = tv;
+        }
     }
     float* row = slab + (size_t)blockIdx.x * 28 * D;
     __syncthreads();
