@@ -2108,8 +2108,15 @@ int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStr
 // 2 the LDS-DMA kernel with 128 x 256 tiles (-DMTMP_TN_WIDE)
 int tn_launch_splits(bool tr, int M, int N, int K, int* mode_out) {
     // two token groups per workgroup / wide tiles once the split count is not what limits the grid
-    const bool two = tr && tn_splits(M, N, K, 256) * 8 * TK <= M;
-    int mode = two ? 1 : 0, splits = tn_splits(M, N, K, two ? 256 : (tr ? 512 : 640));
+    // Workgroups of the one-per-CU kernels: 192, not one per CU -- these workgroups take a whole CU's LDS, so every CU that holds
+    // a workgroup of the image / text streams' concurrent launches delays one of them to a second round; with a quarter of the
+    // CUs left free the launch is ~15 % longer alone and the step shorter (9.03-9.06 / 9.25-9.35 ms against 9.11-9.14 / 9.30-9.42
+    // with 256, two boxes; 224: 9.08-9.11; 160 and 128: no better than 256).
+#ifndef MTMP_TN_WGS
+#define MTMP_TN_WGS 192
+#endif
+    const bool two = tr && tn_splits(M, N, K, MTMP_TN_WGS) * 8 * TK <= M;
+    int mode = two ? 1 : 0, splits = tn_splits(M, N, K, two ? MTMP_TN_WGS : (tr ? 512 : 640));
 #ifndef MTMP_TN_OLD
 #ifndef MTMP_TN_WIDE
     if (two && K >= 256) mode = 3;                         // the DMA kernel with 128 x 128 tiles, split count of `two`
