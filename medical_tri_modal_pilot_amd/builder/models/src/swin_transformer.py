@@ -252,6 +252,14 @@ class SwinTransformer(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    def predraw(self, n, device):
+        """The StochasticDepth draws of the next forward(x) with x.shape[0] == n, issued on the CURRENT stream; forward() waits
+        for them behind its first kernel (a caller that runs the encoder on a stream of its own gets the draws off that stream)."""
+        draw_row_scales(self, n, device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._predrawn_ev = (ev, n)
+
     def forward(self, x, tail_streams=None):
         """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] in the compute dtype.
 
@@ -262,8 +270,15 @@ class SwinTransformer(nn.Module):
         when a forked non-origin stream is joined by the stream that forked it -- tools/dbg/capture_topology.py.)"""
         stem = self.features[0]
         n = x.shape[0]
-        draw_row_scales(self, n, x.device)
+        drawn = getattr(self, "_predrawn_ev", None)
+        if drawn is None:
+            draw_row_scales(self, n, x.device)
         x = ops.swin_stem(x, stem[0].weight, stem[0].bias, stem[2].weight, stem[2].bias, self.compute_dtype)
+        if drawn is not None:                 # predraw(): the draws were issued on another stream, beside the patch embedding
+            if drawn[1] != n:
+                raise RuntimeError("SwinTransformer.predraw() was made for %d images, forward() got %d" % (drawn[1], n))
+            torch.cuda.current_stream().wait_event(drawn[0])
+            self._predrawn_ev = None
         layers = list(self.features)[1:]
         split = tail_streams is not None and _SPLIT_TAIL and n >= 16 and n % 2 == 0 and len(layers) == 7
         for layer in layers[:4] if split else layers:
