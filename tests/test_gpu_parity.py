@@ -289,6 +289,11 @@ def test_gemm_tn_large_m_dma_tiles(ops, M, N, K):
         check(t + ".db", db, dy.double().sum(0).cpu(), 1e-4)
         dw2, db2 = ops.gemm_tn(dy, x)
         assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic (no atomics)
+    # rows that are only 4-byte aligned cannot go through the DMA kernel: the register-staged kernel at the same split count
+    dy, x = wide_y[:, 2:N + 2], wide_x[:, 6:K + 6]
+    dw, db = ops.gemm_tn(dy, x)
+    check(f"gemm_tn.unaligned[M={M},N={N},K={K}].dw", dw, (dy.double().t() @ x.double()).cpu(), 1e-4)
+    check(f"gemm_tn.unaligned[M={M},N={N},K={K}].db", db, dy.double().sum(0).cpu(), 1e-4)
 
 
 @pytest.mark.parametrize("dt", DT)
