@@ -85,6 +85,12 @@ int mtmp_ln_gemm_signs(int dtype, const void* x, const float* gamma, const float
                        unsigned seed, const unsigned* seed_dev, void* signs, void* stream);
 int mtmp_gemm_nt_signs(int dtype, const void* a, const void* w, void* y, int M, int N, int lda, int ldy,
                        const void* signs, float gate_scale, void* stream);
+/* mtmp_gemm_nt_signs with the backward of a dropout on its A operand folded in (autograd of module.py:78-80 in front of dH):
+ * a' = keep ? a / (1 - drop_p) : 0 with mtmp_dropout_bwd's mask for (seed, seed_dev, drop_p) on the contiguous [M,256] tensor,
+ * y = signs ? (a' w^T) * gate_scale : 0, a_out [M,256] (may be NULL) = a' (the weight-gradient product's operand). */
+int mtmp_gemm_nt_signs_drop(int dtype, const void* a, const void* w, void* y, int M, int N, int lda, int ldy,
+                            const void* signs, float gate_scale, float drop_p, unsigned seed, const unsigned* seed_dev,
+                            void* a_out, void* stream);
 
 /* Weight / bias gradient of the Linear and k=1 Conv1d layers (attention.py:60-62, module.py:74-78):
  * dw[N,K] (fp32) = dy[M,N]^T x[M,K];  db[N] (fp32, may be NULL) = column sums of dy.

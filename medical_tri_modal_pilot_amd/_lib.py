@@ -25,6 +25,8 @@ SIGNATURES = {
     "mtmp_sign_bits_bytes": (c_longlong, [c_int, c_int]),
     "mtmp_ln_gemm_signs": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_float, c_uint, c_void_p, c_void_p, c_void_p]),
     "mtmp_gemm_nt_signs": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_void_p]),
+    "mtmp_gemm_nt_signs_drop": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_float, c_uint, c_void_p,
+                                                                                   c_void_p, c_void_p]),
     "mtmp_ln_linear_act": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_int, c_void_p]),
     "mtmp_ffn_fwd": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_float, c_float, c_uint, c_uint, c_void_p, c_void_p]),
     "mtmp_gemm_tn_slab_rows": (c_int, [c_int] * 4),

@@ -507,6 +507,27 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     const T* arow = p.a + (size_t)row * p.lda + 8 * half;
 #pragma unroll
     for (int c = 0; c < KC; ++c) af[c] = frag_load<T>(arow + 16 * c);
+    if constexpr (GATE) {
+        // drop_p > 0 in GATE mode: the A operand is the gradient of a dropout's output (the FFN's drop2 in front of dH = dY W2):
+        // a = keep ? a / (1 - p) : 0 with mtmp_dropout_bwd's mask (element row * K + col of a contiguous [M, K] tensor), applied
+        // to the fragments in registers; p.xn, if given, receives the masked rows (the weight-gradient product's operand) -- the
+        // separate dropout-backward launch and one read of dY are gone.
+        if (p.drop_p > 0.f) {
+            const unsigned thr_a = dropout_threshold(p.drop_p), seed_a = p.seed ^ (p.seed_dev ? *p.seed_dev : 0u);
+            const float sc_a = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const unsigned g0 = (unsigned)row * (K / 4) + 4 * c + 2 * half;
+                const unsigned k0 = dropout_keep4(seed_a, g0, thr_a), k1 = dropout_keep4(seed_a, g0 + 1, thr_a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool keep = ((j < 4 ? k0 >> j : k1 >> (j - 4)) & 1u) != 0;
+                    af[c].v[j] = keep ? from_f32<T>(to_f32(af[c].v[j]) * sc_a) : (T)0.0f;
+                }
+                if (p.xn && blockIdx.y == 0) frag_store<T>(p.xn + (size_t)row * K + 16 * c + 8 * half, af[c]);
+            }
+        }
+    }
     if constexpr (!GATE) {
         float s1 = 0.f;
 #pragma unroll
@@ -2231,6 +2252,22 @@ extern "C" int mtmp_gemm_nt_signs(int dtype, const void* a, const void* w, void*
                    "mtmp_gemm_nt_signs: bad shape M=%d N=%d lda=%d ldy=%d (K is fixed at 256)", M, N, lda, ldy);
     GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, nullptr, nullptr, (bf16*)y, nullptr, nullptr, nullptr, nullptr, M, N, 256, lda, ldy,
                      0, 0.f, 0.f, 0u, nullptr, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs};
+    return launch_ln_gemm_dma(g, 0, 1, (hipStream_t)stream);
+}
+
+// mtmp_gemm_nt_signs with the backward of a dropout on its A operand folded in (autograd of module.py:78-80 in front of the dH
+// product): a' = keep ? a / (1 - p) : 0 with mtmp_dropout_bwd's mask for (seed, seed_dev, p) on the contiguous [M,256] tensor;
+// y = signs ? (a' W^T) * gate_scale : 0; a_out [M,256] (may be NULL) receives a' -- the weight-gradient product's operand.
+extern "C" int mtmp_gemm_nt_signs_drop(int dtype, const void* a, const void* w, void* y, int M, int N, int lda, int ldy,
+                                       const void* signs, float gate_scale, float drop_p, unsigned seed, const unsigned* seed_dev,
+                                       void* a_out, void* stream) {
+    MTMP_CHECK_ARG(a && w && y && signs, "mtmp_gemm_nt_signs_drop: null pointer");
+    MTMP_CHECK_ARG(dtype == 1, "mtmp_gemm_nt_signs_drop: bf16 only (dtype %d)", dtype);
+    MTMP_CHECK_ARG(M > 0 && M < (1 << 24) && N > 0 && N % PanelDma::NP == 0 && lda >= 256 && lda % 8 == 0 && ldy >= N && ldy % 8 == 0 &&
+                       drop_p >= 0.f && drop_p < 1.f,
+                   "mtmp_gemm_nt_signs_drop: bad argument M=%d N=%d lda=%d ldy=%d p=%f (K is fixed at 256)", M, N, lda, ldy, drop_p);
+    GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, nullptr, nullptr, (bf16*)y, nullptr, nullptr, (bf16*)a_out, nullptr, M, N, 256, lda,
+                     ldy, 0, 0.f, drop_p, seed, seed_dev, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs};
     return launch_ln_gemm_dma(g, 0, 1, (hipStream_t)stream);
 }
 

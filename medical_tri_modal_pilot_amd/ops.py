@@ -188,11 +188,18 @@ def transpose_batch(mats):
     return outs
 
 
-def gemm_nt_signs(a2d, w, signs, gate_scale=1.0):
-    """y[M,N] = signs ? (a[M,256] w[N,256]^T) * gate_scale : 0 (bf16; signs from ln_gemm(..., want_signs=True))."""
+def gemm_nt_signs(a2d, w, signs, gate_scale=1.0, drop_p=0.0, seed=0):
+    """y[M,N] = signs ? (a[M,256] w[N,256]^T) * gate_scale : 0 (bf16; signs from ln_gemm(..., want_signs=True)).
+    drop_p > 0: a is the gradient of a dropout's output -- dropout_bwd(a, seed, drop_p) is applied to it inside the launch and
+    returned as well: (y, a_dropped)."""
     _gpu(a2d, w, signs)
     M, N = a2d.shape[0], w.shape[0]
     y = torch.empty(M, N, dtype=a2d.dtype, device=a2d.device)
+    if drop_p > 0:
+        ad = torch.empty(M, a2d.shape[1], dtype=a2d.dtype, device=a2d.device)
+        call("mtmp_gemm_nt_signs_drop", _dt(a2d), _p(a2d), _p(w), _p(y), M, N, a2d.stride(0), N, _p(signs), float(gate_scale),
+             float(drop_p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _p(ad), _stream())
+        return y, ad
     call("mtmp_gemm_nt_signs", _dt(a2d), _p(a2d), _p(w), _p(y), M, N, a2d.stride(0), N, _p(signs), float(gate_scale), _stream())
     return y
 
@@ -290,6 +297,7 @@ def swin_window_attn(qkv, table, heads, shift):
 
 REDUCE_BATCH_MAX = 8
 LATE_REDUCTIONS = True         # FusionStackFn.backward: that launch goes out behind the NEXT bottleneck exchange
+FOLD_DROPOUT_BWD = True         # layer_backward: drop2's backward inside the dH launch (A/B: tools/dbg/ab_patch.py)
 DEFER_REDUCTIONS = True        # layer_backward: one mtmp_reduce_batch per layer and stream instead of seven reduction launches
 
 
@@ -771,16 +779,20 @@ def layer_backward(saved, d_out, sink=None, late=None):
     M = B * N
     d_out = d_out.view(M, D)
     # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
-    dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
     direct = sink is not None and sink.usable()
     red = [] if DEFER_REDUCTIONS else None        # this layer's seven gradient reductions, issued as ONE launch at the end
-    dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None, defer=red)       # [256,1024], [256]
     # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue: from the forward's sign bits
-    # (bf16: M N / 8 bytes of gate instead of re-reading h) or, in the fp32 build, from h itself
-    if hsign is not None:
-        dh = gemm_nt_signs(dy2, w2t, hsign, 1.0 / (1.0 - p))
+    # (bf16: M N / 8 bytes of gate instead of re-reading h) or, in the fp32 build, from h itself.  With the sign-bit kernel the
+    # backward of drop2 (dY2 = dropout_bwd(d_out)) rides on its operand load: one launch and one read of d_out less.
+    if hsign is not None and p > 0 and FOLD_DROPOUT_BWD:
+        dh, dy2 = gemm_nt_signs(d_out, w2t, hsign, 1.0 / (1.0 - p), drop_p=p, seed=seeds[1])
     else:
-        dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
+        dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
+        if hsign is not None:
+            dh = gemm_nt_signs(dy2, w2t, hsign, 1.0 / (1.0 - p))
+        else:
+            dh = gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
+    dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None, defer=red)       # [256,1024], [256]
     dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None, defer=red)      # [1024,256], [1024]
     # dXn2 = dH W1 and the backward of LN2 (+ the residual gradient) in one launch; the M x 256 product stays in LDS
     dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D), st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None, defer=red)

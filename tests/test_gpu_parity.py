@@ -261,6 +261,27 @@ def test_row_panel_kernels_multi_panel(ops, dt, M):
         assert torch.all(dh2.float()[nz] != 0)
 
 
+def test_gemm_nt_signs_with_dropout_backward_folded_in(ops):
+    """mtmp_gemm_nt_signs_drop (the FFN backward's dH product with drop2's backward applied to its operand in registers) against
+    mtmp_dropout_bwd followed by mtmp_gemm_nt_signs: the masked operand it hands on and dH are bit-identical."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    bf = torch.bfloat16
+    for M, p in ((4990, 0.1), (20001, 0.3), (64320, 0.1), (129, 0.5)):
+        x = torch.randn(M, 256, generator=g, device=DEV).to(bf)
+        gam, bet = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+        w1 = (torch.randn(1024, 256, generator=g, device=DEV) / 16).to(bf)
+        w2t = (torch.randn(1024, 256, generator=g, device=DEV) / 16).to(bf)
+        dy = torch.randn(M, 256, generator=g, device=DEV).to(bf)
+        _, _, _, signs = ops.ln_gemm(x, gam, bet, w1, None, 1024, relu=True, drop_p=p, seed=77, want_signs=True)
+        dy2_ref = ops.dropout_bwd(dy, 1234, p)
+        dh_ref = ops.gemm_nt_signs(dy2_ref, w2t, signs, 1.0 / (1.0 - p))
+        dh, dy2 = ops.gemm_nt_signs(dy, w2t, signs, 1.0 / (1.0 - p), drop_p=p, seed=1234)
+        assert torch.equal(dy2, dy2_ref), f"masked operand differs (M={M}, p={p})"
+        assert torch.equal(dh, dh_ref), f"dH differs (M={M}, p={p})"
+        kept = float((dy2 != 0).float().mean())
+        assert abs(kept - (1 - p)) < 0.02
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("M,N,K", [(3456, 768, 256), (1000, 256, 1024), (70, 1024, 256), (20033, 256, 1024)])
 def test_gemm_tn_weight_gradient(ops, dt, M, N, K):
