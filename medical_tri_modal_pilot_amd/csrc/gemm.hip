@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
 // one barrier per stage.  Token tail: rows past m_end are fetched from the clamped last row and the dY rows are zeroed in LDS
 // (one stage per launch).  The bias gradient (column sums of dY) rides on the matrix pipe: dY^T x ones for one 32-column block
 // per matrix wave (+12 % MFMAs; from LDS with vector adds it cost 7 us of the launch wherever it was placed).
-// XT = 1 (shipped): 128 x 128 tiles, five stages of dY | X, matrix waves 64 x 64, 16.5 MB of partial slabs at config 2: 38 / 46 us
+// XT = 1 (shipped): 128 x 128 tiles, three stages of dY | X, matrix waves 64 x 64, 16.5 MB of partial slabs at config 2: 38 / 46 us
 // per launch (kernel trace).  XT = 2 (-DMTMP_TN_WIDE): 128 x 256 tiles, three stages of dY | X lo | X hi, matrix waves 64 x 128:
 // 297 instead of 396 MB from L2 into the CUs and 33 / 40 us per launch -- its pure-MFMA loop (no DMA, no reads, no barriers, no
 // stores) takes 19 us at the 1.88 GHz the chip holds -- but 33 MB of slabs, which the step's HBM-sharing streams pay for
@@ -1556,7 +1556,12 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
 constexpr int DT = 64;                                     // tokens per stage
 constexpr int DTILE = DT * 256;                            // bytes: one [DT][128] bf16 tile
 template <int XT> struct TnDma {
-    static constexpr int DNS = XT == 2 ? 3 : 5;            // stages
+    // three stages (96 KiB) rather than five (all 160 KiB): the loaders idle at the barrier either way, and 64 KiB of the CU stay
+    // free for the other streams' workgroups -- 8.80-8.82 against 8.85-8.88 ms/step and 9.03-9.11 against 9.07-9.14 (two boxes)
+#ifndef MTMP_TN_DNS
+#define MTMP_TN_DNS 3
+#endif
+    static constexpr int DNS = XT == 2 ? 3 : MTMP_TN_DNS;  // stages
     static constexpr int DSTAGE = (1 + XT) * DTILE;        // a stage = dY | X (lo | hi)
     static constexpr int DPW = 4 * (1 + XT);               // DMA pieces per loader wave and stage
     static constexpr int NB = 2 * XT;                      // 32-column X blocks per matrix wave
