@@ -51,10 +51,34 @@ def missing_to_num(missing: torch.Tensor, fullmodal_definition: str = "txt1_img1
     return inverse[tmpl.shape[0]:].type(torch.LongTensor), missing
 
 
-_MISSING_MEMO = {}
+class _MissingMemo:
+    """Pattern ids of the LAST device-resident ``missing`` tensor handed to the trainer.
+
+    A device-resident ``missing`` costs a D2H copy + host sync + H2D copy per step (the pattern ids are host logic, as in
+    the reference).  The memo answers only for the very same tensor OBJECT with an unchanged version counter, and it keeps
+    a reference to that tensor: its storage therefore cannot go back to the caching allocator and come back as another
+    batch's flags at the same address (round-2 finding: a key of (data_ptr, _version, shape, ...) alone matched a fresh
+    ``missing.to(device)`` of the next batch and returned the previous batch's ids)."""
+
+    def __init__(self):
+        self.tensor = self.version = self.ctx = self.value = None
+
+    def lookup(self, missing, ctx):
+        if self.tensor is missing and self.version == missing._version and self.ctx == ctx:
+            return self.value
+        return None
+
+    def store(self, missing, ctx, value):
+        self.tensor, self.version, self.ctx, self.value = missing, missing._version, ctx, value
+
+    def clear(self):
+        self.__init__()
 
 
-def _missing_ids(args, missing, device):
+_MISSING_MEMO = _MissingMemo()
+
+
+def _compute_missing_ids(args, missing, device):
     """missing flags -> pattern ids on `device` (reference trainer.py:53-77, 99-104), bounds-checked."""
     missing_num, _ = missing_to_num(missing, args.fullmodal_definition)
     if args.input_types == "vslt_txt":                                        # trainer.py:99-104
@@ -67,6 +91,18 @@ def _missing_ids(args, missing, device):
         # the reference gathers all_bottleneck_stack[missing, idx_order] from FOUR candidates (mbt_encoder.py:768-776)
         raise IndexError(f"modality pattern id {int(missing_num.max())} is out of bounds for the 4 bottleneck candidates")
     return missing_num.to(device, non_blocking=True)
+
+
+def _missing_ids(args, missing, device, memo=True):
+    """Pattern ids of ``missing`` on ``device``; device-resident flags go through _MISSING_MEMO (same object, same version)."""
+    if not (memo and missing.is_cuda):
+        return _compute_missing_ids(args, missing, device)
+    ctx = (str(device), args.fullmodal_definition, args.input_types)
+    hit = _MISSING_MEMO.lookup(missing, ctx)
+    if hit is None:
+        hit = _compute_missing_ids(args, missing, device)
+        _MISSING_MEMO.store(missing, ctx, hit)
+    return hit
 
 
 def _use_graph(args, flow_type, device, optimizer, scaler) -> bool:
@@ -187,15 +223,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         final_target = train_y[0].float().to(device, non_blocking=True)
     else:
         final_target = train_y.float().to(device, non_blocking=True)
-    # A device-resident `missing` costs a D2H copy + host sync + H2D copy per step here (the pattern ids are host logic, as in
-    # the reference).  The very same tensor (storage, version counter) handed in again maps to the very same ids: keep the last.
-    mkey = ((missing.data_ptr(), missing._version, tuple(missing.shape), missing.dtype, str(missing.device), str(device),
-             args.fullmodal_definition, args.input_types) if missing.is_cuda else None)
-    if mkey is not None and _MISSING_MEMO.get("key") == mkey:
-        missing_num = _MISSING_MEMO["value"]
-    else:
-        missing_num = _missing_ids(args, missing, device)
-        _MISSING_MEMO.update(key=mkey, value=missing_num if mkey is not None else None)
+    missing_num = _missing_ids(args, missing, device)
     static_x = static_x.permute(1, 0)
     age = static_x[1].float().to(device, non_blocking=True)
     gender = static_x[0].float().to(device, non_blocking=True)

@@ -111,6 +111,36 @@ def test_missing_num_bit_exact():
             assert torch.equal(got, want)
 
 
+def test_missing_memo_answers_only_for_the_same_tensor_object_and_version():
+    """the memo of a device-resident `missing` must not match another tensor that merely reuses the address."""
+    from medical_tri_modal_pilot_amd.builder.trainer import trainer as T
+    memo = T._MissingMemo()
+    a = torch.tensor([[0., 1., 1.], [0., 0., 0.]])
+    ctx = ("cpu", "txt1_img1", "vslt_img_txt")
+    assert memo.lookup(a, ctx) is None
+    memo.store(a, ctx, "ids-a")
+    assert memo.lookup(a, ctx) == "ids-a"
+    assert memo.tensor is a                                 # holds the tensor: its storage cannot be recycled
+    assert memo.lookup(a, ("cpu", "txt1", "vslt_img_txt")) is None
+    b = a.clone()                                           # equal content, other object: no hit
+    assert memo.lookup(b, ctx) is None
+    a[0, 1] = 0.                                            # in-place write bumps the version counter
+    assert memo.lookup(a, ctx) is None
+    memo.store(a, ctx, "ids-a2")
+    view = a[:]                                             # a view is another object
+    assert memo.lookup(view, ctx) is None
+    memo.clear()
+    assert memo.lookup(a, ctx) is None
+    # host tensors never go through the memo: two different batches in a row
+    args = _args()
+    T._MISSING_MEMO.clear()
+    m1 = torch.tensor([[0., 1., 1.], [0., 0., 0.], [0., 0., 1.], [0., 1., 0.]])
+    m2 = torch.tensor([[0., 0., 0.], [0., 1., 1.], [0., 1., 0.], [0., 0., 1.]])
+    assert T._missing_ids(args, m1, "cpu").tolist() == [3, 0, 1, 2]
+    assert T._missing_ids(args, m2, "cpu").tolist() == [0, 3, 2, 1]
+    assert T._MISSING_MEMO.tensor is None
+
+
 def test_key_lengths_bit_exact():
     from medical_tri_modal_pilot_amd.builder.models.src.transformer.mbt_encoder import TrimodalTransformerEncoder_MBT
     from oracle import tri_mbt_oracle as O
