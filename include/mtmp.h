@@ -37,10 +37,18 @@ const char* mtmp_last_error(void);
  * q,k,v: [B,N,ld_qkv] (head h = columns [64h,64h+64)); o: [B,N,ld_o]; kv_len: int32[B] valid
  * keys per sample (NULL = unmasked; 0 = fully masked -> uniform average, as the reference);
  * lse: float[B,H,N] out (log2 units, consumed by mtmp_attn_bwd).  If res/o_res are non-NULL,
- * o_res = o + res (the "outputs += residual" of encoder.py:27). */
+ * o_res = o + res (the "outputs += residual" of encoder.py:27).
+ * key_norms (may be NULL): float[ceil(B N / 32)][H], max ||k_h||_2 over each block of 32 consecutive rows of the [B N] token
+ * space (mtmp_key_norms, or the epilogue of the projection that produced k).  With it a wave whose queries satisfy
+ * ||q|| max||k|| scale log2(e) <= 64 skips the running maximum of the softmax altogether (exp2 cannot leave the f32 range
+ * and the softmax is shift invariant: same result, ~40 % fewer vector instructions); other waves, and every wave when it is
+ * NULL, run the online-maximum form. */
 int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res, void* o_res,
-                  float* lse, const int32_t* kv_len, int B, int N, int H, int ld_qkv, int ld_o, float scale,
-                  void* stream);
+                  float* lse, const int32_t* kv_len, const float* key_norms, int B, int N, int H, int ld_qkv, int ld_o,
+                  float scale, void* stream);
+/* out[ceil(rows / 32)][H] = max over each 32-row block of ||k[row, 64h : 64h + 64]||_2 (k: [rows, ld]). */
+long long mtmp_key_norms_floats(long long rows, int H);
+int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream);
 
 /* Backward of the above: dq,dk,dv [B,N,ld_dqkv] from d_o [B,N,ld_do]; o is the forward output.
  * delta_ws: float[B*H*N] scratch. */

@@ -17,7 +17,9 @@ F32, BF16 = 0, 1
 SIGNATURES = {
     "mtmp_abi_version": (c_int, []),
     "mtmp_last_error": (c_char_p, []),
-    "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
+    "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 9 + [c_int] * 5 + [c_float, c_void_p]),
+    "mtmp_key_norms_floats": (c_longlong, [c_longlong, c_int]),
+    "mtmp_key_norms": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
     "mtmp_ln_gemm": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_float, c_uint, c_void_p, c_void_p]),
     "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_void_p, c_float, c_void_p, c_int,

@@ -22,23 +22,6 @@
 #include <math.h>
 #include <type_traits>
 
-// Diagnostic build only (make stamp): s_memtime stamps around the phases of the forward loop.
-#ifdef MTMP_STAMP
-__device__ unsigned long long g_stamp[8];
-#define STAMP(var)                                                                                   \
-    {                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                  \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-    }
-#define STAMP_DECL unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa = 0, sb = 0, sc = 0, sd = 0;
-#define STAMP_ACC  { sa += ts1 - ts0; sb += ts2 - ts1; sc += ts3 - ts2; sd += ts4 - ts3; }
-#else
-#define STAMP(var)
-#define STAMP_DECL
-#define STAMP_ACC
-#endif
-
 namespace {
 
 constexpr int DH = 64;       // head dim: d_model 256 / 4 heads (tri_mbt_vsltcls.py:29-30)
@@ -50,6 +33,7 @@ template <typename T> struct AttnArgs {
     const T* q; const T* k; const T* v;
     T* o; const T* res; T* o_res;
     float* lse; const int* kv_len;
+    const float* knorm;      // [ceil(B N / 32)][H]: max ||k_h||_2 over each 32-row block of the [B N] token rows, or NULL
     int B, N, H, ld_qkv, ld_o;
     float scale;
 };
@@ -115,23 +99,29 @@ MTMP_DEV float half_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 // =============================== forward ====================================
-// Per 64-key tile and wave (32 queries, query = lane):  S^T = K Q^T (8 MFMA), row max (v_max3), rescale
-// decision (wave-uniform, rare after the first tiles), p = exp2(s*c2 - m), row sum, O^T += V^T P^T (8 MFMA,
-// P^T straight from the accumulator registers).  The kernel is VALU-issue-bound at d_h = 64 (per score:
-// fma 4 + exp 8 + add 4 + max 2 + cvt 2.25 issue cycles against 16 cycles of matrix pipe, PMC: vector issue
-// ~60 %, MFMA ~30 % busy), so the loop carries no masks, clamps or address arithmetic: full tiles run a
-// mask-free body on running pointers, the ragged last tile a second copy of the body.
-// (Measured and rejected here, round 1: the running maximum as the C operand of the score MFMAs -- saves the fma but
-//  its 16 registers cost the fourth wave per SIMD: 116-121 us against 107; 256-query workgroups with two
-//  query blocks per wave software-pipelined against each other, double-buffered LDS: 128 us.
-//  Round 2, same harness (tools/bench_kernels.py, 114-122 us for this kernel on gaussian data), all correct against the
-//  oracle, none faster -- DESIGN.md section 4 has the counters behind it: 64 queries per wave at two waves per SIMD
-//  with the four 32 x 32 sub-blocks of a tile software-pipelined in the wave, one barrier per tile: 127-131 us;
-//  K / V tiles by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled unpadded images, tools/dbg/dma_probe), two stages:
-//  116-120 us, three stages at three workgroups per CU: 110-117 us; three or two workgroups per CU with the register
-//  budget that buys: 126-127 us; a start stagger or static priorities by hardware wave slot: no change; the row sums
-//  on the matrix pipe (an all-ones V^T block, 4 more MFMAs and 32 vector adds fewer per tile): 120-124 us at three
-//  workgroups per CU, 165 us at four (225 spilled registers).)
+// Workgroup = 4 waves = 256 query rows; a wave owns 64 of them (two 32-query blocks, query = lane) and walks the
+// keys in 64-key tiles staged through a double-buffered LDS pair (one barrier per tile; the next tile's global loads
+// are issued two tiles ahead into registers).  Per tile a wave runs four 32 x 32 "units" (query block qb, key block kb):
+//     S^T = K Q^T (4 MFMA)  ->  softmax numerators p, row sum  ->  O^T += V^T P^T (4 MFMA, P^T straight from the
+//     accumulator registers)
+// K / V fragments of a key block are read from LDS once and serve both query blocks (half the LDS bytes per MFMA of the
+// 32-query waves this kernel had through round 2: with the vector work cut down, LDS was the next co-limiter).
+//
+// At d_h = 64 the loop is bound by the vector port, not by the matrix pipe (round-2 counters: 13 vector instructions per
+// MFMA, vector port 61 % busy, matrix pipe 32 %), so there are TWO bodies:
+//
+//   bounded ("fast") body -- softmax is shift invariant and the running maximum exists only to keep exp() in range.
+//     When |s| <= ||q|| ||k|| is known to stay below FAST_BOUND (log2 units) for every query of the wave, exp2(s) can
+//     neither overflow nor lose the row's largest terms, so the body is  p = exp2(s), l += p  and nothing else: no row
+//     maximum (24 v_max3 + cross-half swap), no s*c2 - m (32 fma), no rescale branch.  The softmax scale and log2(e)
+//     are folded into the Q fragments once per wave.  LSE = log2(l) (reference point 0) stays exact.
+//     The units of a tile are software-pipelined inside the wave: the score MFMAs of unit u+1 and the P.V MFMAs of unit
+//     u-1 are issued around the exponentials of unit u (sched_group_barrier lays out 1 MFMA : 2 exp : 3 VALU).
+//     The bound comes from p.knorm: max ||k_h|| per 32-token block, a by-product of the Q/K/V projection's epilogue
+//     (mtmp_ln_gemm_qkv) or of mtmp_key_norms; ||q|| is computed here from the fragments the lane holds.
+//   online body -- the classic running maximum with a deferred (exact) rescale; taken per WAVE when the bound is
+//     missing (knorm == NULL), too large, or not finite.  Both bodies have the same barrier structure, so the waves
+//     of one workgroup may differ.
 template <typename T> struct TileR { Frag<T> a, b; };
 
 template <typename T> MTMP_DEV void put_rows_r(T* dst, const TileR<T>& t, int tid) {
@@ -151,12 +141,31 @@ MTMP_DEV void put_tr_r(float* dst, const TileR<float>& t, int tid) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) *reinterpret_cast<f32x2*>(d + e * LDT) = f32x2{t.a.v[e], t.b.v[e]};
 }
+template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
+    Frag<T> r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
+    return r;
+}
+MTMP_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// |scaled score| (log2 units) up to which the bounded body is taken: exp2(+-64) and sums of a few thousand such terms
+// (times |v|) are far inside the f32 / bf16 exponent range (2^+-126), and a row whose scores are all near -64 still
+// keeps 60 binades below its largest term.
+constexpr float FAST_BOUND = 64.0f;
+constexpr int FWD_QW = 64;                      // query rows per wave
+constexpr int FWD_QWG = 4 * FWD_QW;             // ... per workgroup
+
+template <typename T> constexpr int fwd_stage_elems() { return KT * LDT + tr_elems<T>(); }     // one K + V^T image pair
+
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]   keys x dh
-    T* sVt = sK + KT * LDT;                   // V image for the transposed role (frag_tr)
-    const int nqt = (p.N + 127) >> 7;
+    T* sbase = reinterpret_cast<T*>(smem_raw);       // 2 x { K rows [KT][LDT] | V image for the transposed role }
+    const int nqt = (p.N + FWD_QWG - 1) / FWD_QWG;
     const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -168,15 +177,41 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
     if (uniform) kvl = p.N;
     const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
-    const int qrow = qt * 128 + wave * 32 + r;
-    Frag<T> qf[4];
+    const int q0w = qt * FWD_QWG + wave * FWD_QW;          // first query row of this wave
+    Frag<T> qf[2][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
-        qf[c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half),
-                          qrow < p.N && !uniform);
-    f32x16 o0 = {0}, o1 = {0};
-    float m = -INFINITY, l = 0.f;
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = q0w + 32 * qb + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            qf[qb][c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half),
+                                  qrow < p.N && !uniform);
+    }
     const float c2 = p.scale * LOG2E;
+    // ---- which body?  (wave-uniform)
+    bool fast = false;
+    if (p.knorm) {
+        float qs = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = fmaf(to_f32(qf[qb][c].v[j]), to_f32(qf[qb][c].v[j]), s);
+            qs = fmaxf(qs, s);
+        }
+        qs = half_sum(qs) ;                                   // >= either row's ||q||^2 (the half-lanes hold half rows)
+        const int blk0 = (b * p.N) >> 5, blk1 = (b * p.N + p.N - 1) >> 5;
+        float km = 0.f;
+        for (int i = blk0 + lane; i <= blk1; i += 64) km = fmaxf(km, p.knorm[(size_t)i * p.H + hd]);
+        km = wave_max(km);
+        // 1.02: the key norms may have been taken before the keys were rounded to bf16, q * c2 is rounded again below
+        const float bound = sqrtf(qs) * km * (c2 * 1.02f);
+        fast = wave_all(bound <= FAST_BOUND);                 // (a NaN anywhere fails the comparison: online body)
+    }
+    f32x16 o[2][2] = {{{0}, {0}}, {{0}, {0}}};                // [query block][dh half]
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     const int nfull = kvl / KT, ntiles = (kvl + KT - 1) / KT;
     int ra, rb, col;
     tile_map<T>(tid, ra, rb, col);
@@ -185,9 +220,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
     const T* kpb = Kb + (size_t)rb * p.ld_qkv + col;
     const ptrdiff_t kv_off = Vb - Kb;
     TileR<T> kreg, vreg;
-    // global -> registers, one tile ahead (the loads fly under the MFMAs of the current tile); rows of the
-    // ragged last tile are clamped to kv_len - 1: keys past kv_len are never read, their scores are masked
-    // and their P is 0, so whatever finite row stands in for them adds nothing.
+    // global -> registers, two tiles ahead of the MFMAs; rows of the ragged last tile are clamped to kv_len - 1: keys
+    // past kv_len are never read, their scores are masked and their P is 0, so whatever finite row stands in for
+    // them adds nothing.
     auto fetch = [&](int t) {
         if (t < nfull) {
             kreg.a = frag_load<T>(kpa); kreg.b = frag_load<T>(kpb);
@@ -200,114 +235,190 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
             vreg.a = frag_load<T>(ka + kv_off); vreg.b = frag_load<T>(kb_ + kv_off);
         }
     };
-    fetch(0);
-    STAMP_DECL
-    auto body = [&](int it, auto tail_tag) {
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        STAMP(ts0)
-#ifndef MTMP_ABLATE_BARRIER                    // (ablation builds: results are wrong by design, only the timing is read)
-        __syncthreads();
-#endif
-#ifndef MTMP_ABLATE_PUT
+    auto put = [&](int t) {
+        T* sK = sbase + (t & 1) * fwd_stage_elems<T>();
         put_rows_r<T>(sK, kreg, tid);
-        put_tr_r(sVt, vreg, tid);
-#endif
-#ifndef MTMP_ABLATE_BARRIER
+        put_tr_r(sK + KT * LDT, vreg, tid);
+    };
+    fetch(0);
+    put(0);
+    if (ntiles > 1) fetch(1);
+    // start of tile `it`: its images become visible, the other buffer is free for tile it + 1
+    auto tile_begin = [&](int it) {
         __syncthreads();
-#endif
-        STAMP(ts1)
-#ifndef MTMP_ABLATE_FETCH                      // (ablation builds: tools/ablate_attn.sh -- never shipped)
-        if (it + 1 < ntiles) fetch(it + 1);
-#endif
-        f32x16 st[2];
-        tile_qk<T>(st[0], sK, r, half, qf);
-        tile_qk<T>(st[1], sK + 32 * LDT, r, half, qf);
-        if (TAIL) {
-            const int k0 = it * KT;
+        if (it + 1 < ntiles) put(it + 1);
+        if (it + 2 < ntiles) fetch(it + 2);
+    };
+    auto load_k = [&](const T* sK, int kb, Frag<T> (&ka)[4]) {
+        const T* arow = sK + (32 * kb + swz23(r)) * LDT + 8 * half;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int c = 0; c < 4; ++c) ka[c] = frag_load<T>(arow + 16 * c);
+    };
+    auto load_v = [&](const T* sV, int kb, Frag<T> (&vt)[2][2]) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t)
-                    if (k0 + 32 * kb + acc_row_swz(t, half) >= kvl) st[kb][t] = -INFINITY;
+        for (int s = 0; s < 2; ++s) {
+            vt[s][0] = frag_tr(sV, 32 * kb + 16 * s, 0, lane);
+            vt[s][1] = frag_tr(sV, 32 * kb + 16 * s, 32, lane);
         }
-        STAMP(ts2)
-        // v_max3 is inline asm, which the compiler's hazard recogniser does not see: an asm instruction that
-        // reads an MFMA result too early gets whatever the register holds (found as run-to-run 1-ulp noise:
-        // a wrong maximum is still a valid softmax shift).  `seed` is an ordinary instruction on the LAST
-        // accumulator written, so the required wait states are inserted in front of it, and every asm below
-        // depends on it.
-#ifdef MTMP_ABLATE_MAX
-        const float mx = (st[0][15] + st[1][15]) * c2;
-#else
-        const float seed = fmaxf(st[0][15], st[1][15]);
-        float mxa = max3(seed, st[0][0], st[0][1]), mxb = max3(seed, st[1][0], st[1][1]);
+    };
+    auto scores = [&](f32x16& st, const Frag<T> (&ka)[4], int qb) {
+        st = mma0<T>(ka[0], qf[qb][0]);
 #pragma unroll
-        for (int t = 2; t < 14; t += 2) {       // two independent chains
-            mxa = max3(mxa, st[0][t], st[0][t + 1]);
-            mxb = max3(mxb, st[1][t], st[1][t + 1]);
-        }
-        const float mx = half_max(max3(mxa, mxb, fmaxf(st[0][14], st[1][14]))) * c2;
-#endif
-        // Deferred rescale (exact): O, l and m move only when some row's maximum grew; while it has
-        // not, p = exp2(s - m) <= 1 still holds.  Wave-uniform branch, rare after the first tiles.
-        if (!wave_all(mx <= m)) {
-            const float m_new = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - m_new);
-            l *= alpha; o0 *= alpha; o1 *= alpha;
-            m = m_new;
-        }
+        for (int c = 1; c < 4; ++c) mma<T>(st, ka[c], qf[qb][c]);
+    };
+    auto mask_tail = [&](f32x16& st, int k0) {           // ragged last tile: keys >= kv_len drop out
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int t = 0; t < 16; ++t)
+            if (k0 + acc_row_swz(t, half) >= kvl) st[t] = -INFINITY;
+    };
+    auto pv = [&](int qb, const Frag<T> (&pf)[2], const Frag<T> (&vt)[2][2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            mma<T>(o[qb][0], vt[s][0], pf[s]);
+            mma<T>(o[qb][1], vt[s][1], pf[s]);
+        }
+    };
+    if (fast) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qf[qb][c] = frag_scale<T>(qf[qb][c], c2);
+        auto soft = [&](f32x16& st, int qb, Frag<T> (&pf)[2]) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-#ifdef MTMP_ABLATE_EXP
-                const float pv = fmaf(st[kb][t], c2, -m);
-#else
-                const float pv = fast_exp2(fmaf(st[kb][t], c2, -m));
-#endif
-                l += pv;
-                st[kb][t] = pv;
+                const float e = fast_exp2(st[t]);
+                l[qb] += e;
+                st[t] = e;
             }
-        STAMP(ts3)
+            pf[0] = frag_from_acc<T>(st, 0);
+            pf[1] = frag_from_acc<T>(st, 1);
+        };
+        // one MFMA : two exponentials : three plain vector instructions (2 adds + 1 conversion), eight times
+        auto interleave = [&]() {
+            if (sizeof(T) == 2) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const Frag<T> pf = frag_from_acc<T>(st[kb], s);
-                mma<T>(o0, frag_tr(sVt, 32 * kb + 16 * s, 0, lane), pf);
-                mma<T>(o1, frag_tr(sVt, 32 * kb + 16 * s, 32, lane), pf);
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
             }
-        STAMP(ts4)
-        STAMP_ACC
-    };
-    for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
-    if (ntiles > nfull) body(nfull, std::true_type{});
-#ifdef MTMP_STAMP
-    if (lane == 0) {
-        atomicAdd(&g_stamp[0], sa); atomicAdd(&g_stamp[1], sb); atomicAdd(&g_stamp[2], sc); atomicAdd(&g_stamp[3], sd);
-        atomicAdd(&g_stamp[4], (unsigned long long)ntiles);
+        };
+        auto body = [&](int it, auto tail_tag) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+            tile_begin(it);
+            const T* sK = sbase + (it & 1) * fwd_stage_elems<T>();
+            const T* sV = sK + KT * LDT;
+            const int k0 = it * KT;
+            f32x16 s00, s10, s01, s11;                       // s<qb><kb>
+            Frag<T> ka0[4], ka1[4], vt0[2][2], vt1[2][2], p00[2], p10[2], p01[2], p11[2];
+            load_k(sK, 0, ka0);
+            load_k(sK, 1, ka1);
+            scores(s00, ka0, 0);
+            if (TAIL) mask_tail(s00, k0);
+            __builtin_amdgcn_sched_barrier(0);
+            scores(s10, ka0, 1);                             // slot 1: S(1,0) || softmax(0,0)
+            if (TAIL) mask_tail(s10, k0);
+            soft(s00, 0, p00);
+            load_v(sV, 0, vt0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            scores(s01, ka1, 0);                             // slot 2: S(0,1) + PV(0,0) || softmax(1,0)
+            if (TAIL) mask_tail(s01, k0 + 32);
+            pv(0, p00, vt0);
+            soft(s10, 1, p10);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            scores(s11, ka1, 1);                             // slot 3: S(1,1) + PV(1,0) || softmax(0,1)
+            if (TAIL) mask_tail(s11, k0 + 32);
+            pv(1, p10, vt0);
+            soft(s01, 0, p01);
+            load_v(sV, 1, vt1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            pv(0, p01, vt1);                                 // slot 4: PV(0,1) || softmax(1,1)
+            soft(s11, 1, p11);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            pv(1, p11, vt1);                                 // slot 5
+        };
+        for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
+        if (ntiles > nfull) body(nfull, std::true_type{});
+        m[0] = m[1] = 0.f;
+    } else {
+        auto body = [&](int it, auto tail_tag) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+            tile_begin(it);
+            const T* sK = sbase + (it & 1) * fwd_stage_elems<T>();
+            const T* sV = sK + KT * LDT;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Frag<T> ka[4], vt[2][2];
+                load_k(sK, kb, ka);
+                load_v(sV, kb, vt);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    f32x16 st;
+                    scores(st, ka, qb);
+                    if (TAIL) mask_tail(st, it * KT + 32 * kb);
+                    // v_max3 is inline asm, which the compiler's hazard recogniser does not see: an asm instruction
+                    // that reads an MFMA result too early gets whatever the register holds.  `seed` is an ordinary
+                    // instruction on the LAST accumulator register written, so the required wait states are inserted
+                    // in front of it, and every asm below depends on it.
+                    const float seed = fmaxf(st[15], st[14]);
+                    float mxa = max3(seed, st[0], st[1]), mxb = max3(seed, st[2], st[3]);
+#pragma unroll
+                    for (int t = 4; t < 12; t += 4) {
+                        mxa = max3(mxa, st[t], st[t + 1]);
+                        mxb = max3(mxb, st[t + 2], st[t + 3]);
+                    }
+                    const float mx = half_max(max3(mxa, mxb, fmaxf(st[12], st[13]))) * c2;
+                    // Deferred rescale (exact): O, l and m move only when some row's maximum grew; while it has
+                    // not, p = exp2(s - m) <= 1 still holds.  Wave-uniform branch, rare after the first tiles.
+                    if (!wave_all(mx <= m[qb])) {
+                        const float m_new = fmaxf(m[qb], mx);
+                        const float alpha = fast_exp2(m[qb] - m_new);
+                        l[qb] *= alpha; o[qb][0] *= alpha; o[qb][1] *= alpha;
+                        m[qb] = m_new;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const float e = fast_exp2(fmaf(st[t], c2, -m[qb]));
+                        l[qb] += e;
+                        st[t] = e;
+                    }
+                    Frag<T> pf[2] = {frag_from_acc<T>(st, 0), frag_from_acc<T>(st, 1)};
+                    pv(qb, pf, vt);
+                }
+            }
+        };
+        for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
+        if (ntiles > nfull) body(nfull, std::true_type{});
     }
-#endif
-    l = half_sum(l);
     // Epilogue.  A lane owns one query and 4-element pieces of its O row, so direct stores would be 8-byte pieces
     // at a row stride -- partial-line writes (PMC: 72 MB written per launch for a 33 MB output).  The wave's
-    // 32 x 64 tile goes through a wave-private LDS tile instead and leaves as whole 128-byte head rows.
-    __syncthreads();                                  // all waves are done with sK / sVt: reuse them as staging
-    T* sO = reinterpret_cast<T*>(smem_raw) + wave * 32 * LDT;
-    const float inv = 1.0f / l;
+    // 64 x 64 tile goes through a wave-private LDS tile instead and leaves as whole 128-byte head rows.
+    __syncthreads();                                  // all waves are done with the K / V images: reuse them as staging
+    T* sO = reinterpret_cast<T*>(smem_raw) + wave * FWD_QW * LDT;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int qb = 0; qb < 2; ++qb) {
+        l[qb] = half_sum(l[qb]);
+        const float inv = 1.0f / l[qb];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x16& o = dt ? o1 : o0;
-            store4<T>(sO + r * LDT + 32 * dt + 8 * g + 4 * half, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv,
-                      o[4 * g + 3] * inv);
-        }
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& ov = o[qb][dt];
+                store4<T>(sO + (32 * qb + r) * LDT + 32 * dt + 8 * g + 4 * half, ov[4 * g] * inv, ov[4 * g + 1] * inv,
+                          ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
+            }
+        const int qrow = q0w + 32 * qb + r;
+        if (qrow < p.N && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m[qb] + log2f(l[qb]);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS, no barrier needed
     constexpr int CH = DH * (int)sizeof(T) / 16, RPP = 64 / CH;       // 16-byte chunks per row, rows per pass
-    const int q0w = qt * 128 + wave * 32;
 #pragma unroll
-    for (int ps = 0; ps < 32 / RPP; ++ps) {
+    for (int ps = 0; ps < FWD_QW / RPP; ++ps) {
         const int rl = ps * RPP + lane / CH, ch = lane % CH;
         if (q0w + rl < p.N) {
             const size_t off = ((size_t)b * p.N + q0w + rl) * p.ld_o + hd * DH + ch * (16 / (int)sizeof(T));
@@ -317,27 +428,46 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 4 : 1)) void attn_fwd_kernel
                 // residual epilogue (encoder.py:27 "outputs += residual"): the residual adds the
                 // value of O as stored (i.e. rounded to T), like the reference's tensor add.
                 constexpr int E = 16 / (int)sizeof(T);
-                T ob[E], rb[E], sb[E];
+                T ob[E], rbv[E], sb[E];
                 __builtin_memcpy(ob, &ov, 16);
                 const u32x4_t rvv = *reinterpret_cast<const u32x4_t*>(p.res + off);
-                __builtin_memcpy(rb, &rvv, 16);
+                __builtin_memcpy(rbv, &rvv, 16);
 #pragma unroll
-                for (int i = 0; i < E; ++i) sb[i] = from_f32<T>(to_f32(ob[i]) + to_f32(rb[i]));
+                for (int i = 0; i < E; ++i) sb[i] = from_f32<T>(to_f32(ob[i]) + to_f32(rbv[i]));
                 u32x4_t sv;
                 __builtin_memcpy(&sv, sb, 16);
                 *reinterpret_cast<u32x4_t*>(p.o_res + off) = sv;
             }
         }
     }
-    if (qrow < p.N && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m + log2f(l);
 }
 
-template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
-    Frag<T> r;
+// Max ||k_h||_2 per 32-token block and head of a [M, ld] key matrix (M = B N rows, head h = columns [64h, 64h + 64)):
+// the stand-alone producer of AttnArgs::knorm (the Q/K/V projection writes the same table from its epilogue).
+// One wave per block; 8 lanes read one 64-element head row.
+template <typename T> __global__ __launch_bounds__(256) void key_norms_kernel(const T* k, float* out, int M, int H, int ld) {
+    const int lane = threadIdx.x & 63, blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blk * 32 >= M) return;
+    const int rsub = lane >> 3, ch = lane & 7;
+    for (int h = 0; h < H; ++h) {
+        float best = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
-    return r;
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = min(blk * 32 + ps * 8 + rsub, M - 1);
+            const Frag<T> f = frag_load<T>(k + (size_t)row * ld + h * DH + 8 * ch);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = fmaf(to_f32(f.v[j]), to_f32(f.v[j]), s);
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            best = fmaxf(best, s);
+        }
+        best = fmaxf(best, __shfl_xor(best, 8, 64));
+        best = fmaxf(best, __shfl_xor(best, 16, 64));
+        best = fmaxf(best, __shfl_xor(best, 32, 64));
+        if (lane == 0) out[(size_t)blk * H + h] = sqrtf(best);
+    }
 }
+
 // ---- helpers of the backward kernels ----
 
 // 32x32 tile: C + A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
@@ -577,7 +707,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
                 sD[tid] = (q0 + tid < p.N) ? -dreg : 0.f;
             }
             __syncthreads();
-#ifndef MTMP_DKDV_NOFETCH                      // (ablation builds: tools/ablate_dkdv.sh -- never shipped)
             if (it + 1 < nq) {
                 qreg = qs.fetch(it + 1);
                 oreg = os.fetch(it + 1);
@@ -585,7 +714,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
                 lreg = Lb[qn];
                 dreg = Db[qn];
             }
-#endif
             if (kw0 < kvl) {                   // wave-uniform
                 // A 64-query tile = two 32-query blocks, software-pipelined INSIDE the wave so that the matrix pipe
                 // and the vector ALU run side by side (one wave's chain  reads -> S,dP -> exp/mul -> dV,dK  is serial,
@@ -719,7 +847,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     }
 }
 
-template <typename T> size_t fwd_smem() { return (size_t)(KT * LDT + tr_elems<T>()) * sizeof(T); }
+template <typename T> size_t fwd_smem() { return (size_t)2 * fwd_stage_elems<T>() * sizeof(T); }   // >= 4 x 64 x LDT staging rows
 template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T); }
 template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float); }
 
@@ -736,10 +864,10 @@ template <typename K> int set_smem(K kern, size_t bytes) {
 
 template <typename T>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, const void* res, void* o_res, float* lse,
-               const int* kv_len, int B, int N, int H, int ld_qkv, int ld_o, float scale, hipStream_t st) {
-    AttnArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (T*)o, (const T*)res, (T*)o_res, lse, kv_len,
+               const int* kv_len, const float* knorm, int B, int N, int H, int ld_qkv, int ld_o, float scale, hipStream_t st) {
+    AttnArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (T*)o, (const T*)res, (T*)o_res, lse, kv_len, knorm,
                   B, N, H, ld_qkv, ld_o, scale};
-    const int nwg = ((N + 127) / 128) * H * B;
+    const int nwg = ((N + FWD_QWG - 1) / FWD_QWG) * H * B;
     const size_t sm = fwd_smem<T>();
     if (int e = set_smem(attn_fwd_kernel<T>, sm)) return e;
     hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(nwg), dim3(256), sm, st, a);
@@ -770,17 +898,32 @@ bool attn_shape_ok(int B, int N, int H, int ld_a, int ld_b) {
 }  // namespace
 
 extern "C" int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res,
-                             void* o_res, float* lse, const int32_t* kv_len, int B, int N, int H, int ld_qkv,
-                             int ld_o, float scale, void* stream) {
+                             void* o_res, float* lse, const int32_t* kv_len, const float* key_norms, int B, int N, int H,
+                             int ld_qkv, int ld_o, float scale, void* stream) {
     MTMP_CHECK_ARG(q && k && v && o && lse, "mtmp_attn_fwd: null pointer");
     MTMP_CHECK_ARG((res == nullptr) == (o_res == nullptr), "mtmp_attn_fwd: res and o_res must be given together");
     MTMP_CHECK_ARG(attn_shape_ok(B, N, H, ld_qkv, ld_o), "mtmp_attn_fwd: bad shape B=%d N=%d H=%d ld=%d/%d", B, N, H,
                    ld_qkv, ld_o);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) return launch_fwd<float>(q, k, v, o, res, o_res, lse, kv_len, B, N, H, ld_qkv, ld_o, scale, st);
-    if (dtype == 1) return launch_fwd<bf16>(q, k, v, o, res, o_res, lse, kv_len, B, N, H, ld_qkv, ld_o, scale, st);
+    if (dtype == 0) return launch_fwd<float>(q, k, v, o, res, o_res, lse, kv_len, key_norms, B, N, H, ld_qkv, ld_o, scale, st);
+    if (dtype == 1) return launch_fwd<bf16>(q, k, v, o, res, o_res, lse, kv_len, key_norms, B, N, H, ld_qkv, ld_o, scale, st);
     mtmp_set_error("mtmp_attn_fwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
+}
+
+extern "C" long long mtmp_key_norms_floats(long long rows, int H) { return ((rows + 31) / 32) * H; }
+
+extern "C" int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream) {
+    MTMP_CHECK_ARG(k && out, "mtmp_key_norms: null pointer");
+    MTMP_CHECK_ARG(rows > 0 && rows < (1ll << 31) && H > 0 && H <= 4 && ld >= H * DH && (ld % 8) == 0,
+                   "mtmp_key_norms: bad shape rows=%lld H=%d ld=%d", rows, H, ld);
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (int)((rows + 31) / 32);
+    if (dtype == 0) hipLaunchKernelGGL(key_norms_kernel<float>, dim3((nblk + 3) / 4), dim3(256), 0, st, (const float*)k, out, (int)rows, H, ld);
+    else if (dtype == 1) hipLaunchKernelGGL(key_norms_kernel<bf16>, dim3((nblk + 3) / 4), dim3(256), 0, st, (const bf16*)k, out, (int)rows, H, ld);
+    else { mtmp_set_error("mtmp_key_norms: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_key_norms");
+    return MTMP_OK;
 }
 
 extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o,
@@ -800,12 +943,3 @@ extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void
     mtmp_set_error("mtmp_attn_bwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
-
-#ifdef MTMP_STAMP
-// diagnostic build: read and clear the accumulated phase cycles {puts+barriers, S, softmax, PV, tiles}
-extern "C" int mtmp_debug_stamps(unsigned long long* out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[8] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)) != hipSuccess;
-}
-#endif

@@ -336,8 +336,19 @@ def reduce_batch(pending):
     del pending[:]
 
 
-def attn_fwd(qkv, kv_len, res=None):
-    """qkv [B,N,768] (q|k|v), kv_len int32[B] or None -> (o[B,N,256], o+res | None, lse[B,4,N])."""
+def key_norms(qkv):
+    """qkv [B,N,768] -> float[ceil(B N / 32), 4]: max ||k_h||_2 per 32-token block (the table attn_fwd's bounded body needs;
+    the Q/K/V projection writes the same table from its epilogue, this is the stand-alone producer)."""
+    _gpu(qkv)
+    B, N, _ = qkv.shape
+    out = torch.empty(_lib.lib().mtmp_key_norms_floats(B * N, N_HEAD), dtype=torch.float32, device=qkv.device)
+    call("mtmp_key_norms", _dt(qkv), _p(qkv, D_MODEL * qkv.element_size()), _p(out), B * N, N_HEAD, qkv.stride(1), _stream())
+    return out.view(-1, N_HEAD)
+
+
+def attn_fwd(qkv, kv_len, res=None, knorm=None):
+    """qkv [B,N,768] (q|k|v), kv_len int32[B] or None -> (o[B,N,256], o+res | None, lse[B,4,N]).
+    knorm: the key-norm table of key_norms() / ln_gemm(want_knorm=True); None = the online-maximum body everywhere."""
     _gpu(qkv)
     B, N, _ = qkv.shape
     es = qkv.element_size()
@@ -345,7 +356,7 @@ def attn_fwd(qkv, kv_len, res=None):
     o_res = torch.empty_like(o) if res is not None else None
     lse = torch.empty(B, N_HEAD, N, dtype=torch.float32, device=qkv.device)
     call("mtmp_attn_fwd", _dt(qkv), _p(qkv), _p(qkv, D_MODEL * es), _p(qkv, 2 * D_MODEL * es), _p(o), _p(res),
-         _p(o_res), _p(lse), _p(kv_len), B, N, N_HEAD, qkv.stride(1), D_MODEL, D_HEAD ** -0.5, _stream())
+         _p(o_res), _p(lse), _p(kv_len), _p(knorm), B, N, N_HEAD, qkv.stride(1), D_MODEL, D_HEAD ** -0.5, _stream())
     return o, o_res, lse
 
 

@@ -62,11 +62,13 @@ DT = [torch.float32, torch.bfloat16]
 
 
 # ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("bounded", [False, True])
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("N,lens", [(54, None), (54, [54, 4, 30, 7]), (133, [133, 4, 5, 90]),
                                     (261, [261, 200, 4, 64]), (40, [0, 17, 40, 1]), (1005, [1005, 700]),
                                     (2005, [2005, 1290])])        # configs[4]: TIE-len 2000
-def test_attention_fwd_bwd(ops, dt, N, lens):
+def test_attention_fwd_bwd(ops, dt, N, lens, bounded):
+    """bounded: the forward gets the key-norm table, so every wave takes the maximum-free body (|score| <= ~12 here)."""
     g = torch.Generator().manual_seed(7 + N)
     B = 4 if lens is None else len(lens)
     qkv = torch.randn(B, N, 768, generator=g)
@@ -79,14 +81,80 @@ def test_attention_fwd_bwd(ops, dt, N, lens):
     (o_ref * w).sum().backward()
     qd = qkv.to(DEV, dt)
     kvd = None if kv is None else kv.to(DEV, torch.int32)
-    o, o_res, lse = ops.attn_fwd(qd, kvd, res=res.to(DEV, dt))
-    tag = f"attn[{str(dt)[6:]},N={N},{'mask' if lens else 'nomask'}{'' if not lens else lens[1]}]"
+    o, o_res, lse = ops.attn_fwd(qd, kvd, res=res.to(DEV, dt), knorm=ops.key_norms(qd) if bounded else None)
+    tag = f"attn[{str(dt)[6:]},N={N},{'mask' if lens else 'nomask'}{'' if not lens else lens[1]}{',bounded' if bounded else ''}]"
     check(tag + ".o", o.float(), o_ref, TOL[dt])
     check(tag + ".o_res", o_res.float(), o_ref.detach().to(dt).float() + res, TOL[dt])
     dqkv = ops.attn_bwd(qd, o, w.to(DEV, dt), lse, kvd)
     for i, nm in enumerate("qkv"):
         check(f"{tag}.d{nm}", dqkv[..., 256 * i:256 * (i + 1)].float(), q_ref.grad[..., 256 * i:256 * (i + 1)],
               TOL[dt] if dt == torch.float32 else 4e-2)
+
+
+def test_key_norms_table(ops):
+    g = torch.Generator().manual_seed(11)
+    for dt in DT:
+        for B, N in ((3, 45), (2, 133), (1, 32), (5, 7)):
+            qkv = (torch.randn(B, N, 768, generator=g) * torch.rand(B, N, 1, generator=g) * 3).to(dt)
+            got = ops.key_norms(qkv.to(DEV)).cpu()
+            k = qkv[..., 256:512].float().reshape(B * N, 4, 64).norm(dim=-1)            # [B N, 4]
+            nblk = (B * N + 31) // 32
+            want = torch.stack([k[32 * i:32 * i + 32].max(0).values for i in range(nblk)])
+            assert got.shape == want.shape
+            assert torch.allclose(got, want, rtol=1e-5, atol=0), (dt, B, N)
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_attention_bounded_body_adversarial(ops, dt):
+    """The maximum-free body of the forward and its per-wave fallback on inputs built to break them (cdna guide rule 26:
+    a data-dependent branch needs inputs that FORCE it): large norms (fallback), scores just inside the bound (huge and
+    tiny exponentials, no shift), one outlier query row inside a block of tame ones (waves of one workgroup split),
+    one-hot softmax rows, rows whose scores are all strongly negative.  Reference: the oracle in fp32 on the CPU."""
+    g = torch.Generator().manual_seed(23)
+    B, N = 3, 300
+    base = torch.randn(B, N, 768, generator=g)
+    lens = torch.tensor([300, 131, 64])
+    c2 = 0.125 * 1.4426950408889634
+
+    def run(qkv, tag, tol, expect=None):
+        qkv = qkv.to(dt).float()
+        o_ref = O.attention_core(qkv, lens)
+        qd = qkv.to(DEV, dt)
+        kn = ops.key_norms(qd)
+        o_b, _, lse_b = ops.attn_fwd(qd, lens.to(DEV, torch.int32), knorm=kn)
+        o_p, _, lse_p = ops.attn_fwd(qd, lens.to(DEV, torch.int32))
+        assert torch.isfinite(o_b).all() and torch.isfinite(lse_b).all(), tag
+        check(f"attn_adv[{str(dt)[6:]},{tag}].bounded", o_b.float(), o_ref, tol)
+        check(f"attn_adv[{str(dt)[6:]},{tag}].online", o_p.float(), o_ref, tol)
+        check(f"attn_adv[{str(dt)[6:]},{tag}].lse", lse_b, lse_p, 1e-5 if dt == torch.float32 else 2e-2)
+        # which body ran: the bound the kernel forms, per query row
+        qn = qkv[..., :256].reshape(B, N, 4, 64).norm(dim=-1)                                # [B,N,4]
+        kn_b = qkv[..., 256:512].reshape(B, N, 4, 64).norm(dim=-1).amax(1, keepdim=True)     # >= per-block table maxima of b
+        frac_fast = float(((qn * kn_b * c2 * 1.02) <= 64).float().mean())
+        if expect == "fallback":
+            assert torch.equal(o_b, o_p), tag                  # every wave took the online body: bit-identical
+            assert frac_fast == 0.0
+        if expect == "fast":
+            assert frac_fast == 1.0
+        return o_b
+
+    tol = TOL[dt]
+    run(base, "tame", tol, "fast")
+    x = base.clone(); x[..., :512] *= 3.2                       # ||q|| ||k|| c2 ~ 120: nobody qualifies
+    run(x, "large_norms", tol, "fallback")
+    x = base.clone(); x[..., :512] *= 1.7                       # bound ~ 35-45, scores up to ~ +-20: exp2 over 40 binades, unshifted
+    run(x, "near_bound", tol * (1 if dt == torch.float32 else 2), "fast")
+    x = base.clone(); x[1, 37, :256] *= 40.0; x[0, 290, :256] *= 25.0   # outlier query rows: their waves fall back, neighbours do not
+    run(x, "outlier_rows", tol)
+    x = base.clone()                                            # one-hot rows: query 5 of every sample matches key 9 at score ~ +45
+    x[:, 5, :256] = 0; x[:, 9, 256:512] = 0
+    x[:, 5, 0:256:64] = 17.0; x[:, 9, 256:512:64] = 15.0
+    run(x, "one_hot", tol)
+    x = base.clone()                                            # every score of head 2 strongly negative (~ -40 .. -50)
+    u = torch.randn(64, generator=g); u = u / u.norm()
+    x[..., 128:192] = 16.0 * u + 0.05 * x[..., 128:192]
+    x[..., 384:448] = -16.0 * u + 0.05 * x[..., 384:448]
+    run(x, "all_negative", tol)
 
 
 def test_attention_full_size_properties(ops):

@@ -130,7 +130,13 @@ def main():
         res, do = R(B, N, 256), R(B, N, 256)
         kv = torch.full((B,), N, dtype=torch.int32, device=DEV)
         f = 4.0 * B * 4 * N * N * 64
-        rec("attn_fwd[64,1005]", timeit(lambda: ops.attn_fwd(qkv, kv, res=res), a.rounds), f)
+        rec("attn_fwd[64,1005].online", timeit(lambda: ops.attn_fwd(qkv, kv, res=res), a.rounds), f)
+        kn = ops.key_norms(qkv)
+        rec("key_norms[64,1005]", timeit(lambda: ops.key_norms(qkv), a.rounds), bytes_=2.0 * B * N * 256)
+        rec("attn_fwd[64,1005].bounded", timeit(lambda: ops.attn_fwd(qkv, kv, res=res, knorm=kn), a.rounds), f)
+        qs = qkv * 0.35                # scores of the size a LayerNorm-fed projection produces
+        kn2 = ops.key_norms(qs)
+        rec("attn_fwd[64,1005].bounded.smallscores", timeit(lambda: ops.attn_fwd(qs, kv, res=res, knorm=kn2), a.rounds), f)
         o, _, lse = ops.attn_fwd(qkv, kv, res=res)
         rec("attn_bwd[64,1005]", timeit(lambda: ops.attn_bwd(qkv, o, do, lse, kv), a.rounds), 2.5 * f)
     # ---- streaming kernels
