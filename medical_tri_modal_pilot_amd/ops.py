@@ -742,7 +742,7 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     z2 = z.view(M, D)
     qkv, xn1, st1 = ln_gemm(z2, g1, b1, wqkv, bqkv, 3 * D)
     qkv = qkv.view(B, N, 3 * D)
-    o, r1, lse = attn_fwd(qkv, kv_len, res=z)
+    o, r1, lse = attn_fwd(qkv, kv_len, res=z, knorm=key_norms(qkv))
     r1_2 = r1.view(M, D)
     if FUSED_FFN_FWD and z.dtype == torch.bfloat16 and M >= FUSED_FFN_MIN_ROWS:
         out, h, xn2, st2, hsign = ffn_fwd(r1_2, g2, b2, w1c, c1, w2c, c2, drop_p=drop_p, seeds=seeds)
