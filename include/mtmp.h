@@ -69,6 +69,12 @@ int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const float* beta
                  void* y, void* xn, float* stats, int M, int N, int ldx, int ldy, float eps, int relu, float drop_p,
                  unsigned seed, const unsigned* seed_dev, void* stream);
 
+/* mtmp_ln_gemm for the Q/K/V projection of an encoder layer (w = [Wq; Wk; Wv], N = 768, ldy = 768, no activation) that
+ * also fills the key-norm table of mtmp_attn_fwd from its epilogue: key_norms[ceil(M / 32)][4] (mtmp_key_norms_floats(M, 4)
+ * floats).  Replaces module.py:138-144 + attention.py:68-70. */
+int mtmp_ln_gemm_qkv(int dtype, const void* x, const float* gamma, const float* beta, const void* w, const float* bias,
+                     void* y, void* xn, float* stats, float* key_norms, int M, int ldx, float eps, void* stream);
+
 /* y[M,N] = drop(act(a[M,K] w[N,K]^T + bias)) (+ res[M,N]); K % 8 == 0, N % 32 == 0; res must not alias y.
  * Second FFN conv + drop2 + residual (module.py:78-80, encoder.py:32).  With gate[M,N] != NULL the
  * result is gated: y = gate > 0 ? y * gate_scale : 0 -- the backward of ReLU (+ drop1) applied to

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mtmp_key_norms": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
     "mtmp_ln_gemm": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_float, c_uint, c_void_p, c_void_p]),
+    "mtmp_ln_gemm_qkv": (c_int, [c_int] + [c_void_p] * 9 + [c_int, c_int, c_float, c_void_p]),
     "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_void_p, c_float, c_void_p, c_int,
                              c_void_p]),
     "mtmp_sign_bits_bytes": (c_longlong, [c_int, c_int]),

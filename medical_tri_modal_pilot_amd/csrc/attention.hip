@@ -89,15 +89,6 @@ MTMP_DEV void tile_qk(f32x16& acc, const T* lds_rows, int r, int half, const Fra
     for (int c = 1; c < 4; ++c) mma<T>(acc, frag_load<T>(arow + 16 * c), bf[c]);
 }
 
-// max over the two half-waves (lane i <-> lane i + 32) without the LDS crossbar: v_permlane32_swap
-MTMP_DEV float half_max(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-MTMP_DEV float half_sum(float x) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 // =============================== forward ====================================
 // Workgroup = 4 waves = 256 query rows; a wave owns 64 of them (two 32-query blocks, query = lane) and walks the
 // keys in 64-key tiles staged through a double-buffered LDS pair (one barrier per tile; the next tile's global loads
@@ -146,11 +137,6 @@ template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) r.v[j] = from_f32<T>(to_f32(f.v[j]) * s);
     return r;
-}
-MTMP_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
 }
 // |scaled score| (log2 units) up to which the bounded body is taken: exp2(+-64) and sums of a few thousand such terms
 // (times |v|) are far inside the f32 / bf16 exponent range (2^+-126), and a row whose scores are all near -64 still

@@ -176,6 +176,20 @@ MTMP_DEV float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+MTMP_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// max / sum over the two half-waves (lane i <-> lane i + 32) without the LDS crossbar: v_permlane32_swap
+MTMP_DEV float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+MTMP_DEV float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 MTMP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // erf, Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7), branch free: the libm erff expands into
 // a multi-way branch per element inside GEMM epilogues.

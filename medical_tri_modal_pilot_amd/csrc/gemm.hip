@@ -57,6 +57,7 @@ template <typename T> struct GemmArgs {
     const float* row_scale;   // optional per-sample factor (row-mode StochasticDepth): y *= row_scale[row / rows_per_scale]
     int rows_per_scale;
     unsigned short* signs = nullptr;   // row-panel kernels (bf16): 1 bit per output, "y > 0" -- written by the forward, read as the gate
+    float* knorm = nullptr;            // Q/K/V projection (N = 768): [ceil(M / 32)][4] max ||k_h|| per 32-row block (attention.hip, AttnArgs::knorm)
 };
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread).  The loads are
@@ -459,7 +460,10 @@ template <int N> MTMP_DEV void gwait1(unsigned& a) { asm volatile("s_waitcnt vmc
 // gate traffic per launch at config 2 instead of 132 MB.  No LayerNorm in GATE mode (p.gamma == nullptr).
 // K / TORCH_LN / GELU: the same kernel as the frozen image encoder's LayerNorm + Linear (+ exact GELU) for the 384-wide stage
 // (swin_transformer.py:428-449: nn.LayerNorm -- biased variance, eps inside the root -- in front of qkv / mlp.0).
-template <bool RELU, bool DROP, bool GATE, bool SIGNS, int K = 256, bool TORCH_LN = false, bool GELU = false>
+// KNORM (the Q/K/V projection, N = 768 = [Wq; Wk; Wv], head h of K = panel 4 + h): the epilogue also sums the squares of a row's 64
+// key features (a lane holds 32 of them, its half-wave partner the rest) and keeps the maximum over the wave's 32 rows -- the
+// key-norm table that lets the attention forward drop its running maximum (attention.hip, bounded body) at no extra pass over K.
+template <bool RELU, bool DROP, bool GATE, bool SIGNS, int K = 256, bool TORCH_LN = false, bool GELU = false, bool KNORM = false>
 __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
     using T = bf16;
     using P = PanelDmaK<K>;
@@ -601,11 +605,14 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         for (int ps = 0; ps < P::PASSES; ++ps) *reinterpret_cast<u32x4_t*>(const_cast<char*>(tile_ptr(p.y, p.ldy, jp, gp, ps))) = d[ps];
     };
     // one 4-feature piece of an epilogue: activation / dropout / gate, sign bits, rounding, parked in the staging tile
+    float ksq = 0.f, kh0 = 0.f, kh1 = 0.f, kh2 = 0.f, kh3 = 0.f;      // KNORM: running square sum of the key panel in its epilogue; finished heads
+    bool kpanel = false;                                             // (wave-uniform) the epilogue's panel is a key head
     auto piece = [&](int g, int i4, const unsigned (&fld)[4], unsigned gate_bits, unsigned& sign_bits) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = acc[g][4 * i4 + i];
+            if (KNORM && kpanel) ksq = fmaf(v[i], v[i], ksq);
             if (SIGNS) {       // "positive and kept" as ONE lane mask: it selects the value and is shifted into the collection
                 unsigned long long lm = __builtin_amdgcn_ballot_w64(v[i] > 0.f);
                 if (DROP) lm &= __builtin_amdgcn_ballot_w64(fld[i] >= thr);
@@ -626,6 +633,13 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         }
         store4<T>(sS + r * P::FS + ucol(i4), v[0], v[1], v[2], v[3]);
     };
+    auto knorm_finish = [&](int je) {          // both groups of key panel je went through piece(): max over the wave's rows
+        if (je >= 4 && je < 8) {
+            const float mx = wave_max(half_sum(ksq));
+            if (je == 4) kh0 = mx; else if (je == 5) kh1 = mx; else if (je == 6) kh2 = mx; else kh3 = mx;
+        }
+        ksq = 0.f;
+    };
     // One phase = the 16 MFMAs of accumulator group gm of panel jm, issued in eight slices of two; between them (EPI) the
     // epilogue of group ge of panel je, cut into eight pieces of vector work: per 4 features [mask hash] and [ReLU / select /
     // round / park in the staging tile], and (PEND) the drain of the previous phase's tile.  sched_barrier(0) between slices
@@ -639,6 +653,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         constexpr int GW = decltype(gw_tag)::value;
         const size_t cur = (size_t)(((jm - j0) & 1) * P::panel_bytes + gm * P::group_bytes);
         const int n0 = je * P::NP;
+        if (KNORM) kpanel = EPI && je >= 4 && je < 8;
         if (GATE) gload_u16(gnext, signs_ptr(jm, gm));
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
@@ -674,7 +689,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
                 } else {
                     piece(ge, i4, fld, gcur, sign_bits);
                 }
-                constexpr int NV = DROP || GELU ? 9 : 3;
+                constexpr int NV = DROP || GELU ? 9 : (KNORM ? 5 : 3);
                 if (2 * s8 + 8 < KC) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
@@ -684,6 +699,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         }
         __builtin_amdgcn_sched_barrier(0);
         if (SIGNS && EPI) *signs_ptr(je, ge) = (unsigned short)sign_bits;
+        if (KNORM && EPI && ge == 1) knorm_finish(je);
     };
     // the last group's epilogue has no MFMAs left to hide under
     auto epi_alone = [&](int j, int g, int jp, int gp, unsigned& gcur) {
@@ -695,6 +711,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         if (GATE) gwait1<0>(gcur);
         const int n0 = j * P::NP;
         unsigned sign_bits = 0;
+        if (KNORM) kpanel = j >= 4 && j < 8;
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
             const int col = n0 + 32 * g + ucol(i4);
@@ -702,6 +719,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
             if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
             piece(g, i4, fld, gcur, sign_bits);
         }
+        if (KNORM) knorm_finish(j);
         if (SIGNS) *signs_ptr(j, g) = (unsigned short)sign_bits;
         wave_lds_handover();
         drain_load(dr);
@@ -740,6 +758,13 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     }
     epi_alone(j1 - 1, 1, j1 - 1, 0, g1bits);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the repeated last DMA must not outlive the workgroup's LDS)
+    if (KNORM && p.knorm && lane == 0 && m_wave < p.M) {          // heads whose panel this workgroup walked (gridDim.y may split them)
+        float* kn = p.knorm + (size_t)(m_wave >> 5) * 4;
+        if (j0 <= 4 && 4 < j1) kn[0] = sqrtf(kh0);
+        if (j0 <= 5 && 5 < j1) kn[1] = sqrtf(kh1);
+        if (j0 <= 6 && 6 < j1) kn[2] = sqrtf(kh2);
+        if (j0 <= 7 && 7 < j1) kn[3] = sqrtf(kh3);
+    }
 #ifdef MTMP_STAMP
     TSTAMP(ts2)
     if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
@@ -1880,8 +1905,10 @@ int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, int gate, hipStream_t st) {
                          (const void*)ln_gemm_dma_kernel<true, false, false, false>, (const void*)ln_gemm_dma_kernel<true, true, false, false>,
                          (const void*)ln_gemm_dma_kernel<true, false, false, true>, (const void*)ln_gemm_dma_kernel<true, true, false, true>,
                          (const void*)ln_gemm_dma_kernel<false, false, true, false>};
+    const bool knorm = a.knorm != nullptr;           // (the Q/K/V projection: no activation, no dropout, N = 768)
     const int which = gate ? 6 : signs ? 4 + (drop ? 1 : 0) : (relu ? 2 : 0) + (drop ? 1 : 0);
-    if (hipFuncSetAttribute(fs[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
+    const void* fk = (const void*)ln_gemm_dma_kernel<false, false, false, false, 256, false, false, true>;
+    if (hipFuncSetAttribute(knorm ? fk : fs[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
         mtmp_set_error("mtmp_ln_gemm: cannot raise dynamic LDS to %zu", P::lds_bytes);
         return MTMP_ERR_LAUNCH;
     }
@@ -1892,6 +1919,11 @@ int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, int gate, hipStream_t st) {
     const int need = (npanels + P::MAXP - 1) / P::MAXP;
     if (nsplit < need) nsplit = need;
     dim3 grid(mtiles, nsplit);
+    if (knorm) {
+        hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, 256, false, false, true>), grid, dim3(256), P::lds_bytes, st, a);
+        MTMP_CHECK_LAUNCH("mtmp_ln_gemm_qkv");
+        return MTMP_OK;
+    }
     switch (which) {
     case 0: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
     case 1: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, true, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
@@ -2237,6 +2269,24 @@ extern "C" int mtmp_ln_gemm(int dtype, const void* x, const float* gamma, const 
                             const float* bias, void* y, void* xn, float* stats, int M, int N, int ldx, int ldy,
                             float eps, int relu, float drop_p, unsigned seed, const unsigned* seed_dev, void* stream) {
     return ln_gemm_entry(dtype, x, gamma, beta, w, bias, y, xn, stats, M, N, ldx, ldy, eps, relu, drop_p, seed, seed_dev, nullptr, stream);
+}
+// The Q/K/V projection of an encoder layer (module.py:138-144 + attention.py:68-70; w = [Wq; Wk; Wv], N = 768) that also
+// writes the key-norm table of the attention forward's bounded body: key_norms[ceil(M / 32)][4] = max ||k_h|| per block of 32
+// token rows (mtmp_key_norms_floats(M, 4) floats).  bf16: from the projection's epilogue, no extra pass; fp32: the projection
+// followed by mtmp_key_norms (the parity build keeps the round-1 row-panel kernel).
+extern "C" int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream);
+extern "C" int mtmp_ln_gemm_qkv(int dtype, const void* x, const float* gamma, const float* beta, const void* w, const float* bias,
+                                void* y, void* xn, float* stats, float* key_norms, int M, int ldx, float eps, void* stream) {
+    MTMP_CHECK_ARG(x && gamma && beta && w && y && key_norms, "mtmp_ln_gemm_qkv: null pointer");
+    MTMP_CHECK_ARG(M > 0 && ldx >= 256 && ldx % 8 == 0, "mtmp_ln_gemm_qkv: bad shape M=%d ldx=%d", M, ldx);
+    if (dtype == 1) {
+        GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, gamma, beta, (bf16*)xn, stats,
+                         M, 768, 256, ldx, 768, 0, eps, 0.f, 0u, nullptr, nullptr, 1.f, 0, nullptr, 1, nullptr, key_norms};
+        return launch_ln_gemm_dma(a, 0, 0, (hipStream_t)stream);
+    }
+    if (int e = ln_gemm_entry(dtype, x, gamma, beta, w, bias, y, xn, stats, M, 768, ldx, 768, eps, 0, 0.f, 0u, nullptr, nullptr, stream)) return e;
+    const size_t es = dtype == 0 ? 4 : 2;
+    return mtmp_key_norms(dtype, (const char*)y + 256 * es, key_norms, M, 4, 768, stream);
 }
 // Sign bits of a ReLU projection (bf16 build of the row-panel kernels only): one bit per output, "y > 0", in the kernels'
 // private order; mtmp_sign_bits_bytes(M, N) bytes.  mtmp_ln_gemm_signs = mtmp_ln_gemm (relu = 1) that also writes them;

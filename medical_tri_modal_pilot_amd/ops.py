@@ -114,6 +114,20 @@ def ln_gemm(x2d, gamma, beta, w, bias, n_out, relu=False, drop_p=0.0, seed=0, wa
     return (y, xn, stats, None) if want_signs else (y, xn, stats)
 
 
+def ln_gemm_qkv(x2d, gamma, beta, wqkv, bqkv):
+    """The Q/K/V projection: (qkv[M,768], xn[M,256], stats[M,2], knorm[ceil(M/32),4]) -- ln_gemm plus the key-norm table of
+    the attention forward's bounded body, written from the projection's epilogue (bf16) or by mtmp_key_norms behind it (fp32)."""
+    _gpu(x2d, wqkv)
+    M = x2d.shape[0]
+    y = torch.empty(M, 3 * D_MODEL, dtype=x2d.dtype, device=x2d.device)
+    xn = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=x2d.device)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x2d.device)
+    knorm = torch.empty(_lib.lib().mtmp_key_norms_floats(M, N_HEAD), dtype=torch.float32, device=x2d.device)
+    call("mtmp_ln_gemm_qkv", _dt(x2d), _p(x2d), _p(gamma), _p(beta), _p(wqkv), _p(bqkv), _p(y), _p(xn), _p(stats), _p(knorm),
+         M, x2d.stride(0), LN_EPS, _stream())
+    return y, xn, stats, knorm.view(-1, N_HEAD)
+
+
 COPY_BATCH_MAX = 16
 
 
@@ -740,9 +754,9 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     g1, b1, g2, b2, c1, c2 = P[0], P[1], P[8], P[9], P[11], P[13]
     wqkv, bqkv, w1c, w2c, w2t, wqkvt, w1t = fused
     z2 = z.view(M, D)
-    qkv, xn1, st1 = ln_gemm(z2, g1, b1, wqkv, bqkv, 3 * D)
+    qkv, xn1, st1, knorm = ln_gemm_qkv(z2, g1, b1, wqkv, bqkv)
     qkv = qkv.view(B, N, 3 * D)
-    o, r1, lse = attn_fwd(qkv, kv_len, res=z, knorm=key_norms(qkv))
+    o, r1, lse = attn_fwd(qkv, kv_len, res=z, knorm=knorm)
     r1_2 = r1.view(M, D)
     if FUSED_FFN_FWD and z.dtype == torch.bfloat16 and M >= FUSED_FFN_MIN_ROWS:
         out, h, xn2, st2, hsign = ffn_fwd(r1_2, g2, b2, w1c, c1, w2c, c2, drop_p=drop_p, seeds=seeds)

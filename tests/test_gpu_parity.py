@@ -105,6 +105,27 @@ def test_key_norms_table(ops):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M", [64320, 6912, 17024, 300, 33, 4 * 133])
+def test_ln_gemm_qkv_key_norm_table(ops, dt, M):
+    """mtmp_ln_gemm_qkv = mtmp_ln_gemm (same qkv / xn / stats, bit for bit) + the key-norm table from its epilogue (bf16) or from
+    mtmp_key_norms behind it (fp32).  The fused table is taken BEFORE the keys are rounded to bf16: within 2^-8 of the table of
+    the stored keys (the attention kernel budgets 2 % for it)."""
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, 256, generator=g) * (1 + 3 * torch.rand(M, 1, generator=g))).to(DEV, dt)
+    gm, bt = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV), (0.1 * torch.randn(256, generator=g)).to(DEV)
+    w = (torch.randn(768, 256, generator=g) * 0.08).to(DEV, dt)
+    b = (torch.randn(768, generator=g) * 0.3).to(DEV)
+    y0, xn0, st0 = ops.ln_gemm(x, gm, bt, w, b, 768)
+    y1, xn1, st1, kn = ops.ln_gemm_qkv(x, gm, bt, w, b)
+    assert torch.equal(y0, y1) and torch.equal(xn0, xn1) and torch.equal(st0, st1)
+    ref = ops.key_norms(y1.view(1, M, 768))
+    assert kn.shape == ref.shape == ((M + 31) // 32, 4)
+    rel = float(((kn - ref).abs() / ref).max())
+    REPORT[f"ln_gemm_qkv.knorm[{str(dt)[6:]},M={M}]"] = {"rel_err": rel, "tol": 5e-3 if dt == torch.bfloat16 else 0.0}
+    assert rel <= (5e-3 if dt == torch.bfloat16 else 0.0), rel
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_attention_bounded_body_adversarial(ops, dt):
     """The maximum-free body of the forward and its per-wave fallback on inputs built to break them (cdna guide rule 26:
     a data-dependent branch needs inputs that FORCE it): large norms (fallback), scores just inside the bound (huge and
