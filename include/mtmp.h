@@ -46,6 +46,19 @@ const char* mtmp_last_error(void);
 int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res, void* o_res,
                   float* lse, const int32_t* kv_len, const float* key_norms, int B, int N, int H, int ld_qkv, int ld_o,
                   float scale, void* stream);
+/* Grouped forms: up to three token streams (vital signs / image / text of one fusion layer) in ONE launch -- the blocks of the
+ * short streams follow the long stream's in the same grid instead of occupying workgroup slots beside it from other HIP
+ * streams.  All pointer / int arrays are HOST arrays of n entries (1 <= n <= 3); res / o_res / kv_len / key_norms may be NULL
+ * as a whole or per entry; B, H, scale are common.  Same kernels, same results as n calls of the single forms. */
+int mtmp_attn_fwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v, void* const* o,
+                          const void* const* res, void* const* o_res, float* const* lse, const int32_t* const* kv_len,
+                          const float* const* key_norms, const int* N, const int* ld_qkv, const int* ld_o, int B, int H,
+                          float scale, void* stream);
+int mtmp_attn_bwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v,
+                          const void* const* o, const void* const* d_o, const float* const* lse, const int32_t* const* kv_len,
+                          void* const* dq, void* const* dk, void* const* dv, float* const* delta_ws, const int* N,
+                          const int* ld_qkv, const int* ld_o, const int* ld_do, const int* ld_dqkv, int B, int H, float scale,
+                          void* stream);
 /* out[ceil(rows / 32)][H] = max over each 32-row block of ||k[row, 64h : 64h + 64]||_2 (k: [rows, ld]). */
 long long mtmp_key_norms_floats(long long rows, int H);
 int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream);
@@ -261,22 +274,37 @@ int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, 
                                  const long long* missing, int resbottle, const float* d_prev_in, float* d_prev_out,
                                  void* stream);
 
-/* y[M,N] = act(LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias) with nn.LayerNorm semantics: norm1 -> qkv and norm2 -> mlp.0
- * (+ GELU) of the 384-wide Swin blocks (swin_transformer.py:428-449, :115-225) in one launch each.  bf16 only (dtype 1),
- * C = 384, N % 64 == 0; act: 0 none, 2 exact GELU; W bf16, ln_w / ln_b / bias fp32 (bias may be NULL). */
-int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias, void* y,
-                       long long M, int C, int N, float eps, int act, void* stream);
-
-/* The position-wise FFN of an encoder layer in one launch (bf16, d_model 256, d_ff 1024):
- *   h[M,1024] = drop1(relu(LN(x) w1^T + b1)),  out[M,256] = x + drop2(h w2^T + b2)
- * -- module.py:138-144 (custom LayerNorm), module.py:74-80 (the two k = 1 convolutions, ReLU, both dropouts) and the residual
- * of encoder.py:32.  Also written: h (the backward's dW2 operand), xn = LN(x) [M,256], stats[M,2] = (mean, 1/(std+eps)) and, when
- * signs != NULL, the sign bits of h (mtmp_sign_bits_bytes(M, 1024) bytes, mtmp_gemm_nt_signs' gate).  w1 [1024,256], w2 [256,1024]
- * bf16; gamma, beta, b1, b2 fp32.  Dropout masks: keep(seed1 ^ *seed_dev, row*1024+col) and keep(seed2 ^ *seed_dev, row*256+col),
- * the ones mtmp_ln_gemm / mtmp_gemm_nt draw.  out must not alias x. */
-int mtmp_ffn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
-                 const float* b2, void* out, void* h, void* xn, float* stats, void* signs, int M, int ldx, float eps, float drop_p,
-                 unsigned seed1, unsigned seed2, const unsigned* seed_dev, void* stream);
+/* Grouped forms of the fusion layer's row-wise kernels (bf16): the same operation of up to three token streams (vital signs /
+ * image / text) in ONE launch -- see mtmp_attn_fwd_grouped.  All pointer / int arrays are HOST arrays of n entries (1 <= n <= 3),
+ * scalars are common to the streams; same kernels and results as n calls of the single forms.  The parity (fp32) build keeps
+ * the single forms (these return an error for dtype 0).
+ *   mtmp_ln_gemm_qkv_grouped        = mtmp_ln_gemm_qkv per stream
+ *   mtmp_ln_gemm_signs_grouped      = mtmp_ln_gemm_signs per stream (one dropout seed per stream)
+ *   mtmp_gemm_nt_grouped            = mtmp_gemm_nt per stream without gate / row scale (FFN2 + drop2 + residual)
+ *   mtmp_gemm_nt_signs_drop_grouped = mtmp_gemm_nt_signs_drop per stream
+ *   mtmp_gemm_lnbwd_grouped         = mtmp_gemm_lnbwd per stream, partial slabs only (reduce with mtmp_reduce_batch)
+ *   mtmp_gemm_tn_grouped            = mtmp_gemm_tn per stream on the LDS-DMA kernel, partial slabs only: ws[i] holds
+ *                                     splits[i] x (N K + N) floats with splits from mtmp_gemm_tn_group_plan (non-zero return:
+ *                                     these shapes have no grouped form -- call mtmp_gemm_tn per stream) */
+int mtmp_ln_gemm_qkv_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
+                             const void* const* w, const float* const* bias, void* const* y, void* const* xn, float* const* stats,
+                             float* const* key_norms, const int* M, const int* ldx, float eps, void* stream);
+int mtmp_ln_gemm_signs_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
+                               const void* const* w, const float* const* bias, void* const* y, void* const* xn, float* const* stats,
+                               void* const* signs, const int* M, int N, const int* ldx, float eps, float drop_p,
+                               const unsigned* seeds, const unsigned* seed_dev, void* stream);
+int mtmp_gemm_nt_grouped(int dtype, int n, const void* const* a, const void* const* w, const float* const* bias,
+                         const void* const* res, void* const* y, const int* M, int N, int K, const int* lda, const int* ldy,
+                         const int* ldr, int act, float drop_p, const unsigned* seeds, const unsigned* seed_dev, void* stream);
+int mtmp_gemm_nt_signs_drop_grouped(int dtype, int n, const void* const* a, const void* const* w, void* const* y, const int* M, int N,
+                                    const int* lda, const void* const* signs, float gate_scale, float drop_p, const unsigned* seeds,
+                                    const unsigned* seed_dev, void* const* a_out, void* stream);
+int mtmp_gemm_lnbwd_grouped(int dtype, int n, const void* const* dy, const void* const* wt, const void* const* z, const int* ldz,
+                            const float* const* stats, const float* const* gamma, const void* const* d_res, const int* ldr,
+                            void* const* dz, float* const* ws, const int* M, int K, const int* ldy, float eps, void* stream);
+int mtmp_gemm_tn_group_plan(int n, const int* M, int N, int K, int* splits_out);
+int mtmp_gemm_tn_grouped(int dtype, int n, const void* const* dy, const void* const* x, float* const* ws, const int* M, int N, int K,
+                         const int* ldy, const int* ldx, const int* splits, void* stream);
 
 /* Deferred reductions: mtmp_gemm_tn with dw == NULL (and db == NULL) and mtmp_gemm_lnbwd with dgamma_dbeta == NULL leave their
  * partial slabs in ws -- [mtmp_gemm_tn_slab_rows(dtype,M,N,K)][N K + N] and [mtmp_gemm_lnbwd_slab_rows(M)][512] floats -- and

@@ -18,6 +18,8 @@ SIGNATURES = {
     "mtmp_abi_version": (c_int, []),
     "mtmp_last_error": (c_char_p, []),
     "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 9 + [c_int] * 5 + [c_float, c_void_p]),
+    "mtmp_attn_fwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 12 + [c_int, c_int, c_float, c_void_p]),
+    "mtmp_attn_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 16 + [c_int, c_int, c_float, c_void_p]),
     "mtmp_key_norms_floats": (c_longlong, [c_longlong, c_int]),
     "mtmp_key_norms": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
@@ -30,8 +32,16 @@ SIGNATURES = {
     "mtmp_gemm_nt_signs": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_void_p]),
     "mtmp_gemm_nt_signs_drop": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_float, c_uint, c_void_p,
                                                                                    c_void_p, c_void_p]),
-    "mtmp_ln_linear_act": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_int, c_void_p]),
-    "mtmp_ffn_fwd": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_float, c_float, c_uint, c_uint, c_void_p, c_void_p]),
+    "mtmp_ln_gemm_qkv_grouped": (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_float, c_void_p]),
+    "mtmp_ln_gemm_signs_grouped": (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_int, c_void_p, c_float, c_float, c_void_p, c_void_p,
+                                                                                   c_void_p]),
+    "mtmp_gemm_nt_grouped": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 3 + [c_int, c_float, c_void_p,
+                                                                                                       c_void_p, c_void_p]),
+    "mtmp_gemm_nt_signs_drop_grouped": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_float, c_float,
+                                                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtmp_gemm_lnbwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int, c_void_p, c_float, c_void_p]),
+    "mtmp_gemm_tn_group_plan": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p]),
+    "mtmp_gemm_tn_grouped": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_void_p]),
     "mtmp_gemm_tn_slab_rows": (c_int, [c_int] * 4),
     "mtmp_gemm_lnbwd_slab_rows": (c_int, [c_int]),
     "mtmp_reduce_batch": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),

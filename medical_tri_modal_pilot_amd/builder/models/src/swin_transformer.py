@@ -28,7 +28,7 @@ PAD_LOGIT = -30000.0
 
 # Both on in the product; tools/dbg A/B scripts flip these module attributes (no environment switches in the package).
 _SPLIT_TAIL = True     # stages 3-4 as two half batches on two streams
-_FUSED_MLP = True      # mtmp_swin_ln_linear / mtmp_swin_mlp (C = 96 / 192), mtmp_ln_linear_act (C = 384)
+_FUSED_MLP = True      # mtmp_swin_ln_linear / mtmp_swin_mlp (C = 96 / 192)
 
 
 def _w(p: torch.Tensor, dtype) -> torch.Tensor:
@@ -193,12 +193,8 @@ class SwinTransformerBlock(nn.Module):
             x2 = ops.swin_mlp(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps, _w(self.mlp[0].weight, dt),
                               self.mlp[0].bias, _w(self.mlp[3].weight, dt), self.mlp[3].bias, s_mlp, hw)
             return x2.view(n, H, W, C)
-        if dt == torch.bfloat16 and C in ops.SWIN_LN_FC1_WIDTHS and _FUSED_MLP:      # stage 3: norm2 -> fc1 -> GELU in one launch
-            h = ops.swin_ln_linear(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps, _w(self.mlp[0].weight, dt),
-                                   self.mlp[0].bias, act="gelu")
-        else:
-            h = ops.layernorm_rows(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            h = ops.gemm_nt(h, _w(self.mlp[0].weight, dt), self.mlp[0].bias, act="gelu")
+        h = ops.layernorm_rows(x2, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.gemm_nt(h, _w(self.mlp[0].weight, dt), self.mlp[0].bias, act="gelu")
         x2 = ops.gemm_nt(h, _w(self.mlp[3].weight, dt), self.mlp[3].bias, res2d=x2, row_scale=s_mlp, rows_per_scale=hw)
         return x2.view(n, H, W, C)
 

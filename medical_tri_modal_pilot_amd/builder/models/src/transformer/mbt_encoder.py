@@ -176,7 +176,8 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             sinks = [[layer.grad_sink() for layer in layers] for layers in seg] if torch.is_grad_enabled() else None
             cfg = dict(n_layers=len(seg), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
                        prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True, first_only=first_only and final,
-                       missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev))
+                       missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev),
+                       inputs_on_side=side_in is not None and si == 0)
             out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(zs[0], zs[1], zs[2], self.bottlenecks, *params, cfg)
             zs = (out_v, out_i, out_t)
             if not final:

@@ -148,11 +148,14 @@ constexpr int FWD_QWG = 4 * FWD_QW;             // ... per workgroup
 template <typename T> constexpr int fwd_stage_elems() { return KT * LDT + tr_elems<T>(); }     // one K + V^T image pair
 
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel(AttnArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel(Grouped<AttnArgs<T>> grp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sbase = reinterpret_cast<T*>(smem_raw);       // 2 x { K rows [KT][LDT] | V image for the transposed role }
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = grp_find(grp, wg);
+    const AttnArgs<T>& p = grp.seg[seg];
+    const int w = wg - grp.first[seg];
     const int nqt = (p.N + FWD_QWG - 1) / FWD_QWG;
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -525,13 +528,16 @@ template <typename T> MTMP_DEV TileR<T> tile_zero_rows(const TileR<T>& x, int ro
 
 // dQ: workgroup = 128 query rows, loops over key tiles (S^T and dP^T with the query on the lane).
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(Grouped<AttnBwdArgs<T>> grp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]
     T* sV = sK + KT * LDT;                    // [KT][LDT]
     T* sKt = sV + KT * LDT;                   // K image for the transposed role (frag_tr)
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = grp_find(grp, wg);
+    const AttnBwdArgs<T>& p = grp.seg[seg];
+    const int w = wg - grp.first[seg];
     const int nqt = (p.N + 127) >> 7;
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
 // rows (the contraction runs over queries), and those rows are written as zeros; query rows past N carry
 // -LSE = -inf, so their p and dS are exactly 0.
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_kernel(Grouped<AttnBwdArgs<T>> grp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sQ = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]  q x dh
     T* sdO = sQ + KT * LDT;                   // [KT][LDT]
@@ -650,8 +656,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     T* sdOt = sQt + tr_elems<T>();             // dO image for the transposed role
     float* sL = reinterpret_cast<float*>(sdOt + tr_elems<T>());   // [KT] -lse (log2 units), -inf past N
     float* sD = sL + KT;                                     // [KT] -delta
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = grp_find(grp, wg);
+    const AttnBwdArgs<T>& p = grp.seg[seg];
+    const int w = wg - grp.first[seg];
     const int nkt = (p.N + 127) >> 7;
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
     const int kt = w % nkt, bh = w / nkt, hd = bh % p.H, b = bh / p.H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -854,31 +863,37 @@ template <typename K> int set_smem(K kern, size_t bytes) {
     return MTMP_OK;
 }
 
-template <typename T>
-int launch_fwd(const void* q, const void* k, const void* v, void* o, const void* res, void* o_res, float* lse,
-               const int* kv_len, const float* knorm, int B, int N, int H, int ld_qkv, int ld_o, float scale, hipStream_t st) {
-    AttnArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (T*)o, (const T*)res, (T*)o_res, lse, kv_len, knorm,
-                  B, N, H, ld_qkv, ld_o, scale};
-    const int nwg = ((N + FWD_QWG - 1) / FWD_QWG) * H * B;
+// segments -> one grid: first[i] = first block of segment i (largest work first is the caller's business)
+template <typename A, typename F> Grouped<A> make_group(int n, const A* segs, F blocks_of, int& total) {
+    Grouped<A> g;
+    total = 0;
+    for (int i = 0; i < GRP_MAX; ++i) {
+        g.seg[i] = segs[i < n ? i : 0];
+        g.first[i] = total;
+        if (i < n) total += blocks_of(segs[i]);
+    }
+    g.first[GRP_MAX] = total;
+    return g;
+}
+
+template <typename T> int launch_fwd(int n, const AttnArgs<T>* segs, hipStream_t st) {
+    int nwg;
+    const Grouped<AttnArgs<T>> g = make_group(n, segs, [](const AttnArgs<T>& a) { return ((a.N + FWD_QWG - 1) / FWD_QWG) * a.H * a.B; }, nwg);
     const size_t sm = fwd_smem<T>();
     if (int e = set_smem(attn_fwd_kernel<T>, sm)) return e;
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(nwg), dim3(256), sm, st, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(nwg), dim3(256), sm, st, g);
     MTMP_CHECK_LAUNCH("mtmp_attn_fwd");
     return MTMP_OK;
 }
 
-template <typename T>
-int launch_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-               const int* kv_len, void* dq, void* dk, void* dv, float* delta, int B, int N, int H, int ld_qkv,
-               int ld_o, int ld_do, int ld_dqkv, float scale, hipStream_t st) {
-    AttnBwdArgs<T> a{(const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, kv_len,
-                     (T*)dq, (T*)dk, (T*)dv, B, N, H, ld_qkv, ld_do, ld_dqkv, scale, (const T*)o, ld_o};
-    const int nwg = ((N + 127) / 128) * H * B;
+template <typename T> int launch_bwd(int n, const AttnBwdArgs<T>* segs, hipStream_t st) {
+    int nwg;
+    const Grouped<AttnBwdArgs<T>> g = make_group(n, segs, [](const AttnBwdArgs<T>& a) { return ((a.N + 127) / 128) * a.H * a.B; }, nwg);
     if (int e = set_smem(attn_bwd_dq_kernel<T>, dq_smem<T>())) return e;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(nwg), dim3(256), dq_smem<T>(), st, a);      // also writes delta
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(nwg), dim3(256), dq_smem<T>(), st, g);      // also writes delta
     MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dq)");
     if (int e = set_smem(attn_bwd_dkdv_kernel<T>, dkdv_smem<T>())) return e;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(nwg), dim3(256), dkdv_smem<T>(), st, a);
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(nwg), dim3(256), dkdv_smem<T>(), st, g);
     MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dkdv)");
     return MTMP_OK;
 }
@@ -889,18 +904,86 @@ bool attn_shape_ok(int B, int N, int H, int ld_a, int ld_b) {
 
 }  // namespace
 
+template <typename T>
+int fwd_entry(int n, const void* const* q, const void* const* k, const void* const* v, void* const* o, const void* const* res,
+              void* const* o_res, float* const* lse, const int32_t* const* kv_len, const float* const* key_norms, const int* N,
+              const int* ld_qkv, const int* ld_o, int B, int H, float scale, hipStream_t st) {
+    AttnArgs<T> a[GRP_MAX];
+    for (int i = 0; i < n; ++i)
+        a[i] = AttnArgs<T>{(const T*)q[i], (const T*)k[i], (const T*)v[i], (T*)o[i], res ? (const T*)res[i] : nullptr,
+                           o_res ? (T*)o_res[i] : nullptr, lse[i], kv_len ? kv_len[i] : nullptr, key_norms ? key_norms[i] : nullptr,
+                           B, N[i], H, ld_qkv[i], ld_o[i], scale};
+    return launch_fwd<T>(n, a, st);
+}
+
+// n <= 3 streams in ONE launch (all arrays are HOST arrays of n entries; res / o_res / kv_len / key_norms may be NULL as a
+// whole or per entry).  mtmp_attn_fwd is the n = 1 form.
+extern "C" int mtmp_attn_fwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v,
+                                     void* const* o, const void* const* res, void* const* o_res, float* const* lse,
+                                     const int32_t* const* kv_len, const float* const* key_norms, const int* N, const int* ld_qkv,
+                                     const int* ld_o, int B, int H, float scale, void* stream) {
+    MTMP_CHECK_ARG(n >= 1 && n <= GRP_MAX && q && k && v && o && lse && N && ld_qkv && ld_o, "mtmp_attn_fwd: bad group (n=%d)", n);
+    for (int i = 0; i < n; ++i) {
+        MTMP_CHECK_ARG(q[i] && k[i] && v[i] && o[i] && lse[i], "mtmp_attn_fwd: null pointer (stream %d)", i);
+        MTMP_CHECK_ARG((!res || !res[i]) == (!o_res || !o_res[i]), "mtmp_attn_fwd: res and o_res must be given together");
+        MTMP_CHECK_ARG(attn_shape_ok(B, N[i], H, ld_qkv[i], ld_o[i]), "mtmp_attn_fwd: bad shape B=%d N=%d H=%d ld=%d/%d", B, N[i], H,
+                       ld_qkv[i], ld_o[i]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) return fwd_entry<float>(n, q, k, v, o, res, o_res, lse, kv_len, key_norms, N, ld_qkv, ld_o, B, H, scale, st);
+    if (dtype == 1) return fwd_entry<bf16>(n, q, k, v, o, res, o_res, lse, kv_len, key_norms, N, ld_qkv, ld_o, B, H, scale, st);
+    mtmp_set_error("mtmp_attn_fwd: unknown dtype %d", dtype);
+    return MTMP_ERR_ARG;
+}
+
 extern "C" int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res,
                              void* o_res, float* lse, const int32_t* kv_len, const float* key_norms, int B, int N, int H,
                              int ld_qkv, int ld_o, float scale, void* stream) {
-    MTMP_CHECK_ARG(q && k && v && o && lse, "mtmp_attn_fwd: null pointer");
-    MTMP_CHECK_ARG((res == nullptr) == (o_res == nullptr), "mtmp_attn_fwd: res and o_res must be given together");
-    MTMP_CHECK_ARG(attn_shape_ok(B, N, H, ld_qkv, ld_o), "mtmp_attn_fwd: bad shape B=%d N=%d H=%d ld=%d/%d", B, N, H,
-                   ld_qkv, ld_o);
+    return mtmp_attn_fwd_grouped(dtype, 1, &q, &k, &v, &o, &res, &o_res, &lse, &kv_len, &key_norms, &N, &ld_qkv, &ld_o, B, H, scale,
+                                 stream);
+}
+
+template <typename T>
+int bwd_entry(int n, const void* const* q, const void* const* k, const void* const* v, const void* const* o, const void* const* d_o,
+              const float* const* lse, const int32_t* const* kv_len, void* const* dq, void* const* dk, void* const* dv,
+              float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o, const int* ld_do, const int* ld_dqkv, int B,
+              int H, float scale, hipStream_t st) {
+    AttnBwdArgs<T> a[GRP_MAX];
+    for (int i = 0; i < n; ++i)
+        a[i] = AttnBwdArgs<T>{(const T*)q[i], (const T*)k[i], (const T*)v[i], (const T*)d_o[i], lse[i], delta_ws[i],
+                              kv_len ? kv_len[i] : nullptr, (T*)dq[i], (T*)dk[i], (T*)dv[i], B, N[i], H, ld_qkv[i], ld_do[i],
+                              ld_dqkv[i], scale, (const T*)o[i], ld_o[i]};
+    return launch_bwd<T>(n, a, st);
+}
+
+extern "C" int mtmp_attn_bwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v,
+                                     const void* const* o, const void* const* d_o, const float* const* lse,
+                                     const int32_t* const* kv_len, void* const* dq, void* const* dk, void* const* dv,
+                                     float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o, const int* ld_do,
+                                     const int* ld_dqkv, int B, int H, float scale, void* stream) {
+    MTMP_CHECK_ARG(n >= 1 && n <= GRP_MAX && q && k && v && o && d_o && lse && dq && dk && dv && delta_ws && N && ld_qkv && ld_o &&
+                       ld_do && ld_dqkv, "mtmp_attn_bwd: bad group (n=%d)", n);
+    for (int i = 0; i < n; ++i) {
+        MTMP_CHECK_ARG(q[i] && k[i] && v[i] && o[i] && d_o[i] && lse[i] && dq[i] && dk[i] && dv[i] && delta_ws[i],
+                       "mtmp_attn_bwd: null pointer (stream %d)", i);
+        MTMP_CHECK_ARG(attn_shape_ok(B, N[i], H, ld_qkv[i], ld_o[i]) && attn_shape_ok(B, N[i], H, ld_do[i], ld_dqkv[i]),
+                       "mtmp_attn_bwd: bad shape B=%d N=%d H=%d", B, N[i], H);
+    }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) return launch_fwd<float>(q, k, v, o, res, o_res, lse, kv_len, key_norms, B, N, H, ld_qkv, ld_o, scale, st);
-    if (dtype == 1) return launch_fwd<bf16>(q, k, v, o, res, o_res, lse, kv_len, key_norms, B, N, H, ld_qkv, ld_o, scale, st);
-    mtmp_set_error("mtmp_attn_fwd: unknown dtype %d", dtype);
+    if (dtype == 0)
+        return bwd_entry<float>(n, q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, N, ld_qkv, ld_o, ld_do, ld_dqkv, B, H, scale, st);
+    if (dtype == 1)
+        return bwd_entry<bf16>(n, q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, N, ld_qkv, ld_o, ld_do, ld_dqkv, B, H, scale, st);
+    mtmp_set_error("mtmp_attn_bwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
+}
+
+extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                             const float* lse, const int32_t* kv_len, void* dq, void* dk, void* dv, float* delta_ws,
+                             int B, int N, int H, int ld_qkv, int ld_o, int ld_do, int ld_dqkv, float scale,
+                             void* stream) {
+    return mtmp_attn_bwd_grouped(dtype, 1, &q, &k, &v, &o, &d_o, &lse, &kv_len, &dq, &dk, &dv, &delta_ws, &N, &ld_qkv, &ld_o, &ld_do,
+                                 &ld_dqkv, B, H, scale, stream);
 }
 
 extern "C" long long mtmp_key_norms_floats(long long rows, int H) { return ((rows + 31) / 32) * H; }
@@ -918,20 +1001,3 @@ extern "C" int mtmp_key_norms(int dtype, const void* k, float* out, long long ro
     return MTMP_OK;
 }
 
-extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* d_o,
-                             const float* lse, const int32_t* kv_len, void* dq, void* dk, void* dv, float* delta_ws,
-                             int B, int N, int H, int ld_qkv, int ld_o, int ld_do, int ld_dqkv, float scale,
-                             void* stream) {
-    MTMP_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv && delta_ws, "mtmp_attn_bwd: null pointer");
-    MTMP_CHECK_ARG(attn_shape_ok(B, N, H, ld_qkv, ld_o) && attn_shape_ok(B, N, H, ld_do, ld_dqkv),
-                   "mtmp_attn_bwd: bad shape B=%d N=%d H=%d", B, N, H);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0)
-        return launch_bwd<float>(q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, B, N, H, ld_qkv, ld_o, ld_do,
-                                 ld_dqkv, scale, st);
-    if (dtype == 1)
-        return launch_bwd<bf16>(q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, B, N, H, ld_qkv, ld_o, ld_do,
-                                ld_dqkv, scale, st);
-    mtmp_set_error("mtmp_attn_bwd: unknown dtype %d", dtype);
-    return MTMP_ERR_ARG;
-}

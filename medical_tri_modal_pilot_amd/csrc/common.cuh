@@ -210,12 +210,8 @@ MTMP_DEV float erf_as(float x) {
 template <typename T> MTMP_DEV float gelu(float x);
 template <> MTMP_DEV float gelu<float>(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 template <> MTMP_DEV float gelu<bf16>(float x) {
-#ifdef MTMP_GELU_ERF            // (A/B builds)
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f));
-#else
     const float u = x * fmaf(x * x, 0.0713548163f * 1.4426950408889634f, 1.5957691216f * 1.4426950408889634f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
-#endif
 }
 
 // Counter-based dropout mask: element `idx` of a call seeded with `seed` is kept iff
@@ -253,6 +249,15 @@ MTMP_DEV int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// ---- grouped launches: ONE grid over the row blocks / tiles of up to three token streams (vital signs, image, text).
+// A fusion layer runs the same kernel on three streams of very different lengths (1005 / 54 / 133 tokens); as three launches
+// on three HIP streams the small ones hold whole-CU workgroup slots of the big one for 40-90 us each (round 2: every
+// vital-sign-stream kernel ran 15-40 % slower inside the step than alone).  As one launch their blocks simply follow the big
+// stream's in the same grid.  first[i] = first (XCD-remapped) block of segment i, first[n..GRP_MAX] = the grid size.
+constexpr int GRP_MAX = 3;
+template <typename A> struct Grouped { A seg[GRP_MAX]; int first[GRP_MAX + 1]; };
+template <typename A> MTMP_DEV int grp_find(const Grouped<A>& g, int w) { return (w >= g.first[1] ? 1 : 0) + (w >= g.first[2] ? 1 : 0); }
 
 // ---- streaming-kernel helpers shared by elementwise.hip and the fused dX + LayerNorm-backward GEMM (d_model = 256) ----
 MTMP_DEV f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

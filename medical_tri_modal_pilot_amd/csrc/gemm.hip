@@ -24,20 +24,6 @@
 #include <type_traits>
 template <int N> using template_int = std::integral_constant<int, N>;
 
-// Diagnostic build only (make stamp): s_memtime stamps around the phases of the gemm_tn token loop.
-#ifdef MTMP_STAMP
-__device__ unsigned long long g_stamp_tn[8];
-__device__ unsigned long long g_stamp_lng[1024 * 2];      // per workgroup (wave 0): prologue, panel loop
-#define TSTAMP(var)                                                                                  \
-    {                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                  \
-        __builtin_amdgcn_sched_barrier(0);                                                           \
-    }
-#else
-#define TSTAMP(var)
-#endif
-
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64, LDW = BK + 8;
@@ -106,14 +92,11 @@ constexpr int LDO = BN + 8;
 // features each) -- the smaller tile is used when a launch would otherwise have fewer workgroups than ~2 per CU
 // (frozen-encoder stages 3-4, the image / text streams): such launches are bound by the latency chain of ONE
 // workgroup per CU, and more, smaller workgroups overlap their chains.
-#ifndef MTMP_NT_RT128
-#define MTMP_NT_RT128 1
-#endif
 template <int TM> struct NtGeom {
     // RT x NT 32x32 tiles per wave, WR x WC waves.  TM = 128: 4 x 1 waves of 32 tokens x 128 features (-DMTMP_NT_RT128=2:
     // 2 x 2 waves of 64 x 64, one operand fragment fewer per 4 MFMAs -- measured 5-10 % SLOWER on every shape of
     // tools/bench_kernels.py: 7 spilled VGPRs under the 128-register cap); TM = 64: 2 x 2 waves of 32 x 64.
-    static constexpr int RT = TM == 128 ? MTMP_NT_RT128 : 1;
+    static constexpr int RT = 1;
     static constexpr int WR = TM / (32 * RT), WC = 4 / WR, NT = 4 / WC;
 };
 
@@ -275,11 +258,7 @@ template <typename T> MTMP_DEV void bias_or_zero(f32x16 (&b)[Panel<T>::G], const
 }
 // LDS traffic of ONE wave to its private staging tile needs no barrier (a wave's LDS instructions execute in
 // order); this only stops the compiler from moving memory operations across the hand-over point.
-#ifdef MTMP_HANDOVER_WAIT      // (A/B builds: the explicit wait of the first version)
-MTMP_DEV void wave_lds_handover() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 MTMP_DEV void wave_lds_handover() { asm volatile("" ::: "memory"); }
-#endif
 
 template <typename T, bool RELU, bool DROP>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(GemmArgs<T> p) {
@@ -345,19 +324,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
     const unsigned seed_eff = p.seed ^ ((p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u);
     const int tok = lane / P::LPT, ch = lane % P::LPT;           // store phase: this lane's token (+ 64/LPT per pass), 16 B chunk
-#if defined(MTMP_LNG_PRIO) || defined(MTMP_LNG_SLEEP)
-    {
-        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6);      // HW_REG_LDS_ALLOC.LDS_BASE: 0 for the first WG on a CU
-        if (lds_base != 0) {
-#ifdef MTMP_LNG_PRIO
-            __builtin_amdgcn_s_setprio(3);
-#endif
-#ifdef MTMP_LNG_SLEEP
-            __builtin_amdgcn_s_sleep(MTMP_LNG_SLEEP);
-#endif
-        }
-    }
-#endif
     for (int j = j0; j < j1; ++j) {
         const int n0 = j * P::NP;
         T* cur = sP + ((j - j0) & 1) * P::NP * P::LDP;
@@ -367,11 +333,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 #pragma unroll
         for (int g = 0; g < P::G; ++g)
             acc[g] = mma_c<T>(frag_load<T>(cur + (32 * g + r) * P::LDP + 8 * half), af[0], binit[g]);
-#ifdef MTMP_LNG_NOMMA      // (diagnostic builds, results wrong by design: tools/ablate_lng.sh)
-        constexpr int CEND = 2;
-#else
         constexpr int CEND = 16;
-#endif
 #pragma unroll
         for (int c = 1; c < CEND; ++c)
 #pragma unroll
@@ -380,9 +342,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
         panel_commit<T>(nxt, wreg, tid);                         // panel j+1 (or a harmless repeat of the last one)
         bias_fetch<T>(binit, p.bias, p.w, min(j + 1, j1 - 1) * P::NP, half);
         panel_fetch<T>(wreg, p.w, min(j + 2, j1 - 1) * P::NP, p.N, tid);
-#ifdef MTMP_LNG_NOEPI
-        if (p.M < 0)
-#endif
 #pragma unroll
         for (int g = 0; g < P::G; ++g) {
 #pragma unroll
@@ -405,9 +364,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
                 const int t = tok + ps * (64 / P::LPT);
                 const u32x4_t d = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + t * P::FS) + 16 * ch);
                 T* dst = p.y + (size_t)min(m_wave + t, p.M - 1) * p.ldy + n0 + 32 * g;
-#ifdef MTMP_LNG_NOSTORE
-                if (p.M < 0)
-#endif
                 *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(dst) + 16 * ch) = d;
             }
             wave_lds_handover();
@@ -431,7 +387,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ln_gemm_kernel(
 // staging round trip) is issued between the MFMAs of the other: [MFMA g1(j) | epilogue g0(j)] -> s_waitcnt vmcnt(4) (DMA(j+1)
 // is older than exactly the four row-piece stores of the last two epilogues) -> barrier -> DMA(j+2) -> [MFMA g0(j+1) |
 // epilogue g1(j)].
-// K = row length (contraction index): 256 (the fusion layers' d_model) or 384 (Swin stage 3, one workgroup per CU: 96 KiB of panels).
+// K = row length (contraction index) = 256, the fusion layers' d_model.
 template <int K = 256> struct PanelDmaK {
     static constexpr int NP = 64, G = 2, FS = 40, LPT = 4, PASSES = 2, MAXP = 16;   // MAXP panels (1024 features) per workgroup
     static constexpr int KC = K / 16, ROWB = 2 * K;                // 16-wide k-steps; bytes per weight row
@@ -458,15 +414,26 @@ template <int N> MTMP_DEV void gwait1(unsigned& a) { asm volatile("s_waitcnt vmc
 // dH = dY W2 gated by the saved hidden activation (y = h > 0 ? y * gate_scale : 0, autograd of module.py:77-79) reads those
 // bits instead of h itself -- the same kernel geometry, so a lane needs exactly the 16 bits its forward twin wrote: 4 MB of
 // gate traffic per launch at config 2 instead of 132 MB.  No LayerNorm in GATE mode (p.gamma == nullptr).
-// K / TORCH_LN / GELU: the same kernel as the frozen image encoder's LayerNorm + Linear (+ exact GELU) for the 384-wide stage
-// (swin_transformer.py:428-449: nn.LayerNorm -- biased variance, eps inside the root -- in front of qkv / mlp.0).
 // KNORM (the Q/K/V projection, N = 768 = [Wq; Wk; Wv], head h of K = panel 4 + h): the epilogue also sums the squares of a row's 64
 // key features (a lane holds 32 of them, its half-wave partner the rest) and keeps the maximum over the wave's 32 rows -- the
 // key-norm table that lets the attention forward drop its running maximum (attention.hip, bounded body) at no extra pass over K.
-template <bool RELU, bool DROP, bool GATE, bool SIGNS, int K = 256, bool TORCH_LN = false, bool GELU = false, bool KNORM = false>
-__global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(GemmArgs<bf16> p) {
+// both accumulator groups of key panel je went through the epilogue: fold the lane's square sum into the head's maximum over the
+// wave's 32 rows (a free function on references: as a lambda captured by the phase lambdas it kept its variables in scratch)
+MTMP_DEV void knorm_fold(int je, float& ksq, float& kh0, float& kh1, float& kh2, float& kh3) {
+    if (je >= 4 && je < 8) {
+        const float mx = wave_max(half_sum(ksq));
+        kh0 = je == 4 ? mx : kh0; kh1 = je == 5 ? mx : kh1; kh2 = je == 6 ? mx : kh2; kh3 = je == 7 ? mx : kh3;   // (selects: branches kept them in scratch)
+    }
+    ksq = 0.f;
+}
+template <bool RELU, bool DROP, bool GATE, bool SIGNS, bool KNORM = false>
+__global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf16>> grp) {
     using T = bf16;
-    using P = PanelDmaK<K>;
+    constexpr int K = 256;
+    const int seg = grp_find(grp, (int)blockIdx.x);          // row blocks of up to three token streams in one grid (common.cuh)
+    const GemmArgs<bf16>& p = grp.seg[seg];
+    const int bx = (int)blockIdx.x - grp.first[seg];
+    using P = PanelDma;
     constexpr int KC = P::KC;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
@@ -478,7 +445,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     const int per = (npanels + gridDim.y - 1) / gridDim.y;
     const int j0 = blockIdx.y * per, j1 = min(npanels, j0 + per);
     if (j0 >= j1) return;
-    const int m_wave = blockIdx.x * BM + wave * 32;
+    const int m_wave = bx * BM + wave * 32;
     const int row = min(m_wave + r, p.M - 1);
     // DMA slot of this lane: piece i of wave w fills LDS bytes [1024 (ND w + i), +1024) of the panel image, i.e. 16-byte slot
     // q = 64 (ND w + i) + lane = position q % (K/8) of panel row q / (K/8), which takes global chunk position ^ (row & 15)
@@ -489,15 +456,11 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         const unsigned q = 64u * (unsigned)(P::ND * wave + i) + (unsigned)lane, prow = q / (K / 8), pos = q % (K / 8);
         dsrc[i] = prow * (unsigned)P::ROWB + 16u * (pos ^ (prow & 15u));
     }
-    auto panel_dma = [&](int j, int buf) {
+    auto panel_dma = [&](int j, int buf) __attribute__((always_inline)) {
         const char* src = reinterpret_cast<const char*>(p.w + (size_t)j * P::NP * K);
 #pragma unroll
         for (int i = 0; i < P::ND; ++i) dma16(dsrc[i], src, lds0 + buf * P::panel_bytes + (unsigned)(P::ND * wave + i) * 1024u);
     };
-#ifdef MTMP_STAMP
-    unsigned long long ts0, ts1, ts2;
-    TSTAMP(ts0)
-#endif
     panel_dma(j0, 0);
     if (p.gamma) {
         for (int i = tid; i < K; i += 256) {
@@ -547,7 +510,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
             for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 = fmaf(d, d, s2); }
         s2 += __shfl_xor(s2, 32, 64);
         // the fusion layers' LayerNorm: torch.std (Bessel-corrected), eps added to it; nn.LayerNorm: biased variance, eps inside
-        const float rs = TORCH_LN ? rsqrtf(s2 * (1.0f / K) + p.eps) : 1.0f / (sqrtf(s2 * (1.0f / (K - 1))) + p.eps);
+        const float rs = 1.0f / (sqrtf(s2 * (1.0f / (K - 1))) + p.eps);
         __syncthreads();                                         // sG ready
         if (p.gamma) {
 #pragma unroll
@@ -576,7 +539,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     const int rs = swz23(r);
 #pragma unroll
     for (int c = 0; c < 8; ++c) rd[c] = smem_raw + rs * P::ROWB + 16 * ((2 * c + half) ^ (rs & 15));
-    auto ucol = [&](int i4) { return 16 * (i4 >> 1) + 8 * half + 4 * (i4 & 1); };   // first feature of registers 4 i4 .. 4 i4 + 3
+    auto ucol = [&](int i4) __attribute__((always_inline)) { return 16 * (i4 >> 1) + 8 * half + 4 * (i4 & 1); };   // first feature of registers 4 i4 .. 4 i4 + 3
     panel_dma(min(j0 + 1, j1 - 1), 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // panels j0, j0 + 1 landed (this wave's share)
     __syncthreads();                                             // ... everyone's; sB written; sG dead (sS may be written)
@@ -590,29 +553,29 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     // so that LDS round trip also runs under MFMAs; a wave's LDS instructions execute in order, so the next epilogue's first
     // ds_write (slice 1) cannot overtake those reads.
     constexpr int NG = GATE ? 1 : 0, NS = SIGNS ? 1 : 0;         // gate loads / sign stores per tile
-    auto tile_ptr = [&](const T* base, int ld, int jp, int gp, int ps) {
+    auto tile_ptr = [&](const T* base, int ld, int jp, int gp, int ps) __attribute__((always_inline)) {
         const int t = tok + ps * (64 / P::LPT);
         return reinterpret_cast<const char*>(base + (size_t)min(m_wave + t, p.M - 1) * ld + jp * P::NP + 32 * gp) + 16 * ch;
     };
-    auto signs_ptr = [&](int j, int g) { return p.signs + ((size_t)(2 * j + g) * p.M + row) * 2 + half; };
-    auto drain_load = [&](u32x4_t (&d)[P::PASSES]) {
+    auto signs_ptr = [&](int j, int g) __attribute__((always_inline)) { return p.signs + ((size_t)(2 * j + g) * p.M + row) * 2 + half; };
+    auto drain_load = [&](u32x4_t (&d)[P::PASSES]) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < P::PASSES; ++ps)
             d[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + (tok + ps * (64 / P::LPT)) * P::FS) + 16 * ch);
     };
-    auto drain_store = [&](const u32x4_t (&d)[P::PASSES], int jp, int gp) {
+    auto drain_store = [&](const u32x4_t (&d)[P::PASSES], int jp, int gp) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < P::PASSES; ++ps) *reinterpret_cast<u32x4_t*>(const_cast<char*>(tile_ptr(p.y, p.ldy, jp, gp, ps))) = d[ps];
     };
     // one 4-feature piece of an epilogue: activation / dropout / gate, sign bits, rounding, parked in the staging tile
     float ksq = 0.f, kh0 = 0.f, kh1 = 0.f, kh2 = 0.f, kh3 = 0.f;      // KNORM: running square sum of the key panel in its epilogue; finished heads
-    bool kpanel = false;                                             // (wave-uniform) the epilogue's panel is a key head
-    auto piece = [&](int g, int i4, const unsigned (&fld)[4], unsigned gate_bits, unsigned& sign_bits) {
+    float kmask = 0.f;                                               // 1 while the epilogue's panel is a key head (wave-uniform)
+    auto piece = [&](int g, int i4, const unsigned (&fld)[4], unsigned gate_bits, unsigned& sign_bits) __attribute__((always_inline)) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = acc[g][4 * i4 + i];
-            if (KNORM && kpanel) ksq = fmaf(v[i], v[i], ksq);
+            if (KNORM) ksq = fmaf(v[i] * kmask, v[i], ksq);
             if (SIGNS) {       // "positive and kept" as ONE lane mask: it selects the value and is shifted into the collection
                 unsigned long long lm = __builtin_amdgcn_ballot_w64(v[i] > 0.f);
                 if (DROP) lm &= __builtin_amdgcn_ballot_w64(fld[i] >= thr);
@@ -626,19 +589,11 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
                 if (RELU) v[i] = relu1(v[i]);
                 if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
             }
-            if (GELU) v[i] = gelu<T>(v[i]);
             if (GATE)          // bit 15 - (4 i4 + i) of the lane's 16: all ones or zero, and-ed onto the scaled value
                 v[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[i] * p.gate_scale) &
                                                      __builtin_amdgcn_sbfe((int)gate_bits, 15 - (4 * i4 + i), 1));
         }
         store4<T>(sS + r * P::FS + ucol(i4), v[0], v[1], v[2], v[3]);
-    };
-    auto knorm_finish = [&](int je) {          // both groups of key panel je went through piece(): max over the wave's rows
-        if (je >= 4 && je < 8) {
-            const float mx = wave_max(half_sum(ksq));
-            if (je == 4) kh0 = mx; else if (je == 5) kh1 = mx; else if (je == 6) kh2 = mx; else kh3 = mx;
-        }
-        ksq = 0.f;
     };
     // One phase = the 16 MFMAs of accumulator group gm of panel jm, issued in eight slices of two; between them (EPI) the
     // epilogue of group ge of panel je, cut into eight pieces of vector work: per 4 features [mask hash] and [ReLU / select /
@@ -648,12 +603,12 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     // are read eight MFMAs ahead.  gnext / gcur: gate bits of the group being multiplied (loaded here) and of the epilogue's
     // group (loaded one phase ago; GW = vector-memory operations issued since, i.e. the vmcnt that proves them landed).
     auto phase = [&](int jm, int gm, int je, int ge, auto epi_tag, int jp, int gp, auto pend_tag, unsigned& gnext, unsigned& gcur,
-                     auto gw_tag) {
+                     auto gw_tag) __attribute__((always_inline)) {
         constexpr bool EPI = decltype(epi_tag)::value, PEND = decltype(pend_tag)::value;
         constexpr int GW = decltype(gw_tag)::value;
         const size_t cur = (size_t)(((jm - j0) & 1) * P::panel_bytes + gm * P::group_bytes);
         const int n0 = je * P::NP;
-        if (KNORM) kpanel = EPI && je >= 4 && je < 8;
+        if (KNORM) kmask = (EPI && je >= 4 && je < 8) ? 1.f : 0.f;
         if (GATE) gload_u16(gnext, signs_ptr(jm, gm));
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
@@ -689,7 +644,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
                 } else {
                     piece(ge, i4, fld, gcur, sign_bits);
                 }
-                constexpr int NV = DROP || GELU ? 9 : (KNORM ? 5 : 3);
+                constexpr int NV = DROP ? 9 : (KNORM ? 5 : 3);
                 if (2 * s8 + 8 < KC) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
@@ -699,10 +654,10 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         }
         __builtin_amdgcn_sched_barrier(0);
         if (SIGNS && EPI) *signs_ptr(je, ge) = (unsigned short)sign_bits;
-        if (KNORM && EPI && ge == 1) knorm_finish(je);
+        if (KNORM && EPI && ge == 1) knorm_fold(je, ksq, kh0, kh1, kh2, kh3);
     };
     // the last group's epilogue has no MFMAs left to hide under
-    auto epi_alone = [&](int j, int g, int jp, int gp, unsigned& gcur) {
+    auto epi_alone = [&](int j, int g, int jp, int gp, unsigned& gcur) __attribute__((always_inline)) {
         u32x4_t dr[P::PASSES];
         wave_lds_handover();
         drain_load(dr);
@@ -711,7 +666,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         if (GATE) gwait1<0>(gcur);
         const int n0 = j * P::NP;
         unsigned sign_bits = 0;
-        if (KNORM) kpanel = j >= 4 && j < 8;
+        if (KNORM) kmask = (j >= 4 && j < 8) ? 1.f : 0.f;
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
             const int col = n0 + 32 * g + ucol(i4);
@@ -719,7 +674,7 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
             if (DROP) dropout_fields4(seed_eff, ((unsigned)row * (unsigned)p.N + (unsigned)col) >> 2, fld);
             piece(g, i4, fld, gcur, sign_bits);
         }
-        if (KNORM) knorm_finish(j);
+        if (KNORM) knorm_fold(j, ksq, kh0, kh1, kh2, kh3);
         if (SIGNS) *signs_ptr(j, g) = (unsigned short)sign_bits;
         wave_lds_handover();
         drain_load(dr);
@@ -735,9 +690,6 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
     // the top of the B phase before) are older than S + 8 + G, a B phase's than S + G.
     constexpr int NST = P::PASSES + NS, WDMA = 2 * (NG + NST), WA = NST + 8 + NG, WB = NST + NG;
     unsigned g0bits = 0, g1bits = 0;                             // gate bits of the g = 0 / g = 1 group in flight
-#ifdef MTMP_STAMP
-    TSTAMP(ts1)
-#endif
     phase(j0, 0, 0, 0, No{}, 0, 0, No{}, g0bits, g1bits, template_int<0>{});
     if (j0 < j1 - 1) {
         phase(j0, 1, j0, 0, Yes{}, 0, 0, No{}, g1bits, g0bits, template_int<NG>{});
@@ -765,384 +717,6 @@ __global__ __launch_bounds__(256, (K == 256 ? 2 : 1)) void ln_gemm_dma_kernel(Ge
         if (j0 <= 6 && 6 < j1) kn[2] = sqrtf(kh2);
         if (j0 <= 7 && 7 < j1) kn[3] = sqrtf(kh3);
     }
-#ifdef MTMP_STAMP
-    TSTAMP(ts2)
-    if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
-        g_stamp_lng[2 * blockIdx.x] = ts1 - ts0;
-        g_stamp_lng[2 * blockIdx.x + 1] = ts2 - ts1;
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------
-// The position-wise FFN of an encoder layer in ONE kernel (bf16): out = x + drop2(relu-drop1(LN(x) W1^T + b1) W2^T + b2)
-// (module.py:138-144, :74-80, encoder.py:32).  The 4 x 256-wide hidden activation h is still written (the backward's dW2 operand)
-// and its sign bits too, but it is never read back: as two launches the step moved 198 + 198 MB here, fused it moves 231 MB.
-// Structure = the row-panel kernel with a second product chained behind every panel: a workgroup owns 128 rows (32 per wave, the
-// normalised rows as 16 register fragments); per panel of 64 hidden units
-//   1. H^T panel = W1[panel] xn^T (+ b1): 2 x 16 MFMAs, W1 rows through swz23, so that after ReLU / dropout the accumulator
-//      registers 8s..8s+7 ARE the k-step-s operand fragments of the second product (common.cuh) -- no LDS round trip between the
-//      two GEMMs; the same values go through the wave's staging tile to h (64-byte row pieces);
-//   2. out^T += W2[:, panel] H panel: 8 output tiles x 4 k-steps = 32 MFMAs, accumulated over the 16 panels in 128 registers.
-// Both weight panels ([64][256] of W1, [256][64] of W2, 32 KiB each) arrive by LDS-DMA into chunk-permuted unpadded rows, double
-// buffered: 128 KiB of LDS, one workgroup per CU, one wave per SIMD (<= 512 registers).
-struct FfnFwdArgs {
-    const bf16* x; const float* gamma; const float* beta; const bf16* w1; const float* b1; const bf16* w2; const float* b2;
-    bf16* out; bf16* h; bf16* xn; float* stats; unsigned short* signs;
-    int M, ldx;
-    float eps, drop_p;
-    unsigned seed1, seed2;
-    const unsigned* seed_dev;
-};
-struct FfnLds {
-    static constexpr unsigned w1_off = 0, w2_off = 65536, stage_off = 131072, b1_off = stage_off + 4 * 32 * 40 * 2, b2_off = b1_off + 4096;
-    static constexpr size_t bytes = b2_off + 1024;
-};
-template <bool DROP>
-__global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(FfnFwdArgs p) {
-    using T = bf16;
-    using L = FfnLds;
-    constexpr int FS = 40, NPAN = 16;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, half = lane >> 5;
-    T* sS = reinterpret_cast<T*>(smem_raw + L::stage_off) + wave * 32 * FS;       // wave-private [32][FS]
-    float* sG = reinterpret_cast<float*>(smem_raw + L::stage_off);                // gamma|beta, prologue only (aliases sS)
-    float* sB1 = reinterpret_cast<float*>(smem_raw + L::b1_off);
-    float* sB2 = reinterpret_cast<float*>(smem_raw + L::b2_off);
-    const int m_wave = blockIdx.x * BM + wave * 32;
-    const int row = min(m_wave + r, p.M - 1);
-    // DMA slots.  W1 panel: as ln_gemm_dma_kernel (slot q -> row q / 32, position q % 32 takes chunk position ^ (row & 15)).
-    // W2 panel [256 rows][8 chunks of 16 B]: slot q -> row q / 8, position q % 8 takes chunk position ^ ((row >> 1) & 7).
-    unsigned d1[8], d2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const unsigned q = 64u * (unsigned)(8 * wave + i) + (unsigned)lane;
-        d1[i] = (q >> 5) * 512u + 16u * ((q & 31u) ^ ((q >> 5) & 15u));
-        d2[i] = (q >> 3) * 2048u + 16u * ((q & 7u) ^ ((q >> 4) & 7u));
-    }
-    // piece i (0..7) of this wave's share of the W1 / W2 panel j
-    auto dma_w1 = [&](int j, int i) {
-        dma16(d1[i], reinterpret_cast<const char*>(p.w1 + (size_t)j * 64 * 256),
-              lds0 + L::w1_off + (unsigned)(j & 1) * 32768u + (unsigned)(8 * wave + i) * 1024u);
-    };
-    auto dma_w2 = [&](int j, int i) {
-        dma16(d2[i], reinterpret_cast<const char*>(p.w2 + (size_t)j * 64),
-              lds0 + L::w2_off + (unsigned)(j & 1) * 32768u + (unsigned)(8 * wave + i) * 1024u);
-    };
-#ifdef MTMP_STAMP
-    unsigned long long ts0, ts1, ts2, ts3;
-    TSTAMP(ts0)
-#endif
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma_w1(0, i);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma_w2(0, i);
-    sG[tid] = p.gamma[tid];
-    sG[256 + tid] = p.beta[tid];
-    for (int i = tid; i < 1024; i += 256) sB1[i] = p.b1[i];
-    sB2[tid] = p.b2[tid];
-    // ---- LayerNorm prologue (module.py:138-144: torch.std, eps added to it), lane (r, half) holds k = 16c + 8 half + j of row r
-    Frag<T> af[16];
-    const T* arow = p.x + (size_t)row * p.ldx + 8 * half;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) af[c] = frag_load<T>(arow + 16 * c);
-    {
-        float s1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s1 += to_f32(af[c].v[j]);
-        s1 += __shfl_xor(s1, 32, 64);
-        const float mean = s1 * (1.0f / 256.0f);
-        float s2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = to_f32(af[c].v[j]) - mean; s2 = fmaf(d, d, s2); }
-        s2 += __shfl_xor(s2, 32, 64);
-        const float rs = 1.0f / (sqrtf(s2 * (1.0f / 255.0f)) + p.eps);
-        __syncthreads();                                         // sG ready
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int k = 16 * c + 8 * half;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                af[c].v[j] = from_f32<T>(fmaf(sG[k + j], (to_f32(af[c].v[j]) - mean) * rs, sG[256 + k + j]));
-            if (p.xn) frag_store<T>(p.xn + (size_t)row * 256 + k, af[c]);
-        }
-        if (p.stats && half == 0) {
-            p.stats[2 * (size_t)row] = mean;
-            p.stats[2 * (size_t)row + 1] = rs;
-        }
-    }
-    const unsigned thr = dropout_threshold(p.drop_p);
-    const float keep_scale = 1.0f / (1.0f - p.drop_p);
-    const unsigned sdev = (p.drop_p > 0.f && p.seed_dev) ? *p.seed_dev : 0u;
-    const unsigned seed1 = p.seed1 ^ sdev, seed2 = p.seed2 ^ sdev;
-    const int tok = lane >> 2, ch = lane & 3;                    // store phase: this lane's token (+ 16 per pass), 16 B chunk
-    const int rs_ = swz23(r);
-    const char* rd1[8];                                          // W1 panel: row 32g + swz23(r), k-step c
-#pragma unroll
-    for (int c = 0; c < 8; ++c) rd1[c] = smem_raw + L::w1_off + rs_ * 512 + 16 * ((2 * c + half) ^ (rs_ & 15));
-    const char* rd2[4];                                          // W2 panel: row 32t + swz23(r), k-step ks of the panel
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) rd2[ks] = smem_raw + L::w2_off + rs_ * 128 + 16 * ((2 * ks + half) ^ ((rs_ >> 1) & 7));
-    auto ucol = [&](int i4) { return 16 * (i4 >> 1) + 8 * half + 4 * (i4 & 1); };
-    auto tile_store = [&](T* base, int ld, int col0, const u32x4_t (&d)[2]) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int t = tok + 16 * ps;
-            *reinterpret_cast<u32x4_t*>(reinterpret_cast<char*>(base + (size_t)min(m_wave + t, p.M - 1) * ld + col0) + 16 * ch) = d[ps];
-        }
-    };
-    auto tile_load = [&](u32x4_t (&d)[2]) {
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-            d[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sS + (tok + 16 * ps) * FS) + 16 * ch);
-    };
-    f32x16 acc2[8], acc1[2];
-    Frag<T> hf[4];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc2[t] = f32x16{0};
-    // A panel is walked in four segments of 16 MFMAs, each cut into eight slices of two (sched_barrier(0) between slices, as in
-    // ln_gemm_dma_kernel) that carry the vector work of ANOTHER accumulator group:
-    //   S1  H group 0                     | drain of the previous panel's group-1 tile
-    //   S2  H group 1                     | ReLU / dropout / sign bits / park of group 0     -> operand fragments hf[0..1]
-    //   S3  out += W2[:, units 0..31] H   | the same for group 1; drain of the group-0 tile  -> hf[2..3]
-    //   S4  out += W2[:, units 32..63] H  | (next iteration's S1 drains the group-1 tile)
-    // One staging tile per wave is enough: a wave's LDS instructions execute in order, and a tile is drained (read) in the
-    // first slice of the segment whose later slices park the next one.
-    unsigned fld[4], sign_bits = 0;
-    auto bias_init = [&](int j, int g) {
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(sB1 + 64 * j + 32 * g + ucol(i4));
-            acc1[g][4 * i4] = v[0]; acc1[g][4 * i4 + 1] = v[1]; acc1[g][4 * i4 + 2] = v[2]; acc1[g][4 * i4 + 3] = v[3];
-        }
-    };
-    // vector piece s8 (0..7) of the hidden group g of panel j: even = mask hash of 4 units, odd = select / sign / park
-    auto h_piece = [&](int j, int g, int s8) {
-        const int i4 = s8 >> 1;
-        if ((s8 & 1) == 0) {
-            if (DROP) dropout_fields4(seed1, ((unsigned)row * 1024u + (unsigned)(64 * j + 32 * g + ucol(i4))) >> 2, fld);
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = acc1[g][4 * i4 + i];
-            unsigned long long lm = __builtin_amdgcn_ballot_w64(v > 0.f);
-            if (DROP) lm &= __builtin_amdgcn_ballot_w64(fld[i] >= thr);
-            const float sv = DROP ? v * keep_scale : v;
-            asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %2, %3\n\tv_addc_co_u32_e64 %1, vcc, %1, %1, %3"
-                : "=&v"(v), "+v"(sign_bits) : "v"(sv), "s"(lm) : "vcc");
-            acc1[g][4 * i4 + i] = v;
-        }
-        store4<T>(sS + r * FS + ucol(i4), acc1[g][4 * i4], acc1[g][4 * i4 + 1], acc1[g][4 * i4 + 2], acc1[g][4 * i4 + 3]);
-    };
-    auto h_finish = [&](int j, int g) {                          // after piece 7: sign bits out, operand fragments
-        if (p.signs) p.signs[((size_t)(2 * j + g) * p.M + row) * 2 + half] = (unsigned short)sign_bits;
-        sign_bits = 0;
-        hf[2 * g] = frag_from_acc<T>(acc1[g], 0);
-        hf[2 * g + 1] = frag_from_acc<T>(acc1[g], 1);
-    };
-    auto h_drain = [&](int j, int g) {                           // staging tile -> h rows (64-byte pieces)
-        u32x4_t dr[2];
-        wave_lds_handover();
-        tile_load(dr);
-        wave_lds_handover();
-        tile_store(p.h, 1024, 64 * j + 32 * g, dr);
-    };
-    constexpr int NV = DROP ? 9 : 4;
-    // segment of the first product: group g of panel j; VP: the pieces of group vg; DR: first drain the tile (dj, dg)
-    auto seg1 = [&](int j, int g, auto vp_tag, int vg, auto dr_tag, int dj, int dg, auto dma_tag) {
-        constexpr bool VP = decltype(vp_tag)::value, DR = decltype(dr_tag)::value, DMA = decltype(dma_tag)::value;
-        const size_t cur = (size_t)((j & 1) * 32768 + g * 16384);
-        bias_init(j, g);
-        Frag<T> b[16];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) b[c].v = *reinterpret_cast<const bf16x8*>(rd1[c] + cur);
-        if (DR) h_drain(dj, dg);
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (s8 < 4) {
-                b[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd1[2 * s8] + cur + 256);
-                b[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd1[2 * s8 + 1] + cur + 256);
-            }
-            mma<T>(acc1[g], b[2 * s8], af[2 * s8]);
-            if (DMA) dma_w1(j + 1, s8);                          // one piece of the next W1 panel per slice
-            mma<T>(acc1[g], b[2 * s8 + 1], af[2 * s8 + 1]);
-            if (VP) {
-                h_piece(j, vg, s8);
-                if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, NV + 2, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (VP) h_finish(j, vg);
-    };
-    // segment of the second product: k-steps 2 q, 2 q + 1 of panel j (the units of hidden group q) into all eight output tiles
-    auto seg2 = [&](int j, int q, auto vp_tag, int vg, auto dr_tag, int dg, auto dma_tag) {
-        constexpr bool VP = decltype(vp_tag)::value, DR = decltype(dr_tag)::value, DMA = decltype(dma_tag)::value;
-        const size_t cur = (size_t)((j & 1) * 32768);
-        Frag<T> a[16];                                           // fragment m = 8 (ks & 1) + t
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a[m].v = *reinterpret_cast<const bf16x8*>(rd2[2 * q] + cur + m * 4096);
-        if (DR) h_drain(j, dg);
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (s8 < 4) {
-                a[8 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd2[2 * q + 1] + cur + (2 * s8) * 4096);
-                a[9 + 2 * s8].v = *reinterpret_cast<const bf16x8*>(rd2[2 * q + 1] + cur + (2 * s8 + 1) * 4096);
-            }
-            const int m0 = 2 * s8, m1 = 2 * s8 + 1;
-            mma<T>(acc2[m0 & 7], a[m0], hf[2 * q + (m0 >> 3)]);
-            if (DMA) dma_w2(j + 1, s8);                          // one piece of the next W2 panel per slice
-            mma<T>(acc2[m1 & 7], a[m1], hf[2 * q + (m1 >> 3)]);
-            if (VP) {
-                h_piece(j, vg, s8);
-                if (s8 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, NV + 2, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (VP) h_finish(j, vg);
-    };
-    using Yes = std::true_type;
-    using No = std::false_type;
-    // Vector-memory operations of one iteration in issue order (sg = 1 with sign bits, else 0):
-    //   S1: 2 h stores (drain), 8 W1(j+1) pieces | S2: sg sign store | barrier B | S3: 2 h stores, sg | S4: 8 W2(j+1) pieces | barrier A
-    // W1(j+1) is waited for at barrier A of the next iteration: 2 + 2 sg + 8 operations are younger; W2(j+1) at its barrier B:
-    // 2 + 8 + sg are younger.  (Iterations 0 and 1 have issued less and wait with vmcnt(0).)
-    const int nsig = p.signs ? 1 : 0;
-#ifdef MTMP_STAMP
-    TSTAMP(ts1)
-#endif
-#ifdef MTMP_FFN_SPREAD_DMA          // (measured: 6.8 k cycles per panel against 5.2 k -- a DMA piece between two MFMAs costs more than up front)
-    for (int j = 0; j < NPAN; ++j) {
-        if (j < 2)     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nsig) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __syncthreads();                                         // A: W1(j) landed for everyone; the panels j - 1 are free
-        if (j == 0)            seg1(j, 0, No{}, 0, No{}, 0, 0, Yes{});
-        else if (j + 1 < NPAN) seg1(j, 0, No{}, 0, Yes{}, j - 1, 1, Yes{});
-        else                   seg1(j, 0, No{}, 0, Yes{}, j - 1, 1, No{});      // (no panel left to fetch)
-        seg1(j, 1, Yes{}, 0, No{}, 0, 0, No{});
-        if (j < 2)     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nsig) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-        else           asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __syncthreads();                                         // B: W2(j) landed for everyone
-        seg2(j, 0, Yes{}, 1, Yes{}, 0, No{});
-        if (j + 1 < NPAN) seg2(j, 1, No{}, 0, No{}, 0, Yes{});
-        else              seg2(j, 1, No{}, 0, No{}, 0, No{});
-    }
-#else
-    // Both panels of j + 1 are requested right behind the barrier: the 4 h stores and 2 sg sign stores of an iteration are the
-    // only younger operations when they are waited for.
-#ifdef MTMP_STAMP
-    unsigned long long tq0, tq1, tq2, tq3, tq4, tq5, sA = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-#endif
-    for (int j = 0; j < NPAN; ++j) {
-#ifdef MTMP_STAMP
-        TSTAMP(tq0)
-#endif
-        if (j < 2)     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (nsig) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __syncthreads();                                         // panel j landed for everyone; the panels j - 1 are free
-        if (j + 1 < NPAN) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dma_w1(j + 1, i);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dma_w2(j + 1, i);
-        }
-#ifdef MTMP_STAMP
-        TSTAMP(tq1)
-#endif
-        if (j == 0) seg1(j, 0, No{}, 0, No{}, 0, 0, No{});
-        else        seg1(j, 0, No{}, 0, Yes{}, j - 1, 1, No{});
-#ifdef MTMP_STAMP
-        TSTAMP(tq2)
-#endif
-        seg1(j, 1, Yes{}, 0, No{}, 0, 0, No{});
-#ifdef MTMP_STAMP
-        TSTAMP(tq3)
-#endif
-        seg2(j, 0, Yes{}, 1, Yes{}, 0, No{});
-#ifdef MTMP_STAMP
-        TSTAMP(tq4)
-#endif
-        seg2(j, 1, No{}, 0, No{}, 0, No{});
-#ifdef MTMP_STAMP
-        TSTAMP(tq5)
-        sA += tq1 - tq0; s1 += tq2 - tq1; s2 += tq3 - tq2; s3 += tq4 - tq3; s4 += tq5 - tq4;
-#endif
-    }
-#ifdef MTMP_STAMP
-    if (tid == 0 && blockIdx.x == 7) {
-        g_stamp_tn[0] = sA; g_stamp_tn[1] = s1; g_stamp_tn[2] = s2; g_stamp_tn[3] = s3; g_stamp_tn[4] = s4;
-    }
-#endif
-#endif
-    h_drain(NPAN - 1, 1);
-#ifdef MTMP_STAMP
-    TSTAMP(ts2)
-#endif
-    // ---- epilogue: + b2, drop2, round, + residual (the un-normalised input row), 32 features at a time
-    u32x4_t rv[8][2];                                            // the residual row pieces of all eight tiles, requested up front
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-            rv[t][ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(
-                            p.x + (size_t)min(m_wave + tok + 16 * ps, p.M - 1) * p.ldx + 32 * t) + 16 * ch);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            const int col = 32 * t + ucol(i4);
-            unsigned fld[4];
-            if (DROP) dropout_fields4(seed2, ((unsigned)row * 256u + (unsigned)col) >> 2, fld);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(sB2 + col);
-            float v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = acc2[t][4 * i4 + i] + bv[i];
-                if (DROP) v[i] = fld[i] >= thr ? v[i] * keep_scale : 0.f;
-            }
-            store4<T>(sS + r * FS + ucol(i4), v[0], v[1], v[2], v[3]);
-        }
-        u32x4_t dr[2];
-        wave_lds_handover();
-        tile_load(dr);
-        wave_lds_handover();
-#pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const bf16x8 ov = __builtin_bit_cast(bf16x8, dr[ps]), xv = __builtin_bit_cast(bf16x8, rv[t][ps]);
-            bf16x8 yv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) yv[i] = from_f32<T>(to_f32(ov[i]) + to_f32(xv[i]));
-            dr[ps] = __builtin_bit_cast(u32x4_t, yv);
-        }
-        tile_store(p.out, 256, 32 * t, dr);
-    }
-#ifdef MTMP_STAMP
-    TSTAMP(ts3)
-    if (tid == 0 && blockIdx.x < 512) {
-        g_stamp_lng[4 * blockIdx.x] = ts1 - ts0;
-        g_stamp_lng[4 * blockIdx.x + 1] = ts2 - ts1;
-        g_stamp_lng[4 * blockIdx.x + 2] = ts3 - ts2;
-        g_stamp_lng[4 * blockIdx.x + 3] = ts0;
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1151,15 +725,18 @@ __global__ __launch_bounds__(256, 1) void ffn_fwd_kernel(FfnFwdArgs p) {
 // workgroups per CU instead of three, and every large launch got 20-30 % slower (dH 93 -> 120 us, FFN2 76 -> 97 us);
 // only launches with < 1 workgroup per CU gained.  Occupancy hides this loop's latency better than depth.
 template <typename T, bool RELU, int TM, bool DROP>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) void gemm_nt_kernel(GemmArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) void gemm_nt_kernel(Grouped<GemmArgs<T>> grp) {
     using G = NtGeom<TM>;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = grp_find(grp, wg);
+    const GemmArgs<T>& p = grp.seg[seg];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sA = reinterpret_cast<T*>(smem_raw);   // [TM][LDW]
     T* sW = sA + TM * LDW;                    // [BN][LDW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int wr = wave % G::WR, foff = (wave / G::WR) * 32 * G::NT;
     const int ntn = (p.N + BN - 1) / BN;
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int w = wg - grp.first[seg];
     const int m0 = (w / ntn) * TM, n0 = (w % ntn) * BN;
     const int nk = (p.K + BK - 1) / BK;
     TileRegs<T> areg, wreg;
@@ -1306,34 +883,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
     TnRegs<T> yreg, xreg;
     tn_fetch<T>(yreg, p.dy, p.ldy, m_lo, m_end, n0, tid);
     tn_fetch<T>(xreg, p.x, p.ldx, m_lo, m_end, k0, tid);
-#ifdef MTMP_STAMP
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, sa = 0, sb = 0, sc = 0, sd = 0, nst = 0;
-#endif
     for (int m0 = m_lo; m0 < m_end; m0 += TK) {
-        TSTAMP(ts0)
         __syncthreads();
-        TSTAMP(ts1)
-#ifndef MTMP_TN_NOCOMMIT                                  // (ablation builds: tools/ablate_tn.sh -- never shipped)
         tn_mask<T>(yreg);
         tn_mask<T>(xreg);
         tn_commit<T>(sY, yreg.f, tid);
         tn_commit<T>(sX, xreg.f, tid);
-#endif
         if (k0 == 0) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 csum[e] += to_f32(yreg.f[0].v[e]) + to_f32(yreg.f[1].v[e]) + to_f32(yreg.f[2].v[e]) + to_f32(yreg.f[3].v[e]);
         }
-        TSTAMP(ts2)
         __syncthreads();
-        TSTAMP(ts3)
-#ifndef MTMP_TN_NOFETCH
         if (m0 + TK < m_end) {
             tn_fetch<T>(yreg, p.dy, p.ldy, m0 + TK, m_end, n0, tid);
             tn_fetch<T>(xreg, p.x, p.ldx, m0 + TK, m_end, k0, tid);
         }
-#endif
-#ifndef MTMP_TN_NOMMA
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const Frag<T> a0 = frag_load<T>(sY + (wn + r) * LDX + 16 * c + 8 * half);
@@ -1343,18 +908,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
             mma<T>(acc[0][0], a0, b0); mma<T>(acc[0][1], a0, b1);
             mma<T>(acc[1][0], a1, b0); mma<T>(acc[1][1], a1, b1);
         }
-#endif
-        TSTAMP(ts4)
-#ifdef MTMP_STAMP
-        sa += ts1 - ts0; sb += ts2 - ts1; sc += ts3 - ts2; sd += ts4 - ts3; ++nst;
-#endif
     }
-#ifdef MTMP_STAMP
-    if (lane == 0) {
-        atomicAdd(&g_stamp_tn[0], sa); atomicAdd(&g_stamp_tn[1], sb); atomicAdd(&g_stamp_tn[2], sc);
-        atomicAdd(&g_stamp_tn[3], sd); atomicAdd(&g_stamp_tn[4], nst);
-    }
-#endif
     // partial slab row: [N*K] products then [N] column sums
     float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
 #pragma unroll
@@ -1477,39 +1031,21 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
     }
     __syncthreads();
     // (ablation builds, tools/dbg/ablate_tn.sh: results are wrong by design, only the timing is read)
-#ifdef MTMP_TN_NOMMA
-#define TN_MMA(...)
-#else
-#define TN_MMA(...) tr_mma(__VA_ARGS__)
-#endif
-#ifdef MTMP_TN_NOCOMMIT
-#define TN_COMMIT(...)
-#else
-#define TN_COMMIT(...) tr_commit(__VA_ARGS__)
-#endif
-#ifdef MTMP_TN_NOFETCH
-#define TN_FETCH(...)
-#else
-#define TN_FETCH(...) tr_fetch(__VA_ARGS__)
-#endif
     for (int s = 0; s < nsteps; s += 2) {
         // even step: multiply stage 0, stage 1 <- registers y1/x1 (step s+1), refill them with step s+3
-        TN_MMA(acc, sm, sm + MAT, wn, wk, lane);
-        TN_COMMIT(sm + STAGE, y1, tid); TN_COMMIT(sm + STAGE + MAT, x1, tid);
+        tr_mma(acc, sm, sm + MAT, wn, wk, lane);
+        tr_commit(sm + STAGE, y1, tid); tr_commit(sm + STAGE + MAT, x1, tid);
         if (bias_blk) tr_csum(csum, y1);
-        TN_FETCH(y1, p.dy, p.ldy, mg + (s + 3) * ST, m_end, n0, tid); TN_FETCH(x1, p.x, p.ldx, mg + (s + 3) * ST, m_end, k0, tid);
+        tr_fetch(y1, p.dy, p.ldy, mg + (s + 3) * ST, m_end, n0, tid); tr_fetch(x1, p.x, p.ldx, mg + (s + 3) * ST, m_end, k0, tid);
         __syncthreads();
         if (s + 1 >= nsteps) break;
         // odd step: multiply stage 1, stage 0 <- y0/x0 (step s+2), refill with step s+4
-        TN_MMA(acc, sm + STAGE, sm + STAGE + MAT, wn, wk, lane);
-        TN_COMMIT(sm, y0, tid); TN_COMMIT(sm + MAT, x0, tid);
+        tr_mma(acc, sm + STAGE, sm + STAGE + MAT, wn, wk, lane);
+        tr_commit(sm, y0, tid); tr_commit(sm + MAT, x0, tid);
         if (bias_blk) tr_csum(csum, y0);
-        TN_FETCH(y0, p.dy, p.ldy, mg + (s + 4) * ST, m_end, n0, tid); TN_FETCH(x0, p.x, p.ldx, mg + (s + 4) * ST, m_end, k0, tid);
+        tr_fetch(y0, p.dy, p.ldy, mg + (s + 4) * ST, m_end, n0, tid); tr_fetch(x0, p.x, p.ldx, mg + (s + 4) * ST, m_end, k0, tid);
         __syncthreads();
     }
-#undef TN_MMA
-#undef TN_COMMIT
-#undef TN_FETCH
     if constexpr (NG == 2) {
         // group 1 -> LDS [64 accumulator registers][256 threads] (64 KiB, over the dead tiles) -> group 0 adds
         float* xch = reinterpret_cast<float*>(smem_raw);
@@ -1583,10 +1119,7 @@ constexpr int DTILE = DT * 256;                            // bytes: one [DT][12
 template <int XT> struct TnDma {
     // three stages (96 KiB) rather than five (all 160 KiB): the loaders idle at the barrier either way, and 64 KiB of the CU stay
     // free for the other streams' workgroups -- 8.80-8.82 against 8.85-8.88 ms/step and 9.03-9.11 against 9.07-9.14 (two boxes)
-#ifndef MTMP_TN_DNS
-#define MTMP_TN_DNS 3
-#endif
-    static constexpr int DNS = XT == 2 ? 3 : MTMP_TN_DNS;  // stages
+    static constexpr int DNS = XT == 2 ? 3 : 3;            // stages
     static constexpr int DSTAGE = (1 + XT) * DTILE;        // a stage = dY | X (lo | hi)
     static constexpr int DPW = 4 * (1 + XT);               // DMA pieces per loader wave and stage
     static constexpr int NB = 2 * XT;                      // 32-column X blocks per matrix wave
@@ -1610,13 +1143,11 @@ template <int DPW> MTMP_DEV void tn_wait_stages(int k) {   // all but the last k
     else tn_wait<0>();
 }
 template <int NB> struct TnChunk { Frag<bf16> a[2], b[NB]; };
-#ifdef MTMP_TND_NOBAR                                        // (ablation build: no stage barriers, results wrong)
-#define TND_BARRIER()
-#else
-#define TND_BARRIER() __syncthreads()
-#endif
 template <int XT>
-__global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
+__global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(Grouped<TnArgs<bf16>> grp) {
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = grp_find(grp, wg);
+    const TnArgs<bf16>& p = grp.seg[seg];
     constexpr int DNS = TnDma<XT>::DNS, DSTAGE = TnDma<XT>::DSTAGE, DPW = TnDma<XT>::DPW, NB = TnDma<XT>::NB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_raw);
@@ -1624,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
     const bool loader = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tn = p.N / 128, tk = p.K / (128 * XT);
-    int w = xcd_remap(blockIdx.x, gridDim.x);
+    int w = wg - grp.first[seg];
     const int split = w / (tn * tk);
     w -= split * tn * tk;
     const int kt = w % tk, n0 = (w / tk) * 128, k0 = kt * 128 * XT;
@@ -1637,9 +1168,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
     const unsigned ycol = (unsigned)(n0 * 2 + lc * 16), xcol = (unsigned)(k0 * 2 + lc * 16);
     const unsigned ldyb = (unsigned)p.ldy * 2u, ldxb = (unsigned)p.ldx * 2u;
     auto issue = [&](int st_) {
-#ifdef MTMP_TND_NODMA                                       // (ablation builds, tools/dbg/ablate_tn.sh: timing only, results wrong)
-        return;
-#endif
         const unsigned dst = lds0 + (unsigned)((st_ % DNS) * DSTAGE + wave * 4096);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1678,33 +1206,22 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
     auto chunk = [&](int st_, int c) {
         const char* sb = smem_raw + (st_ % DNS) * DSTAGE + c * 4096;
         TnChunk<NB> f;
-#ifdef MTMP_TND_MMAONLY
-        f.a[0] = f.a[1] = frag_zero<bf16>();
-        asm volatile("" : "+v"(f.a[0].v), "+v"(f.a[1].v));
-#pragma unroll
-        for (int j = 0; j < NB; ++j) { f.b[j] = frag_zero<bf16>(); asm volatile("" : "+v"(f.b[j].v)); }
-#elif !defined(MTMP_TND_NOREAD)
         f.a[0] = frag_tr_at(sb + aoff0);
 #pragma unroll
         for (int j = 0; j < NB; ++j) f.b[j] = frag_tr_at(sb + boff[j]);
         f.a[1] = frag_tr_at(sb + aoff1);
-#endif
         return f;
     };
     auto mma8 = [&](const TnChunk<NB>& f, bool with_cs) {
-#if !defined(MTMP_TND_NOMMA) && !defined(MTMP_TND_NOREAD)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < NB; ++j) mma<bf16>(acc[i][j], f.a[i], f.b[j]);
-#ifndef MTMP_TND_NOCSUM
         if (with_cs) {
             Frag<bf16> a;
             a.v = cs_hi ? f.a[1].v : f.a[0].v;
             mma<bf16>(acc_cs, a, ones);
         }
-#endif
-#endif
     };
     // stage st_ has landed for every wave (barrier passed): in a tail stage zero the dY rows past m_end (their products and
     // their column sums vanish), then one more barrier (every thread: row = t >> 3, 32 bytes)
@@ -1719,40 +1236,23 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
             __syncthreads();
         }
     };
-#ifdef MTMP_STAMP
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ta = 0, ta2 = 0, ta3 = 0, tb = 0, s_wait = 0, s_bar = 0, s_work = 0;
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    TSTAMP(ts0)
     // Barrier B(s) publishes stage s (the loaders waited for their pieces of it) and tells the loaders that the matrix waves
     // are done reading stage s-1, whose buffer takes stage s+DNS-1.  Two loops, one per role, executing the same barriers (no
     // MFMA shares a control-flow merge with loader code).
     if (loader) {
         const int pre = min(nst, DNS);
         for (int s = 0; s < pre; ++s) issue(s);
-        TSTAMP(ts1)
         for (int s = 0; s < nst; ++s) {
-            TSTAMP(ta)
             tn_wait_stages<DPW>(min(nst - 1, max(DNS - 1, s + DNS - 2)) - s);
-            TSTAMP(ta2)
-            TND_BARRIER();                                 // B(s)
-            TSTAMP(ta3)
+            __syncthreads();                                 // B(s)
             fix_tail(s);
             if (s >= 1 && s + DNS - 1 < nst) issue(s + DNS - 1);
-            TSTAMP(tb)
-#ifdef MTMP_STAMP
-            s_wait += ta2 - ta; s_bar += ta3 - ta2; s_work += tb - ta3;
-#endif
         }
     } else {
-        TSTAMP(ts1)
         // one stage: each k-chunk's fragments requested one chunk (8 MFMAs) ahead of its MFMAs (pinned in this order)
         for (int s = 0; s < nst; ++s) {
-            TSTAMP(ta)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            TSTAMP(ta2)
-            TND_BARRIER();                                 // B(s)
-            TSTAMP(ta3)
+            __syncthreads();                                 // B(s)
             fix_tail(s);
             const TnChunk<NB> f0 = chunk(s, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -1766,13 +1266,8 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
             mma8(f2, cs_c23);
             __builtin_amdgcn_sched_barrier(0);
             mma8(f3, cs_c23);
-            TSTAMP(tb)
-#ifdef MTMP_STAMP
-            s_wait += ta2 - ta; s_bar += ta3 - ta2; s_work += tb - ta3;
-#endif
         }
     }
-    TSTAMP(ts2)
     float* red = reinterpret_cast<float*>(smem_raw);       // [2][128 columns] over the dead tiles
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1785,16 +1280,6 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
     __syncthreads();
     float* out = p.slab + (size_t)split * ((size_t)p.N * p.K + p.N);
     if (!loader) {
-#ifdef MTMP_TND_NOSTORE                                     // (ablation build: one store per lane keeps the accumulators alive)
-        float keep = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int t = 0; t < 16; ++t) keep += acc[i][j][t];
-        out[(size_t)(n0 + wn + acc_row(0, half)) * p.K + k0 + kcol + r] = keep;
-#else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1802,17 +1287,9 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(TnArgs<bf16> p) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     out[(size_t)(n0 + wn + 32 * i + acc_row(t, half)) * p.K + k0 + kcol + 32 * j + r] = acc[i][j][t];
-#endif
     } else if (tid < 128 && (tid >> 5) % tkp == kt) {
         out[(size_t)p.N * p.K + n0 + tid] = red[tid] + red[128 + tid];
     }
-#ifdef MTMP_STAMP
-    TSTAMP(ts3)
-    if ((threadIdx.x == 0 || threadIdx.x == 256) && blockIdx.x < 128) {
-        unsigned long long* o = g_stamp_lng + 16 * blockIdx.x + 8 * (threadIdx.x >> 8);
-        o[0] = ts1 - ts0; o[1] = s_wait; o[2] = s_work; o[3] = __builtin_amdgcn_s_memrealtime() - rt0; o[4] = ts3 - ts2; o[5] = ts3 - ts0; o[6] = s_bar; o[7] = nst;
-    }
-#endif
 }
 
 // Several slab reductions in ONE launch: out_e[c] = sum_r slab_e[r][c] for up to RB_MAX entries (blockIdx.y); columns below
@@ -1897,66 +1374,66 @@ int tn_splits(int M, int N, int K, int target_wgs) {
     return s < 1 ? 1 : s;
 }
 
+// segments -> one grid: first[i] = first block of segment i; unused entries repeat segment 0 behind the end of the grid
+template <typename A, typename F> Grouped<A> make_group(int n, const A* segs, F blocks_of, int& total) {
+    Grouped<A> g;
+    total = 0;
+    for (int i = 0; i < GRP_MAX; ++i) {
+        g.seg[i] = segs[i < n ? i : 0];
+        g.first[i] = total;
+        if (i < n) total += blocks_of(segs[i]);
+    }
+    g.first[GRP_MAX] = total;
+    return g;
+}
+
 // mode: 0 forward (relu / dropout from the arguments; a.signs != nullptr with relu: also write the sign bits), 1 gate by a.signs
-int launch_ln_gemm_dma(GemmArgs<bf16> a, int relu, int gate, hipStream_t st) {
+// n segments (token streams) in one launch: same N / activation / dropout switch / sign bits / key-norm table in all of them
+int launch_ln_gemm_dma(int n, const GemmArgs<bf16>* segs, int relu, int gate, hipStream_t st) {
     using P = PanelDma;
+    const GemmArgs<bf16>& a = segs[0];
     const bool drop = a.drop_p > 0.f, signs = !gate && relu && a.signs;
+    for (int i = 1; i < n; ++i)
+        if (segs[i].N != a.N || (segs[i].drop_p > 0.f) != drop || !segs[i].signs != !a.signs || !segs[i].knorm != !a.knorm ||
+            !segs[i].gamma != !a.gamma) {
+            mtmp_set_error("mtmp_ln_gemm (grouped): the streams of one launch must agree in N, dropout, sign bits and key norms");
+            return MTMP_ERR_ARG;
+        }
     const void* fs[7] = {(const void*)ln_gemm_dma_kernel<false, false, false, false>, (const void*)ln_gemm_dma_kernel<false, true, false, false>,
                          (const void*)ln_gemm_dma_kernel<true, false, false, false>, (const void*)ln_gemm_dma_kernel<true, true, false, false>,
                          (const void*)ln_gemm_dma_kernel<true, false, false, true>, (const void*)ln_gemm_dma_kernel<true, true, false, true>,
                          (const void*)ln_gemm_dma_kernel<false, false, true, false>};
     const bool knorm = a.knorm != nullptr;           // (the Q/K/V projection: no activation, no dropout, N = 768)
     const int which = gate ? 6 : signs ? 4 + (drop ? 1 : 0) : (relu ? 2 : 0) + (drop ? 1 : 0);
-    const void* fk = (const void*)ln_gemm_dma_kernel<false, false, false, false, 256, false, false, true>;
+    const void* fk = (const void*)ln_gemm_dma_kernel<false, false, false, false, true>;
     if (hipFuncSetAttribute(knorm ? fk : fs[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
         mtmp_set_error("mtmp_ln_gemm: cannot raise dynamic LDS to %zu", P::lds_bytes);
         return MTMP_ERR_LAUNCH;
     }
     // as launch_ln_gemm below; a workgroup's bias block in LDS holds at most MAXP panels
-    const int mtiles = (a.M + BM - 1) / BM, npanels = a.N / P::NP;
+    int mtiles;
+    const Grouped<GemmArgs<bf16>> g = make_group(n, segs, [](const GemmArgs<bf16>& x) { return (x.M + BM - 1) / BM; }, mtiles);
+    const int npanels = a.N / P::NP;
     int nsplit = 512 / mtiles;
     nsplit = nsplit < 1 ? 1 : (nsplit > npanels ? npanels : nsplit);
     const int need = (npanels + P::MAXP - 1) / P::MAXP;
     if (nsplit < need) nsplit = need;
     dim3 grid(mtiles, nsplit);
     if (knorm) {
-        hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, 256, false, false, true>), grid, dim3(256), P::lds_bytes, st, a);
+        hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, true>), grid, dim3(256), P::lds_bytes, st, g);
         MTMP_CHECK_LAUNCH("mtmp_ln_gemm_qkv");
         return MTMP_OK;
     }
     switch (which) {
-    case 0: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
-    case 1: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, true, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
-    case 2: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
-    case 3: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true, false, false>), grid, dim3(256), P::lds_bytes, st, a); break;
-    case 4: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false, false, true>), grid, dim3(256), P::lds_bytes, st, a); break;
-    case 5: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true, false, true>), grid, dim3(256), P::lds_bytes, st, a); break;
-    default: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, true, false>), grid, dim3(256), P::lds_bytes, st, a); break;
+    case 0: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false>), grid, dim3(256), P::lds_bytes, st, g); break;
+    case 1: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, true, false, false>), grid, dim3(256), P::lds_bytes, st, g); break;
+    case 2: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false, false, false>), grid, dim3(256), P::lds_bytes, st, g); break;
+    case 3: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true, false, false>), grid, dim3(256), P::lds_bytes, st, g); break;
+    case 4: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, false, false, true>), grid, dim3(256), P::lds_bytes, st, g); break;
+    case 5: hipLaunchKernelGGL((ln_gemm_dma_kernel<true, true, false, true>), grid, dim3(256), P::lds_bytes, st, g); break;
+    default: hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, true, false>), grid, dim3(256), P::lds_bytes, st, g); break;
     }
     MTMP_CHECK_LAUNCH("mtmp_ln_gemm");
-    return MTMP_OK;
-}
-// nn.LayerNorm + Linear (+ exact GELU) over 384-wide rows: the row-panel kernel with K = 384, one workgroup per CU
-int launch_ln_linear_384(GemmArgs<bf16> a, int gelu, hipStream_t st) {
-    using P = PanelDmaK<384>;
-    const void* f = gelu ? (const void*)ln_gemm_dma_kernel<false, false, false, false, 384, true, true>
-                         : (const void*)ln_gemm_dma_kernel<false, false, false, false, 384, true, false>;
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P::lds_bytes) != hipSuccess) {
-        mtmp_set_error("mtmp_ln_linear_act: cannot raise dynamic LDS to %zu", P::lds_bytes);
-        return MTMP_ERR_LAUNCH;
-    }
-    const int mtiles = (a.M + BM - 1) / BM, npanels = a.N / P::NP;
-    int nsplit = 256 / mtiles;                               // ~ one workgroup per CU
-#ifdef MTMP_LN384_NSPLIT
-    nsplit = MTMP_LN384_NSPLIT;                              // (diagnostic builds)
-#endif
-    nsplit = nsplit < 1 ? 1 : (nsplit > npanels ? npanels : nsplit);
-    const int need = (npanels + P::MAXP - 1) / P::MAXP;
-    if (nsplit < need) nsplit = need;
-    dim3 grid(mtiles, nsplit);
-    if (gelu) hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, 384, true, true>), grid, dim3(256), P::lds_bytes, st, a);
-    else      hipLaunchKernelGGL((ln_gemm_dma_kernel<false, false, false, false, 384, true, false>), grid, dim3(256), P::lds_bytes, st, a);
-    MTMP_CHECK_LAUNCH("mtmp_ln_linear_act");
     return MTMP_OK;
 }
 template <typename T>
@@ -1966,9 +1443,7 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
         mtmp_set_error("mtmp_ln_gemm: N=%d must be a multiple of %d for this dtype", a.N, Panel<T>::NP);
         return MTMP_ERR_ARG;
     }
-#ifndef MTMP_LNG_OLD
-    if constexpr (sizeof(T) == 2) return launch_ln_gemm_dma(a, relu, 0, st);
-#endif
+    if constexpr (sizeof(T) == 2) return launch_ln_gemm_dma(1, &a, relu, 0, st);
     if (sm > 48 * 1024) {
         const void* fs[4] = {(const void*)ln_gemm_kernel<T, false, false>, (const void*)ln_gemm_kernel<T, false, true>,
                              (const void*)ln_gemm_kernel<T, true, false>, (const void*)ln_gemm_kernel<T, true, true>};
@@ -1993,7 +1468,8 @@ int launch_ln_gemm(GemmArgs<T> a, int relu, hipStream_t st) {
     return MTMP_OK;
 }
 template <typename T, int TM>
-int launch_gemm_nt_tm(GemmArgs<T> a, int relu, hipStream_t st) {
+int launch_gemm_nt_tm(int n, const GemmArgs<T>* segs, int relu, hipStream_t st) {
+    const GemmArgs<T>& a = segs[0];
     size_t sm = (size_t)(TM + BN) * LDW * sizeof(T);
     const size_t stage = (size_t)TM * LDO * sizeof(T);
     if (sm < stage) sm = stage;
@@ -2006,19 +1482,30 @@ int launch_gemm_nt_tm(GemmArgs<T> a, int relu, hipStream_t st) {
             return MTMP_ERR_LAUNCH;
         }
     }
-    dim3 grid(((a.M + TM - 1) / TM) * ((a.N + BN - 1) / BN));
+    int nwg;
+    const Grouped<GemmArgs<T>> g = make_group(n, segs, [](const GemmArgs<T>& x) { return ((x.M + TM - 1) / TM) * ((x.N + BN - 1) / BN); }, nwg);
+    dim3 grid(nwg);
     const bool drop = a.drop_p > 0.f;
-    if (relu && drop)       hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM, true>), grid, dim3(256), sm, st, a);
-    else if (relu)          hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM, false>), grid, dim3(256), sm, st, a);
-    else if (drop)          hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM, true>), grid, dim3(256), sm, st, a);
-    else                    hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM, false>), grid, dim3(256), sm, st, a);
+    if (relu && drop)       hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM, true>), grid, dim3(256), sm, st, g);
+    else if (relu)          hipLaunchKernelGGL((gemm_nt_kernel<T, true, TM, false>), grid, dim3(256), sm, st, g);
+    else if (drop)          hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM, true>), grid, dim3(256), sm, st, g);
+    else                    hipLaunchKernelGGL((gemm_nt_kernel<T, false, TM, false>), grid, dim3(256), sm, st, g);
     MTMP_CHECK_LAUNCH("mtmp_gemm_nt");
     return MTMP_OK;
 }
+// n segments in one launch: same N, K, activation, dropout switch; the tile height by the size of the whole grid
 template <typename T>
-int launch_gemm_nt(GemmArgs<T> a, int relu, hipStream_t st) {
-    const long long wgs128 = (long long)((a.M + 127) / 128) * ((a.N + BN - 1) / BN);
-    return wgs128 < 512 ? launch_gemm_nt_tm<T, 64>(a, relu, st) : launch_gemm_nt_tm<T, 128>(a, relu, st);
+int launch_gemm_nt(int n, const GemmArgs<T>* segs, int relu, hipStream_t st) {
+    long long wgs128 = 0;
+    for (int i = 0; i < n; ++i) {
+        wgs128 += (long long)((segs[i].M + 127) / 128) * ((segs[i].N + BN - 1) / BN);
+        if (segs[i].N != segs[0].N || segs[i].K != segs[0].K || segs[i].act != segs[0].act ||
+            (segs[i].drop_p > 0.f) != (segs[0].drop_p > 0.f)) {
+            mtmp_set_error("mtmp_gemm_nt (grouped): the streams of one launch must agree in N, K, activation and dropout");
+            return MTMP_ERR_ARG;
+        }
+    }
+    return wgs128 < 512 ? launch_gemm_nt_tm<T, 64>(n, segs, relu, st) : launch_gemm_nt_tm<T, 128>(n, segs, relu, st);
 }
 // ---------------------------------------------------------------------------
 // dX of a LayerNorm-fed projection fused with that LayerNorm's backward (autograd of module.py:138-144 in front of
@@ -2038,13 +1525,16 @@ template <typename T> struct LnBwdGemmArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kernel(LnBwdGemmArgs<T> p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kernel(Grouped<LnBwdGemmArgs<T>> grp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int seg = grp_find(grp, (int)blockIdx.x);
+    const LnBwdGemmArgs<T>& p = grp.seg[seg];
+    const int bx = (int)blockIdx.x - grp.first[seg];
     T* sA = reinterpret_cast<T*>(smem_raw);   // [128][LDW]  dY tile
     T* sW = sA + 128 * LDW;                   // [256][LDW]  W^T tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int wr = wave & 1, wc = wave >> 1;
-    const int m0 = blockIdx.x * 128;
+    const int m0 = bx * 128;
     const int nk = (p.K + BK - 1) / BK;
     TileRegs<T> areg, wreg0, wreg1;
     tile_fetch<T>(areg, p.dy, p.ldy, m0, p.M, 0, tid, p.K);
@@ -2136,11 +1626,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kern
         }
     }
     __syncthreads();                          // all rows of sX are consumed: its head becomes the partials' scratch
-    flush_partials<2>(part, p.slab + (size_t)blockIdx.x * 512, reinterpret_cast<float*>(smem_raw), lane, wave);
+    flush_partials<2>(part, p.slab + (size_t)bx * 512, reinterpret_cast<float*>(smem_raw), lane, wave);
 }
 
 template <typename T>
-int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStream_t st) {
+int launch_gemm_lnbwd(int n, LnBwdGemmArgs<T>* segs, float* const* dgamma_dbeta, float* const* ws, hipStream_t st) {
     size_t sm = (size_t)(128 + 256) * LDW * sizeof(T);
     const size_t stage = (size_t)128 * LDXT * sizeof(T);
     if (sm < stage) sm = stage;
@@ -2150,13 +1640,23 @@ int launch_gemm_lnbwd(LnBwdGemmArgs<T> a, float* dgamma_dbeta, float* ws, hipStr
         mtmp_set_error("mtmp_gemm_lnbwd: cannot raise dynamic LDS to %zu", sm);
         return MTMP_ERR_LAUNCH;
     }
-    const int nb = (a.M + 127) / 128;
-    a.slab = ws;
-    hipLaunchKernelGGL(gemm_lnbwd_kernel<T>, dim3(nb), dim3(256), sm, st, a);
+    for (int i = 0; i < n; ++i) {
+        segs[i].slab = ws[i];
+        if (segs[i].K != segs[0].K) {
+            mtmp_set_error("mtmp_gemm_lnbwd (grouped): the streams of one launch must agree in K");
+            return MTMP_ERR_ARG;
+        }
+    }
+    int nb;
+    const Grouped<LnBwdGemmArgs<T>> g = make_group(n, segs, [](const LnBwdGemmArgs<T>& x) { return (x.M + 127) / 128; }, nb);
+    hipLaunchKernelGGL(gemm_lnbwd_kernel<T>, dim3(nb), dim3(256), sm, st, g);
     MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd");
-    if (!dgamma_dbeta) return MTMP_OK;                        // partials only: the caller reduces them (mtmp_reduce_batch)
-    launch_slab_reduce(ws, nb, 512, ws + (size_t)nb * 512, dgamma_dbeta, st);
-    MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd(reduce)");
+    for (int i = 0; i < n; ++i) {
+        if (!dgamma_dbeta || !dgamma_dbeta[i]) continue;      // partials only: the caller reduces them (mtmp_reduce_batch)
+        const int nbi = (segs[i].M + 127) / 128;
+        launch_slab_reduce(ws[i], nbi, 512, ws[i] + (size_t)nbi * 512, dgamma_dbeta[i], st);
+        MTMP_CHECK_LAUNCH("mtmp_gemm_lnbwd(reduce)");
+    }
     return MTMP_OK;
 }
 
@@ -2170,26 +1670,10 @@ int tn_launch_splits(bool tr, int M, int N, int K, int* mode_out) {
     // a workgroup of the image / text streams' concurrent launches delays one of them to a second round; with a quarter of the
     // CUs left free the launch is ~15 % longer alone and the step shorter (9.03-9.06 / 9.25-9.35 ms against 9.11-9.14 / 9.30-9.42
     // with 256, two boxes; 224: 9.08-9.11; 160 and 128: no better than 256).
-#ifndef MTMP_TN_WGS
-#define MTMP_TN_WGS 192
-#endif
-    const bool two = tr && tn_splits(M, N, K, MTMP_TN_WGS) * 8 * TK <= M;
-    int mode = two ? 1 : 0, splits = tn_splits(M, N, K, two ? MTMP_TN_WGS : (tr ? 512 : 640));
-#ifndef MTMP_TN_OLD
-#ifndef MTMP_TN_WIDE
+    constexpr int TN_WGS = 192;
+    const bool two = tr && tn_splits(M, N, K, TN_WGS) * 8 * TK <= M;
+    int mode = two ? 1 : 0, splits = tn_splits(M, N, K, two ? TN_WGS : (tr ? 512 : 640));
     if (two && K >= 256) mode = 3;                         // the DMA kernel with 128 x 128 tiles, split count of `two`
-#else
-    // (A/B build: 128 x 256 tiles.  33 / 40 us per launch against 38 / 46 us for the 128 x 128 form alone, but twice the partial-
-    //  slab bytes (33 MB written, and read again by the reduction) in a step whose streams share the HBM: 9.12-9.33 ms/step
-    //  against 9.15-9.18, the register-staged kernel 9.30-9.34, one box)
-    if (two && K % 256 == 0) {
-        const int tiles = (N / 128) * (K / 256), max_s = (M + 4 * TK - 1) / (4 * TK);
-        splits = 256 / tiles > max_s ? max_s : 256 / tiles;
-        if (splits < 1) splits = 1;
-        mode = 2;
-    }
-#endif
-#endif
     if (mode_out) *mode_out = mode;
     return splits;
 }
@@ -2217,8 +1701,10 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     }
     const dim3 grid(splits * (N / 128) * (K / 128)), grid_w(splits * (N / 128) * (K / 256));
     if constexpr (TR) {
-        if (dma && wide) hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid_w, dim3(512), sm, st, a);
-        else if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, grid, dim3(512), sm, st, a);
+        int nwg;
+        const Grouped<TnArgs<bf16>> g = make_group(1, &a, [&](const TnArgs<bf16>& x) { return (int)(wide ? grid_w.x : grid.x); }, nwg);
+        if (dma && wide) hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid_w, dim3(512), sm, st, g);
+        else if (dma) hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, grid, dim3(512), sm, st, g);
         else if (two) hipLaunchKernelGGL(gemm_tn_tr_kernel<2>, grid, dim3(512), sm, st, a);
         else     hipLaunchKernelGGL(gemm_tn_tr_kernel<1>, grid, dim3(256), sm, st, a);
     } else {
@@ -2235,6 +1721,37 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     const size_t blocks = (cols + 4 * (256 / rlanes) - 1) / (4 * (256 / rlanes));
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), 1), dim3(256), 0, st, t);
     MTMP_CHECK_LAUNCH("mtmp_gemm_tn(reduce)");
+    return MTMP_OK;
+}
+
+// Grouped weight gradients (bf16, LDS-DMA kernel): the same product of up to three token streams in one launch, partial slabs
+// only (the caller reduces them with mtmp_reduce_batch).  The longest stream is split as its single launch would be; the others
+// so that a workgroup walks about as many tokens (a workgroup = one 128 x 128 tile of one split, one per CU).
+int tn_group_plan(int n, const int* M, int N, int K, int* splits) {
+    int big = 0;
+    for (int i = 1; i < n; ++i) if (M[i] > M[big]) big = i;
+    int mode;
+    const int s0 = tn_launch_splits(true, M[big], N, K, &mode);
+    if (mode != 3 || N % 128 || K % 128) return 1;            // the longest stream would not take the DMA kernel: no grouped form
+    const int target = (M[big] + s0 - 1) / s0;
+    for (int i = 0; i < n; ++i) {
+        int si = i == big ? s0 : (M[i] + target / 2) / target;
+        const int max_s = (M[i] + 4 * TK - 1) / (4 * TK);
+        if (si > max_s) si = max_s;
+        splits[i] = si < 1 ? 1 : si;
+    }
+    return 0;
+}
+int launch_gemm_tn_grouped(int n, TnArgs<bf16>* segs, hipStream_t st) {
+    const size_t sm = (size_t)TnDma<1>::DNS * TnDma<1>::DSTAGE;
+    if (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) {
+        mtmp_set_error("mtmp_gemm_tn: cannot raise dynamic LDS to %zu", sm);
+        return MTMP_ERR_LAUNCH;
+    }
+    int nwg;
+    const Grouped<TnArgs<bf16>> g = make_group(n, segs, [](const TnArgs<bf16>& x) { return x.splits * (x.N / 128) * (x.K / 128); }, nwg);
+    hipLaunchKernelGGL(gemm_tn_dma_kernel<1>, dim3(nwg), dim3(512), sm, st, g);
+    MTMP_CHECK_LAUNCH("mtmp_gemm_tn_grouped");
     return MTMP_OK;
 }
 
@@ -2282,7 +1799,7 @@ extern "C" int mtmp_ln_gemm_qkv(int dtype, const void* x, const float* gamma, co
     if (dtype == 1) {
         GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, gamma, beta, (bf16*)xn, stats,
                          M, 768, 256, ldx, 768, 0, eps, 0.f, 0u, nullptr, nullptr, 1.f, 0, nullptr, 1, nullptr, key_norms};
-        return launch_ln_gemm_dma(a, 0, 0, (hipStream_t)stream);
+        return launch_ln_gemm_dma(1, &a, 0, 0, (hipStream_t)stream);
     }
     if (int e = ln_gemm_entry(dtype, x, gamma, beta, w, bias, y, xn, stats, M, 768, ldx, 768, eps, 0, 0.f, 0u, nullptr, nullptr, stream)) return e;
     const size_t es = dtype == 0 ? 4 : 2;
@@ -2307,7 +1824,7 @@ extern "C" int mtmp_gemm_nt_signs(int dtype, const void* a, const void* w, void*
                    "mtmp_gemm_nt_signs: bad shape M=%d N=%d lda=%d ldy=%d (K is fixed at 256)", M, N, lda, ldy);
     GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, nullptr, nullptr, (bf16*)y, nullptr, nullptr, nullptr, nullptr, M, N, 256, lda, ldy,
                      0, 0.f, 0.f, 0u, nullptr, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs};
-    return launch_ln_gemm_dma(g, 0, 1, (hipStream_t)stream);
+    return launch_ln_gemm_dma(1, &g, 0, 1, (hipStream_t)stream);
 }
 
 // mtmp_gemm_nt_signs with the backward of a dropout on its A operand folded in (autograd of module.py:78-80 in front of the dH
@@ -2323,44 +1840,7 @@ extern "C" int mtmp_gemm_nt_signs_drop(int dtype, const void* a, const void* w, 
                    "mtmp_gemm_nt_signs_drop: bad argument M=%d N=%d lda=%d ldy=%d p=%f (K is fixed at 256)", M, N, lda, ldy, drop_p);
     GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, nullptr, nullptr, (bf16*)y, nullptr, nullptr, (bf16*)a_out, nullptr, M, N, 256, lda,
                      ldy, 0, 0.f, drop_p, seed, seed_dev, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs};
-    return launch_ln_gemm_dma(g, 0, 1, (hipStream_t)stream);
-}
-
-// y[M,N] = act(LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias), nn.LayerNorm semantics (biased variance, eps inside the
-// root): norm1 -> qkv and norm2 -> mlp.0 (+ GELU) of the 384-wide Swin blocks (swin_transformer.py:428-449) in one launch
-// each.  bf16 (dtype 1), C = 384, N % 64 == 0; act: 0 none, 2 exact GELU; bias may be NULL.
-extern "C" int mtmp_ln_linear_act(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias,
-                                  void* y, long long M, int C, int N, float eps, int act, void* stream) {
-    MTMP_CHECK_ARG(x && ln_w && ln_b && w && y, "mtmp_ln_linear_act: null pointer");
-    MTMP_CHECK_ARG(dtype == 1 && C == 384 && M > 0 && M < (1ll << 31) && N > 0 && N % 64 == 0 && (act == 0 || act == 2),
-                   "mtmp_ln_linear_act: bf16, C = 384, N %% 64 == 0, act 0 | 2 only (dtype=%d C=%d N=%d act=%d)", dtype, C, N, act);
-    GemmArgs<bf16> a{(const bf16*)x, (const bf16*)w, bias, nullptr, (bf16*)y, ln_w, ln_b, nullptr, nullptr, (int)M, N, C, C, N, 0, eps,
-                     0.f, 0u, nullptr, nullptr, 1.f, 0, nullptr, 1};
-    return launch_ln_linear_384(a, act == 2, (hipStream_t)stream);
-}
-
-// out[M,256] = x + drop2(h W2^T + b2),  h[M,1024] = drop1(relu(LN(x) W1^T + b1)): module.py:138-144, :74-80 and the residual of
-// encoder.py:32 in one launch (bf16, d_model 256 / d_ff 1024).  Also written: h (dW2's operand), xn = LN(x), stats (mean,
-// 1/(std+eps)) and the sign bits of h (mtmp_gemm_nt_signs' gate; may be NULL).  out must not alias x.
-extern "C" int mtmp_ffn_fwd(int dtype, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
-                            const void* w2, const float* b2, void* out, void* h, void* xn, float* stats, void* signs, int M, int ldx,
-                            float eps, float drop_p, unsigned seed1, unsigned seed2, const unsigned* seed_dev, void* stream) {
-    MTMP_CHECK_ARG(x && gamma && beta && w1 && b1 && w2 && b2 && out && h && x != out, "mtmp_ffn_fwd: null pointer / aliasing");
-    MTMP_CHECK_ARG(dtype == 1, "mtmp_ffn_fwd: bf16 only (dtype %d)", dtype);
-    MTMP_CHECK_ARG(M > 0 && ldx >= 256 && ldx % 8 == 0 && drop_p >= 0.f && drop_p < 1.f && (double)M * 1024 < 4294967296.0,
-                   "mtmp_ffn_fwd: bad shape M=%d ldx=%d drop_p=%f", M, ldx, drop_p);
-    FfnFwdArgs a{(const bf16*)x, gamma, beta, (const bf16*)w1, b1, (const bf16*)w2, b2, (bf16*)out, (bf16*)h, (bf16*)xn, stats,
-                 (unsigned short*)signs, M, ldx, eps, drop_p, seed1, seed2, seed_dev};
-    const void* f = drop_p > 0.f ? (const void*)ffn_fwd_kernel<true> : (const void*)ffn_fwd_kernel<false>;
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FfnLds::bytes) != hipSuccess) {
-        mtmp_set_error("mtmp_ffn_fwd: cannot raise dynamic LDS to %zu", FfnLds::bytes);
-        return MTMP_ERR_LAUNCH;
-    }
-    const dim3 grid((M + BM - 1) / BM);
-    if (drop_p > 0.f) hipLaunchKernelGGL(ffn_fwd_kernel<true>, grid, dim3(256), FfnLds::bytes, (hipStream_t)stream, a);
-    else              hipLaunchKernelGGL(ffn_fwd_kernel<false>, grid, dim3(256), FfnLds::bytes, (hipStream_t)stream, a);
-    MTMP_CHECK_LAUNCH("mtmp_ffn_fwd");
-    return MTMP_OK;
+    return launch_ln_gemm_dma(1, &g, 0, 1, (hipStream_t)stream);
 }
 
 // Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32
@@ -2380,13 +1860,13 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
         GemmArgs<float> g{(const float*)a, (const float*)w, bias, (const float*)res, (float*)y, nullptr, nullptr,
                           nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, seed_dev, (const float*)gate, gate_scale, act, row_scale,
                           rows_per_scale};
-        return launch_gemm_nt<float>(g, 0, st);
+        return launch_gemm_nt<float>(1, &g, 0, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, bias, (const bf16*)res, (bf16*)y, nullptr, nullptr, nullptr,
                          nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, seed_dev, (const bf16*)gate, gate_scale, act, row_scale,
                          rows_per_scale};
-        return launch_gemm_nt<bf16>(g, 0, st);
+        return launch_gemm_nt<bf16>(1, &g, 0, st);
     }
     mtmp_set_error("mtmp_gemm_nt: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
@@ -2408,12 +1888,12 @@ extern "C" int mtmp_gemm_lnbwd(int dtype, const void* dy, const void* wt, const 
     if (dtype == 0) {
         LnBwdGemmArgs<float> a{(const float*)dy, (const float*)wt, (const float*)z, stats, gamma, (const float*)d_res,
                                (float*)dz, nullptr, M, K, ldy, ldz, ldr, eps};
-        return launch_gemm_lnbwd<float>(a, dgamma_dbeta, ws, st);
+        return launch_gemm_lnbwd<float>(1, &a, &dgamma_dbeta, &ws, st);
     }
     if (dtype == 1) {
         LnBwdGemmArgs<bf16> a{(const bf16*)dy, (const bf16*)wt, (const bf16*)z, stats, gamma, (const bf16*)d_res,
                               (bf16*)dz, nullptr, M, K, ldy, ldz, ldr, eps};
-        return launch_gemm_lnbwd<bf16>(a, dgamma_dbeta, ws, st);
+        return launch_gemm_lnbwd<bf16>(1, &a, &dgamma_dbeta, &ws, st);
     }
     mtmp_set_error("mtmp_gemm_lnbwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
@@ -2469,6 +1949,131 @@ extern "C" int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw,
 
 namespace {
 // g_out[i] = keep(seed, i) ? g_in[i] / (1-p) : 0 -- backward of the epilogue dropout (same mask).
+// ------------------------------------------------------------------------------------------------------------------------
+// Grouped forms (bf16): the same operation of up to three token streams of one fusion layer in ONE launch (common.cuh, Grouped).
+// All pointer / int arrays are HOST arrays of n entries; scalars are common to the streams.  Same kernels, same results as n
+// calls of the single forms.  The parity (fp32) build keeps the single forms.
+#define MTMP_CHECK_GROUP(name, n, dtype)                                                                             \
+    MTMP_CHECK_ARG((n) >= 1 && (n) <= GRP_MAX && (dtype) == 1, name ": 1..%d streams, bf16 only (n=%d dtype=%d)", GRP_MAX, n, dtype)
+
+extern "C" int mtmp_ln_gemm_qkv_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
+                                        const void* const* w, const float* const* bias, void* const* y, void* const* xn,
+                                        float* const* stats, float* const* key_norms, const int* M, const int* ldx, float eps,
+                                        void* stream) {
+    MTMP_CHECK_GROUP("mtmp_ln_gemm_qkv_grouped", n, dtype);
+    GemmArgs<bf16> a[GRP_MAX];
+    for (int i = 0; i < n; ++i) {
+        MTMP_CHECK_ARG(x[i] && gamma[i] && beta[i] && w[i] && y[i] && key_norms[i] && M[i] > 0 && ldx[i] >= 256 && ldx[i] % 8 == 0,
+                       "mtmp_ln_gemm_qkv_grouped: bad argument (stream %d)", i);
+        a[i] = GemmArgs<bf16>{(const bf16*)x[i], (const bf16*)w[i], bias ? bias[i] : nullptr, nullptr, (bf16*)y[i], gamma[i], beta[i],
+                              xn ? (bf16*)xn[i] : nullptr, stats ? stats[i] : nullptr, M[i], 768, 256, ldx[i], 768, 0, eps, 0.f, 0u,
+                              nullptr, nullptr, 1.f, 0, nullptr, 1, nullptr, key_norms[i]};
+    }
+    return launch_ln_gemm_dma(n, a, 0, 0, (hipStream_t)stream);
+}
+
+// mtmp_ln_gemm_signs (FFN1: LayerNorm + Conv1d(k=1) + ReLU + drop1 + sign bits), N common, one seed per stream
+extern "C" int mtmp_ln_gemm_signs_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
+                                          const void* const* w, const float* const* bias, void* const* y, void* const* xn,
+                                          float* const* stats, void* const* signs, const int* M, int N, const int* ldx, float eps,
+                                          float drop_p, const unsigned* seeds, const unsigned* seed_dev, void* stream) {
+    MTMP_CHECK_GROUP("mtmp_ln_gemm_signs_grouped", n, dtype);
+    MTMP_CHECK_ARG(N > 0 && N % PanelDma::NP == 0 && drop_p >= 0.f && drop_p < 1.f, "mtmp_ln_gemm_signs_grouped: bad N=%d / dropout %f", N, drop_p);
+    GemmArgs<bf16> a[GRP_MAX];
+    for (int i = 0; i < n; ++i) {
+        MTMP_CHECK_ARG(x[i] && gamma[i] && beta[i] && w[i] && y[i] && signs[i] && M[i] > 0 && ldx[i] >= 256 && ldx[i] % 8 == 0 &&
+                           (double)M[i] * N < 4294967296.0, "mtmp_ln_gemm_signs_grouped: bad argument (stream %d)", i);
+        a[i] = GemmArgs<bf16>{(const bf16*)x[i], (const bf16*)w[i], bias ? bias[i] : nullptr, nullptr, (bf16*)y[i], gamma[i], beta[i],
+                              xn ? (bf16*)xn[i] : nullptr, stats ? stats[i] : nullptr, M[i], N, 256, ldx[i], N, 0, eps, drop_p,
+                              seeds ? seeds[i] : 0u, seed_dev, nullptr, 1.f, 0, nullptr, 1, (unsigned short*)signs[i]};
+    }
+    return launch_ln_gemm_dma(n, a, 1, 0, (hipStream_t)stream);
+}
+
+// mtmp_gemm_nt_signs_drop (dH = dY W2 through ReLU + drop1, drop2's backward on the operand), N common
+extern "C" int mtmp_gemm_nt_signs_drop_grouped(int dtype, int n, const void* const* a_in, const void* const* w, void* const* y,
+                                               const int* M, int N, const int* lda, const void* const* signs, float gate_scale,
+                                               float drop_p, const unsigned* seeds, const unsigned* seed_dev, void* const* a_out,
+                                               void* stream) {
+    MTMP_CHECK_GROUP("mtmp_gemm_nt_signs_drop_grouped", n, dtype);
+    MTMP_CHECK_ARG(N > 0 && N % PanelDma::NP == 0 && drop_p >= 0.f && drop_p < 1.f, "mtmp_gemm_nt_signs_drop_grouped: bad N=%d / dropout %f", N, drop_p);
+    GemmArgs<bf16> g[GRP_MAX];
+    for (int i = 0; i < n; ++i) {
+        MTMP_CHECK_ARG(a_in[i] && w[i] && y[i] && signs[i] && M[i] > 0 && M[i] < (1 << 24) && lda[i] >= 256 && lda[i] % 8 == 0,
+                       "mtmp_gemm_nt_signs_drop_grouped: bad argument (stream %d)", i);
+        g[i] = GemmArgs<bf16>{(const bf16*)a_in[i], (const bf16*)w[i], nullptr, nullptr, (bf16*)y[i], nullptr, nullptr,
+                              a_out ? (bf16*)a_out[i] : nullptr, nullptr, M[i], N, 256, lda[i], N, 0, 0.f, drop_p, seeds ? seeds[i] : 0u,
+                              seed_dev, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs[i]};
+    }
+    return launch_ln_gemm_dma(n, g, 0, 1, (hipStream_t)stream);
+}
+
+// mtmp_gemm_nt (FFN2: y = drop(a w^T + bias) + res), N / K / act common, no gate, no row scale
+extern "C" int mtmp_gemm_nt_grouped(int dtype, int n, const void* const* a_in, const void* const* w, const float* const* bias,
+                                    const void* const* res, void* const* y, const int* M, int N, int K, const int* lda, const int* ldy,
+                                    const int* ldr, int act, float drop_p, const unsigned* seeds, const unsigned* seed_dev,
+                                    void* stream) {
+    MTMP_CHECK_GROUP("mtmp_gemm_nt_grouped", n, dtype);
+    MTMP_CHECK_ARG(N > 0 && K > 0 && K % 8 == 0 && N % 32 == 0 && act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f,
+                   "mtmp_gemm_nt_grouped: bad shape N=%d K=%d act=%d p=%f", N, K, act, drop_p);
+    GemmArgs<bf16> g[GRP_MAX];
+    for (int i = 0; i < n; ++i) {
+        const bool has_res = res && res[i];
+        MTMP_CHECK_ARG(a_in[i] && w[i] && y[i] && M[i] > 0 && lda[i] >= K && lda[i] % 8 == 0 && ldy[i] >= N && ldy[i] % 8 == 0 &&
+                           (!has_res || (ldr[i] >= N && ldr[i] % 8 == 0)) && (double)M[i] * N < 4294967296.0,
+                       "mtmp_gemm_nt_grouped: bad argument (stream %d)", i);
+        g[i] = GemmArgs<bf16>{(const bf16*)a_in[i], (const bf16*)w[i], bias ? bias[i] : nullptr, has_res ? (const bf16*)res[i] : nullptr,
+                              (bf16*)y[i], nullptr, nullptr, nullptr, nullptr, M[i], N, K, lda[i], ldy[i], has_res ? ldr[i] : 0, 0.f,
+                              drop_p, seeds ? seeds[i] : 0u, seed_dev, nullptr, 1.f, act, nullptr, 1};
+    }
+    return launch_gemm_nt<bf16>(n, g, 0, (hipStream_t)stream);
+}
+
+// mtmp_gemm_lnbwd, partial slabs only (ws[i]: mtmp_gemm_lnbwd_ws_floats(M[i]) floats; reduce with mtmp_reduce_batch), K common
+extern "C" int mtmp_gemm_lnbwd_grouped(int dtype, int n, const void* const* dy, const void* const* wt, const void* const* z,
+                                       const int* ldz, const float* const* stats, const float* const* gamma, const void* const* d_res,
+                                       const int* ldr, void* const* dz, float* const* ws, const int* M, int K, const int* ldy, float eps,
+                                       void* stream) {
+    MTMP_CHECK_GROUP("mtmp_gemm_lnbwd_grouped", n, dtype);
+    MTMP_CHECK_ARG(K > 0 && K % 8 == 0, "mtmp_gemm_lnbwd_grouped: bad K=%d", K);
+    LnBwdGemmArgs<bf16> a[GRP_MAX];
+    for (int i = 0; i < n; ++i) {
+        const bool has_res = d_res && d_res[i];
+        MTMP_CHECK_ARG(dy[i] && wt[i] && z[i] && stats[i] && gamma[i] && dz[i] && ws[i] && M[i] > 0 && ldy[i] >= K && ldy[i] % 8 == 0 &&
+                           ldz[i] >= 256 && ldz[i] % 4 == 0 && (!has_res || (ldr[i] >= 256 && ldr[i] % 4 == 0)),
+                       "mtmp_gemm_lnbwd_grouped: bad argument (stream %d)", i);
+        a[i] = LnBwdGemmArgs<bf16>{(const bf16*)dy[i], (const bf16*)wt[i], (const bf16*)z[i], stats[i], gamma[i],
+                                   has_res ? (const bf16*)d_res[i] : nullptr, (bf16*)dz[i], nullptr, M[i], K, ldy[i], ldz[i],
+                                   has_res ? ldr[i] : 0, eps};
+    }
+    return launch_gemm_lnbwd<bf16>(n, a, nullptr, ws, (hipStream_t)stream);
+}
+
+// Weight gradients of up to three streams in one launch (bf16 LDS-DMA kernel), partial slabs only: ws[i] holds
+// splits[i] x (N K + N) floats, splits from mtmp_gemm_tn_group_plan (non-zero return: no grouped form for these shapes --
+// use mtmp_gemm_tn per stream); reduce with mtmp_reduce_batch (rows = splits[i]).
+extern "C" int mtmp_gemm_tn_group_plan(int n, const int* M, int N, int K, int* splits_out) {
+    if (n < 1 || n > GRP_MAX || !M || !splits_out || N <= 0 || K <= 0) return 1;
+    for (int i = 0; i < n; ++i) if (M[i] <= 0) return 1;
+    return tn_group_plan(n, M, N, K, splits_out);
+}
+extern "C" int mtmp_gemm_tn_grouped(int dtype, int n, const void* const* dy, const void* const* x, float* const* ws, const int* M,
+                                    int N, int K, const int* ldy, const int* ldx, const int* splits, void* stream) {
+    MTMP_CHECK_GROUP("mtmp_gemm_tn_grouped", n, dtype);
+    MTMP_CHECK_ARG(N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0, "mtmp_gemm_tn_grouped: N=%d K=%d must be multiples of 128", N, K);
+    TnArgs<bf16> a[GRP_MAX];
+    for (int i = 0; i < n; ++i) {
+        MTMP_CHECK_ARG(dy[i] && x[i] && ws[i] && M[i] > 0 && splits[i] >= 1 && ldy[i] >= N && ldx[i] >= K && ldy[i] % 8 == 0 &&
+                           ldx[i] % 8 == 0 && (uintptr_t)dy[i] % 16 == 0 && (uintptr_t)x[i] % 16 == 0 &&
+                           (unsigned long long)M[i] * (unsigned)(ldy[i] > ldx[i] ? ldy[i] : ldx[i]) * 2ull < (1ull << 32),
+                       "mtmp_gemm_tn_grouped: bad argument (stream %d)", i);
+        int rps = (M[i] + splits[i] - 1) / splits[i];
+        rps = (rps + TK - 1) / TK * TK;
+        a[i] = TnArgs<bf16>{(const bf16*)dy[i], (const bf16*)x[i], ws[i], M[i], N, K, ldy[i], ldx[i], splits[i], rps};
+    }
+    return launch_gemm_tn_grouped(n, a, (hipStream_t)stream);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* gi, T* go, size_t n4, unsigned seed0, const unsigned* seed_dev,
                                                           float p) {
@@ -2501,14 +2106,3 @@ extern "C" int mtmp_dropout_bwd(int dtype, const void* g_in, void* g_out, long l
     return MTMP_OK;
 }
 
-#ifdef MTMP_STAMP
-// diagnostic build: read and clear {barrier 1, load wait + transpose + LDS write, barrier 2, fetch issue + MFMA, steps}
-extern "C" int mtmp_debug_stamps_lng(unsigned long long* out2048) {
-    return hipMemcpyFromSymbol(out2048, HIP_SYMBOL(g_stamp_lng), 2048 * sizeof(unsigned long long)) != hipSuccess;
-}
-extern "C" int mtmp_debug_stamps_tn(unsigned long long* out8) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_tn), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    unsigned long long z[8] = {0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_tn), z, sizeof(z)) != hipSuccess;
-}
-#endif

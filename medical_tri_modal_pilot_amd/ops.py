@@ -6,6 +6,7 @@ path (LN+projection, attention fwd/bwd, FFN, LN backward, TIE embedding, stem,
 AdamW) is a libmtmp_hip.so kernel; there is no CPU or eager fallback -- inputs
 that are not on a GPU raise.
 """
+import contextlib
 import ctypes
 from typing import Optional
 
@@ -164,25 +165,6 @@ def stream_lengths(lens, n_bott, txt_idx):
     return pick(0), pick(1)
 
 
-def ffn_fwd(x2d, gamma, beta, w1, b1, w2, b2, drop_p=0.0, seeds=(0, 0), want_signs=True):
-    """The layer's FFN in one launch (bf16): returns (out = x + drop2(h w2^T + b2), h = drop1(relu(LN(x) w1^T + b1)), xn, stats,
-    sign bits of h | None) -- mtmp_ffn_fwd; the same masks and roundings as ln_gemm(relu, drop) followed by gemm_nt(res, drop)."""
-    _gpu(x2d, w1, w2)
-    if x2d.dtype != torch.bfloat16:
-        raise TypeError("ffn_fwd: bf16 only")
-    M = x2d.shape[0]
-    dev = x2d.device
-    out = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=dev)
-    h = torch.empty(M, 4 * D_MODEL, dtype=x2d.dtype, device=dev)
-    xn = torch.empty(M, D_MODEL, dtype=x2d.dtype, device=dev)
-    stats = torch.empty(M, 2, dtype=torch.float32, device=dev)
-    signs = torch.empty(_lib.lib().mtmp_sign_bits_bytes(M, 4 * D_MODEL), dtype=torch.uint8, device=dev) if want_signs else None
-    call("mtmp_ffn_fwd", _dt(x2d), _p(x2d), _p(gamma), _p(beta), _p(w1), _p(b1), _p(w2), _p(b2), _p(out), _p(h), _p(xn), _p(stats),
-         _p(signs), M, x2d.stride(0), LN_EPS, float(drop_p), int(seeds[0]) & 0xFFFFFFFF, int(seeds[1]) & 0xFFFFFFFF, _p(_seed_word),
-         _stream())
-    return out, h, xn, stats, signs
-
-
 def transpose_batch(mats):
     """[m.t().contiguous() for m in mats] (2-D, contiguous, one 16- or 32-bit dtype) in ONE launch; the results are views of
     one buffer."""
@@ -271,29 +253,18 @@ def swin_mlp(x2d, ln_w, ln_b, eps, w1, b1, w2, b2, row_scale=None, rows_per_scal
 
 
 # measured on 64 images: C = 96: 53 us against 16 + 69 us for mtmp_layernorm_rows + mtmp_gemm_nt; C = 192: 68 us against
-# 11 + 39 us (every wave re-reads the 221 KB weight from L2) -- so only the first stage takes the fused launch
-# Widths at which the Swin blocks take the fused norm1 -> qkv launch / the fused norm2 -> mlp.0 -> GELU launch.  384 (stage 3,
-# mtmp_ln_linear_act) is built and tested but NOT routed: per launch it beats layernorm_rows + gemm_nt (20 vs 27 us, 24 vs 32 us
-# at half batch), per encoder forward it does not (1773-1803 vs 1754-1810 us over the four split / un-split combinations,
-# tools/dbg/swin_tail_ab.py): 9 us of its 20 are the LayerNorm prologue of a workgroup that holds a whole CU.
+# 11 + 39 us (every wave re-reads the 221 KB weight from L2) -- so only the first stage takes the fused launch.  (A row-panel
+# form for the 384-wide stage was built and measured in round 2: faster per launch, no gain per encoder forward; removed.)
 SWIN_LN_LINEAR_WIDTHS = (96,)
-SWIN_LN_FC1_WIDTHS = ()
 
 
-def swin_ln_linear(x2d, ln_w, ln_b, eps, w, bias, act=None):
-    """x2d [M,C] bf16 -> act(LayerNorm(x2d) w^T + bias) [M,N] in one launch: mtmp_swin_ln_linear (C = 96 or 192, no activation)
-    or the row-panel kernel mtmp_ln_linear_act (C = 384; act None | "gelu")."""
+def swin_ln_linear(x2d, ln_w, ln_b, eps, w, bias):
+    """x2d [M,C] bf16 -> LayerNorm(x2d) w^T + bias [M,N] in one launch (mtmp_swin_ln_linear, C = 96 or 192)."""
     _gpu(x2d)
     x2d = _c(x2d)
     M, C = x2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
-    if C == 384:
-        call("mtmp_ln_linear_act", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), ACT[act],
-             _stream())
-        return y
-    if act is not None:
-        raise ValueError("swin_ln_linear: an activation needs C = 384")
     call("mtmp_swin_ln_linear", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), _stream())
     return y
 
@@ -385,6 +356,147 @@ def attn_bwd(qkv, o, d_o, lse, kv_len):
          _p(lse), _p(kv_len), _p(dqkv), _p(dqkv, D_MODEL * es), _p(dqkv, 2 * D_MODEL * es), _p(delta),
          B, N, N_HEAD, qkv.stride(1), o.stride(1), d_o.stride(1), dqkv.stride(1), D_HEAD ** -0.5, _stream())
     return dqkv
+
+
+def _ptrs(ts, byte_offset=0):
+    """host array of n device pointers (None entries -> NULL)"""
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() + byte_offset for t in ts])
+
+
+def _ints(vs):
+    return (ctypes.c_int * len(vs))(*vs)
+
+
+def attn_fwd_grouped(qkvs, kv_lens, ress, knorms):
+    """attn_fwd for up to three streams in ONE launch: lists of qkv [B,N_i,768], kv_len, res, knorm (entries may be None)
+    -> lists (o, o_res, lse)."""
+    _gpu(*qkvs)
+    n, B = len(qkvs), qkvs[0].shape[0]
+    es, dt, dev = qkvs[0].element_size(), qkvs[0].dtype, qkvs[0].device
+    Ns = [q.shape[1] for q in qkvs]
+    o = [torch.empty(B, N, D_MODEL, dtype=dt, device=dev) for N in Ns]
+    o_res = [None if r is None else torch.empty(B, N, D_MODEL, dtype=dt, device=dev) for N, r in zip(Ns, ress)]
+    lse = [torch.empty(B, N_HEAD, N, dtype=torch.float32, device=dev) for N in Ns]
+    call("mtmp_attn_fwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(o),
+         _ptrs(ress), _ptrs(o_res), _ptrs(lse), _ptrs(kv_lens), _ptrs(knorms), _ints(Ns), _ints([q.stride(1) for q in qkvs]),
+         _ints([D_MODEL] * n), B, N_HEAD, D_HEAD ** -0.5, _stream())
+    return o, o_res, lse
+
+
+def attn_bwd_grouped(qkvs, os_, d_os, lses, kv_lens):
+    """attn_bwd for up to three streams in two launches (dQ, dK/dV) -> list of dqkv [B,N_i,768]."""
+    _gpu(*qkvs)
+    n, B = len(qkvs), qkvs[0].shape[0]
+    es = qkvs[0].element_size()
+    Ns = [q.shape[1] for q in qkvs]
+    dqkv = [torch.empty_like(q) for q in qkvs]
+    delta = [torch.empty(B * N_HEAD * N, dtype=torch.float32, device=qkvs[0].device) for N in Ns]
+    call("mtmp_attn_bwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(os_),
+         _ptrs(d_os), _ptrs(lses), _ptrs(kv_lens), _ptrs(dqkv), _ptrs(dqkv, D_MODEL * es), _ptrs(dqkv, 2 * D_MODEL * es),
+         _ptrs(delta), _ints(Ns), _ints([q.stride(1) for q in qkvs]), _ints([o.stride(1) for o in os_]),
+         _ints([d.stride(1) for d in d_os]), _ints([d.stride(1) for d in dqkv]), B, N_HEAD, D_HEAD ** -0.5, _stream())
+    return dqkv
+
+
+def _uints(vs):
+    return (ctypes.c_uint * len(vs))(*[int(v) & 0xFFFFFFFF for v in vs])
+
+
+def ln_gemm_qkv_grouped(xs, gammas, betas, ws, biases):
+    """ln_gemm_qkv of up to three streams in one launch (bf16): lists -> lists (qkv, xn, stats, knorm)."""
+    _gpu(*xs)
+    n, dt, dev = len(xs), xs[0].dtype, xs[0].device
+    Ms = [x.shape[0] for x in xs]
+    y = [torch.empty(M, 3 * D_MODEL, dtype=dt, device=dev) for M in Ms]
+    xn = [torch.empty(M, D_MODEL, dtype=dt, device=dev) for M in Ms]
+    st = [torch.empty(M, 2, dtype=torch.float32, device=dev) for M in Ms]
+    kn = [torch.empty(_lib.lib().mtmp_key_norms_floats(M, N_HEAD), dtype=torch.float32, device=dev) for M in Ms]
+    call("mtmp_ln_gemm_qkv_grouped", _dt(xs[0]), n, _ptrs(xs), _ptrs(gammas), _ptrs(betas), _ptrs(ws), _ptrs(biases), _ptrs(y),
+         _ptrs(xn), _ptrs(st), _ptrs(kn), _ints(Ms), _ints([x.stride(0) for x in xs]), LN_EPS, _stream())
+    return y, xn, st, [k.view(-1, N_HEAD) for k in kn]
+
+
+def ln_gemm_signs_grouped(xs, gammas, betas, ws, biases, n_out, drop_p, seeds):
+    """ln_gemm(relu, dropout, sign bits) of up to three streams in one launch (bf16): lists -> lists (y, xn, stats, signs)."""
+    _gpu(*xs)
+    n, dt, dev = len(xs), xs[0].dtype, xs[0].device
+    Ms = [x.shape[0] for x in xs]
+    y = [torch.empty(M, n_out, dtype=dt, device=dev) for M in Ms]
+    xn = [torch.empty(M, D_MODEL, dtype=dt, device=dev) for M in Ms]
+    st = [torch.empty(M, 2, dtype=torch.float32, device=dev) for M in Ms]
+    sg = [torch.empty(_lib.lib().mtmp_sign_bits_bytes(M, n_out), dtype=torch.uint8, device=dev) for M in Ms]
+    call("mtmp_ln_gemm_signs_grouped", _dt(xs[0]), n, _ptrs(xs), _ptrs(gammas), _ptrs(betas), _ptrs(ws), _ptrs(biases), _ptrs(y),
+         _ptrs(xn), _ptrs(st), _ptrs(sg), _ints(Ms), n_out, _ints([x.stride(0) for x in xs]), LN_EPS, float(drop_p), _uints(seeds),
+         _p(_seed_word), _stream())
+    return y, xn, st, sg
+
+
+def gemm_nt_grouped(as_, ws, biases, ress, drop_p, seeds):
+    """gemm_nt (bias, dropout, residual) of up to three streams in one launch (bf16): lists -> list of y."""
+    _gpu(*as_)
+    n, dt, dev = len(as_), as_[0].dtype, as_[0].device
+    Ms, K, N = [a.shape[0] for a in as_], as_[0].shape[1], ws[0].shape[0]
+    y = [torch.empty(M, N, dtype=dt, device=dev) for M in Ms]
+    call("mtmp_gemm_nt_grouped", _dt(as_[0]), n, _ptrs(as_), _ptrs(ws), _ptrs(biases), _ptrs(ress), _ptrs(y), _ints(Ms), N, K,
+         _ints([a.stride(0) for a in as_]), _ints([N] * n), _ints([0 if r is None else r.stride(0) for r in ress]), 0, float(drop_p),
+         _uints(seeds), _p(_seed_word), _stream())
+    return y
+
+
+def gemm_nt_signs_drop_grouped(as_, ws, signs, gate_scale, drop_p, seeds):
+    """gemm_nt_signs (with the dropout backward of the operand folded in when drop_p > 0) of up to three streams in one
+    launch: lists -> (list of y, list of dropped operands | the operands themselves when drop_p == 0)."""
+    _gpu(*as_)
+    n, dt, dev = len(as_), as_[0].dtype, as_[0].device
+    Ms, N = [a.shape[0] for a in as_], ws[0].shape[0]
+    y = [torch.empty(M, N, dtype=dt, device=dev) for M in Ms]
+    ad = [torch.empty(M, a.shape[1], dtype=dt, device=dev) for M, a in zip(Ms, as_)] if drop_p > 0 else None
+    call("mtmp_gemm_nt_signs_drop_grouped", _dt(as_[0]), n, _ptrs(as_), _ptrs(ws), _ptrs(y), _ints(Ms), N,
+         _ints([a.stride(0) for a in as_]), _ptrs(signs), float(gate_scale), float(drop_p), _uints(seeds), _p(_seed_word),
+         None if ad is None else _ptrs(ad), _stream())
+    return y, (ad if ad is not None else list(as_))
+
+
+def gemm_lnbwd_grouped(dys, wts, zs, statss, gammas, d_ress, gb_outs, defers):
+    """gemm_lnbwd of up to three streams in one launch, reductions deferred: lists -> list of (dz, dgamma, dbeta);
+    defers[i] receives stream i's reduction entry (reduce_batch)."""
+    _gpu(*dys)
+    n, dev = len(dys), dys[0].device
+    Ms, K = [d.shape[0] for d in dys], dys[0].shape[1]
+    dz = [torch.empty(M, D_MODEL, dtype=z.dtype, device=dev) for M, z in zip(Ms, zs)]
+    gb = [g if g is not None else torch.empty(2 * D_MODEL, dtype=torch.float32, device=dev) for g in gb_outs]
+    ws = [torch.empty(_lib.lib().mtmp_gemm_lnbwd_ws_floats(M), dtype=torch.float32, device=dev) for M in Ms]
+    call("mtmp_gemm_lnbwd_grouped", _dt(zs[0]), n, _ptrs(dys), _ptrs(wts), _ptrs(zs), _ints([z.stride(0) for z in zs]), _ptrs(statss),
+         _ptrs(gammas), _ptrs(d_ress), _ints([0 if r is None else r.stride(0) for r in d_ress]), _ptrs(dz), _ptrs(ws), _ints(Ms), K,
+         _ints([d.stride(0) for d in dys]), LN_EPS, _stream())
+    for i in range(n):
+        defers[i].append((ws[i], _lib.lib().mtmp_gemm_lnbwd_slab_rows(Ms[i]), 2 * D_MODEL, gb[i], 2 * D_MODEL, None))
+    return [(dz[i], gb[i][:D_MODEL], gb[i][D_MODEL:]) for i in range(n)]
+
+
+def gemm_tn_grouped(dys, xs, outs, defers):
+    """gemm_tn of up to three streams in one launch (LDS-DMA kernel), reductions deferred: lists -> list of (dw, db).
+    Falls back to one gemm_tn per stream when the shapes have no grouped form (short streams)."""
+    _gpu(*dys)
+    n, dev = len(dys), dys[0].device
+    Ms, N, K = [d.shape[0] for d in dys], dys[0].shape[1], xs[0].shape[1]
+    splits = (ctypes.c_int * n)()
+    if dys[0].dtype != torch.bfloat16 or _lib.lib().mtmp_gemm_tn_group_plan(n, _ints(Ms), N, K, splits) != 0:
+        return [gemm_tn(dys[i], xs[i], out=outs[i], defer=defers[i]) for i in range(n)]
+    res, wss = [], []
+    for i in range(n):
+        if outs[i] is not None:
+            dw, db = outs[i]
+        else:
+            dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+        res.append((dw, db))
+        wss.append(torch.empty(splits[i] * (N * K + N), dtype=torch.float32, device=dev))
+    call("mtmp_gemm_tn_grouped", _dt(dys[0]), n, _ptrs(dys), _ptrs(xs), _ptrs(wss), _ints(Ms), N, K,
+         _ints([d.stride(0) for d in dys]), _ints([x.stride(0) for x in xs]), splits, _stream())
+    for i in range(n):
+        defers[i].append((wss[i], int(splits[i]), N * K + N, res[i][0], N * K, res[i][1]))
+    return res
 
 
 def ln_bwd(z2d, stats, gamma, dy2d, d_res2d=None, gb_out=None):
@@ -737,15 +849,6 @@ PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, 
 STREAM_ISSUE_ORDER_FWD = (0, 1, 2)
 STREAM_ISSUE_ORDER_BWD = (0, 1, 2)
 
-# The FFN half of a layer as ONE launch (mtmp_ffn_fwd) instead of mtmp_ln_gemm_signs + mtmp_gemm_nt (bit-identical results).
-# Built, tested (tests/test_gpu_parity.py::test_ffn_fwd_fused_equals_two_launches), NOT routed: 137 us against 138-147 us back to
-# back, but 160 us per launch inside the step against ~128 us for the pair (main-queue kernel time of a profiled replay 7.60 vs
-# 7.37 ms): one workgroup per CU (128 KiB of weight panels, 350 registers) runs the 503 row blocks in two rounds and shares the
-# CU with nothing; its panel loop sits at 5.2 k cycles per 64 MFMAs (tools/dbg/stamp_ffn.py).
-FUSED_FFN_FWD = False
-FUSED_FFN_MIN_ROWS = 32768
-
-
 def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T, wqkv^T, w1^T) in compute dtype.
     Returns (out [B,N,256], saved tuple)."""
@@ -758,11 +861,8 @@ def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     qkv = qkv.view(B, N, 3 * D)
     o, r1, lse = attn_fwd(qkv, kv_len, res=z, knorm=knorm)
     r1_2 = r1.view(M, D)
-    if FUSED_FFN_FWD and z.dtype == torch.bfloat16 and M >= FUSED_FFN_MIN_ROWS:
-        out, h, xn2, st2, hsign = ffn_fwd(r1_2, g2, b2, w1c, c1, w2c, c2, drop_p=drop_p, seeds=seeds)
-    else:
-        h, xn2, st2, hsign = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
-        out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
+    h, xn2, st2, hsign = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
+    out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
     saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds, hsign)
     return out.view(B, N, D), saved
 
@@ -841,6 +941,82 @@ def layer_backward(saved, d_out, sink=None, late=None):
     return dz.view(B, N, D), grads
 
 
+# One launch per layer step over the active streams (bf16): csrc/common.cuh, Grouped.  The three streams of a fusion layer are
+# 1005 / 54 / 133 tokens long; as three launches on three HIP streams the short ones held whole-CU workgroup slots beside the
+# long one's kernels (round 2: every vital-sign-stream kernel 15-40 % slower in the step than alone, ~1.2 ms per step, ~200
+# launches).  The parity (fp32) build keeps one launch per stream.
+GROUPED_LAUNCHES = True
+
+
+def grouped_ok(z) -> bool:
+    return GROUPED_LAUNCHES and z.dtype == torch.bfloat16
+
+
+def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds):
+    """layer_forward for the active streams of one fusion layer with ONE launch per step (lists, one entry per stream)."""
+    n = len(zs)
+    B, D = zs[0].shape[0], D_MODEL
+    Ns = [z.shape[1] for z in zs]
+    z2 = [z.view(B * N, D) for z, N in zip(zs, Ns)]
+    qkv, xn1, st1, knorm = ln_gemm_qkv_grouped(z2, [P[0] for P in Ps], [P[1] for P in Ps], [f[0] for f in fuseds], [f[1] for f in fuseds])
+    qkv = [q.view(B, N, 3 * D) for q, N in zip(qkv, Ns)]
+    o, r1, lse = attn_fwd_grouped(qkv, kv_lens, list(zs), knorm)
+    r1_2 = [r.view(B * N, D) for r, N in zip(r1, Ns)]
+    h, xn2, st2, hsign = ln_gemm_signs_grouped(r1_2, [P[8] for P in Ps], [P[9] for P in Ps], [f[2] for f in fuseds],
+                                               [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds])
+    out = gemm_nt_grouped(h, [f[3] for f in fuseds], [P[13] for P in Ps], r1_2, drop_p, [sd[1] for sd in seeds])
+    saved = [(zs[i], kv_lens[i], Ps[i][0], Ps[i][8], fuseds[i][5], fuseds[i][6], fuseds[i][4], xn1[i], st1[i], qkv[i], o[i], lse[i],
+              r1[i], xn2[i], st2[i], h[i], drop_p, seeds[i], hsign[i]) for i in range(n)]
+    return [out[i].view(B, Ns[i], D) for i in range(n)], saved
+
+
+def layer_backward_grouped(saveds, d_outs, sinks, late):
+    """layer_backward for the active streams of one fusion layer, one launch per step.  Returns (list of dz, list of
+    per-stream gradient tuples | None) like layer_backward; the reductions of ALL streams go into `late` as one entry."""
+    n = len(saveds)
+    B, D = saveds[0][0].shape[0], D_MODEL
+    Ns = [sv[0].shape[1] for sv in saveds]
+    Ms = [B * N for N in Ns]
+    p = saveds[0][16]
+    d_out = [d.view(M, D) for d, M in zip(d_outs, Ms)]
+    direct = [sk is not None and sk.usable() for sk in sinks]
+    reds = [[] for _ in range(n)]
+    col = lambda k: [sv[k] for sv in saveds]
+    z, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, hsign = (col(0), col(2), col(3), col(4), col(5), col(6), col(7),
+                                                                              col(8), col(9), col(10), col(11), col(12), col(13),
+                                                                              col(14), col(15), col(18))
+    kv = col(1)
+    seeds = col(17)
+    dh, dy2 = gemm_nt_signs_drop_grouped(d_out, w2t, hsign, 1.0 / (1.0 - p), p, [sd[1] for sd in seeds])
+    gw2 = gemm_tn_grouped(dy2, h, [(sinks[i].w2, sinks[i].c2) if direct[i] else None for i in range(n)], reds)
+    gw1 = gemm_tn_grouped(dh, xn2, [(sinks[i].w1, sinks[i].c1) if direct[i] else None for i in range(n)], reds)
+    r1_2 = [r.view(M, D) for r, M in zip(r1, Ms)]
+    l2 = gemm_lnbwd_grouped(dh, w1t, r1_2, st2, g2, d_out, [sinks[i].gb2 if direct[i] else None for i in range(n)], reds)
+    dr1 = [t[0] for t in l2]
+    dqkv = attn_bwd_grouped(qkv, o, [d.view(B, N, D) for d, N in zip(dr1, Ns)], lse, kv)
+    dqkv = [d.view(M, 3 * D) for d, M in zip(dqkv, Ms)]
+    gwq = gemm_tn_grouped(dqkv, xn1, [(sinks[i].wqkv, sinks[i].bqkv) if direct[i] else None for i in range(n)], reds)
+    l1 = gemm_lnbwd_grouped(dqkv, wqkvt, [t.view(M, D) for t, M in zip(z, Ms)], st1, g1, dr1,
+                            [sinks[i].gb1 if direct[i] else None for i in range(n)], reds)
+    allred = [e for r_ in reds for e in r_]
+    marks = [sinks[i] for i in range(n) if direct[i]]
+    if late is not None:
+        late.append((allred, marks))
+    else:
+        reduce_batch(allred)
+        for sk in marks:
+            sk.flat.mark_ready(sk.idx)
+    grads = []
+    for i in range(n):
+        if direct[i]:
+            grads.append(None)
+            continue
+        dwqkv, dbqkv = gwq[i]
+        grads.append((l1[i][1], l1[i][2], dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
+                      l2[i][1], l2[i][2], gw1[i][0], gw1[i][1], gw2[i][0], gw2[i][1]))
+    return [l1[i][0].view(B, Ns[i], D) for i in range(n)], grads
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """layer_forward / layer_backward as one autograd node (layer-level API and tests)."""
 
@@ -877,6 +1053,36 @@ def _exchange_w(dev):
     if k not in _exchange_w_dev:
         _exchange_w_dev[k] = _EXCHANGE_W.to(dev)
     return _exchange_w_dev[k]
+
+
+# How a layer's streams are cut into launches (bf16 build; the fp32 build launches per stream whatever the mode):
+#   "all"   -- one launch per step over all active streams, on the caller's stream
+#   "small" -- the vital-sign stream alone on the caller's stream, image + text together on side stream 0
+#   "none"  -- one launch group per stream (vital signs on the caller's stream, image / text on the two side streams)
+# Measured in one box (bench.py, ms/step): see DESIGN.md section 7.
+GROUP_MODE = "small"
+
+
+def launch_groups(ms, streams, z, solo=False):
+    """[(stream indices, HIP side stream | None)] for the active streams `ms` of one layer."""
+    mode = "none" if (solo or not grouped_ok(z)) else GROUP_MODE
+    if len(ms) == 1 or streams is None and mode != "all":
+        return [([m], None) for m in ms] if mode != "all" else [(list(ms), None)]
+    if mode == "all":
+        return [(list(ms), None)]
+    if mode == "small":
+        return [([ms[0]], None), (list(ms[1:]), streams[0])]
+    return [([m], None if m == ms[0] else streams[(m - 1) % len(streams)]) for m in ms]
+
+
+def stream_of_group(m, streams, z):
+    """the HIP side stream on which the group led by stream m runs its backward (None = the caller's stream)"""
+    if m == 0 or streams is None:
+        return None
+    mode = GROUP_MODE if grouped_ok(z) else "none"
+    if mode == "all":
+        return None
+    return streams[0] if mode == "small" else streams[(m - 1) % len(streams)]
 
 
 class FusionStackFn(torch.autograd.Function):
@@ -939,27 +1145,34 @@ class FusionStackFn(torch.autograd.Function):
             ms = [0] if last else list(range(n_s))
             outs = [None, None, None]
             row = [None, None, None]
-            if streams is not None and len(ms) > 1:
+            # launch groups of this layer: (streams, HIP stream).  Layer 0 keeps one group per stream while the image / text
+            # inputs are still being made on the side streams (the vital-sign stream's first layer runs beside the image encoder)
+            groups = launch_groups(ms, streams, z[0], solo=(li == 0 and bool(cfg.get("inputs_on_side"))))
+            if len(groups) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-            for m in [q for q in STREAM_ISSUE_ORDER_FWD if q in ms]:
-                P = params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER]
-                if streams is not None and m > 0:
-                    s = streams[m - 1]
-                    s.wait_event(ev)
-                    with torch.cuda.stream(s):
-                        mark(f"f{li}.m{m}.s")
-                        outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
-                                                        cfg["seeds"][li][m])
-                        mark(f"f{li}.m{m}.e")
-                else:
-                    mark(f"f{li}.m{m}.s")
-                    outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
-                                                    cfg["seeds"][li][m])
-                    mark(f"f{li}.m{m}.e")
-            if streams is not None and len(ms) > 1:
-                for s in streams:
-                    cur.wait_stream(s)
+            for gms, gs in groups:
+                if gs is not None:
+                    gs.wait_event(ev)
+                with (torch.cuda.stream(gs) if gs is not None else contextlib.nullcontext()):
+                    mark(f"f{li}.g{gms[0]}.s")
+                    if grouped_ok(z[0]):
+                        go, gsaved = layer_forward_grouped(
+                            [z[m] for m in gms], [cfg["kv"][m] for m in gms],
+                            [params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER] for m in gms],
+                            [cfg["fused"][li][m] for m in gms], cfg["drop_p"], [cfg["seeds"][li][m] for m in gms])
+                        for i, m in enumerate(gms):
+                            outs[m], row[m] = go[i], gsaved[i]
+                    else:
+                        for m in gms:
+                            P = params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER]
+                            outs[m], row[m] = layer_forward(z[m], cfg["kv"][m], P, cfg["fused"][li][m], cfg["drop_p"],
+                                                            cfg["seeds"][li][m])
+                    mark(f"f{li}.g{gms[0]}.e")
+            if len(groups) > 1:
+                for _, gs in groups:
+                    if gs is not None:
+                        cur.wait_stream(gs)
             saved.append(row)
             active.append(ms)
             if last:
@@ -1013,13 +1226,14 @@ class FusionStackFn(torch.autograd.Function):
         # A layer's gradient reductions (one mtmp_reduce_batch launch per stream) are issued one layer LATE, on the same stream:
         # the bottleneck exchange in between needs the streams' dz but none of their parameter gradients, and it is the image /
         # text streams' last launches that the vital-sign stream waits for there.
-        late = [[], [], []]
+        late = [[], [], []]          # keyed by the first stream of the launch group that produced them
 
         def flush_late(m):
-            for red, sk in late[m]:
+            for red, sks in late[m]:
                 reduce_batch(red)
-                if sk is not None:
-                    sk.flat.mark_ready(sk.idx)
+                for sk in (sks if isinstance(sks, (list, tuple)) else [sks]):
+                    if sk is not None:
+                        sk.flat.mark_ready(sk.idx)
             del late[m][:]
         for li in range(n_run - 1, -1, -1):
             ms = active[li]
@@ -1031,43 +1245,50 @@ class FusionStackFn(torch.autograd.Function):
                 bottleneck_exchange_bwd(dz, cfg["missing"], cfg["resbottle"], d_prev_bott, d_out_prev)
                 d_prev_bott = d_out_prev
             nxt = [None, None, None]
-            if streams is not None and len(ms) > 1:
+            groups = launch_groups(ms, streams, saved[li][ms[0]][0])
+            if len(groups) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-            for m in [q for q in STREAM_ISSUE_ORDER_BWD if q in ms]:
-                sink = cfg["sinks"][li][m] if cfg.get("sinks") else None
-                if streams is not None and m > 0:
-                    s = streams[m - 1]
-                    s.wait_event(ev)
-                    with torch.cuda.stream(s):
-                        mark(f"b{li}.m{m}.s")
-                        flush_late(m)                   # the layer above's reductions: behind this layer's exchange
-                        nxt[m], g = layer_backward(saved[li][m], dz[m], sink, late=late[m] if LATE_REDUCTIONS else None)
-                        mark(f"b{li}.m{m}.e")
-                else:
-                    mark(f"b{li}.m{m}.s")
-                    flush_late(m)
-                    nxt[m], g = layer_backward(saved[li][m], dz[m], sink, late=late[m] if LATE_REDUCTIONS else None)
-                    mark(f"b{li}.m{m}.e")
-                base = (li * n_s + m) * PARAMS_PER_LAYER
-                if g is not None:
-                    for k in range(PARAMS_PER_LAYER):
-                        pgrads[base + k] = g[k].view(pshapes[base + k])
-            if streams is not None and len(ms) > 1:
-                for s in streams:
-                    cur.wait_stream(s)
+            for gi, (gms, gs) in enumerate(groups):
+                if gs is not None:
+                    gs.wait_event(ev)
+                with (torch.cuda.stream(gs) if gs is not None else contextlib.nullcontext()):
+                    mark(f"b{li}.g{gms[0]}.s")
+                    flush_late(gms[0])                  # the layer above's reductions of this group: behind this layer's exchange
+                    lt = late[gms[0]] if LATE_REDUCTIONS else None
+                    if grouped_ok(saved[li][ms[0]][0]):
+                        gdz, gg = layer_backward_grouped([saved[li][m] for m in gms], [dz[m] for m in gms],
+                                                         [cfg["sinks"][li][m] if cfg.get("sinks") else None for m in gms], lt)
+                    else:
+                        gdz, gg = [], []
+                        for m in gms:
+                            d1, g1_ = layer_backward(saved[li][m], dz[m], cfg["sinks"][li][m] if cfg.get("sinks") else None, late=lt)
+                            gdz.append(d1)
+                            gg.append(g1_)
+                    for i, m in enumerate(gms):
+                        nxt[m] = gdz[i]
+                        if gg[i] is not None:
+                            base = (li * n_s + m) * PARAMS_PER_LAYER
+                            for k in range(PARAMS_PER_LAYER):
+                                pgrads[base + k] = gg[i][k].view(pshapes[base + k])
+                    mark(f"b{li}.g{gms[0]}.e")
+            if len(groups) > 1:
+                for _, gs in groups:
+                    if gs is not None:
+                        cur.wait_stream(gs)
             saved[li] = None
             # streams skipped by the vslt-only last layer re-enter here with zero gradient
             if len(ms) == 1 and li > 0:
                 for m in range(1, n_s):
                     nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
             dz = nxt
-        for m in range(3):                  # the first layer's reductions
+        for m in range(3):                  # the first layer's reductions, on the stream their group ran on
             if late[m]:
-                if streams is not None and m > 0:
-                    with torch.cuda.stream(streams[m - 1]):
+                gs = stream_of_group(m, streams, next(t for t in dz if t is not None))
+                if gs is not None:
+                    with torch.cuda.stream(gs):
                         flush_late(m)
-                    cur.wait_stream(streams[m - 1])
+                    cur.wait_stream(gs)
                 else:
                     flush_late(m)
         if cfg.get("prebuilt"):            # the bottleneck rows' gradient flows on through the stream-input nodes

@@ -81,26 +81,6 @@ def main():
                                   seed=3, want_signs=True)
         rec("gemm_nt.dH_signs[M,1024,256]", timeit(lambda: ops.gemm_nt_signs(dy, w2t, sg, 1.0 / 0.9), a.rounds), 2.0 * M * 1024 * 256,
             2.0 * M * (256 + 1024) + M * 128)
-    if want("ffn"):                 # the layer's FFN: two launches against the fused one
-        x0 = R(M, 256)
-        gm0, bt0 = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
-        w1, b1, w2, b2 = R(1024, 256) * 0.05, torch.zeros(1024, device=DEV), R(256, 1024) * 0.03, torch.zeros(256, device=DEV)
-        def two():
-            hh, _, _, _ = ops.ln_gemm(x0, gm0, bt0, w1, b1, 1024, relu=True, drop_p=0.1, seed=3, want_signs=True)
-            return ops.gemm_nt(hh, w2, b2, res2d=x0, drop_p=0.1, seed=4)
-        rec("ffn.two_launches[M]", timeit(two, a.rounds), 4.0 * M * 1024 * 256)
-        rec("ffn.fused[M]", timeit(lambda: ops.ffn_fwd(x0, gm0, bt0, w1, b1, w2, b2, drop_p=0.1, seeds=(3, 4)), a.rounds),
-            4.0 * M * 1024 * 256)
-    if want("swin3"):               # stage-3 projections of the image encoder at half batch (32 images x 196 tokens, C = 384)
-        C, rows = 384, 6272
-        xs = R(rows, C)
-        lw, lb = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
-        for n, act in ((3 * C, None), (4 * C, "gelu")):
-            w, b = R(n, C) * 0.05, torch.zeros(n, device=DEV)
-            rec(f"swin3.ln_linear[{rows},{n},{C}].{act}", timeit(lambda: ops.swin_ln_linear(xs, lw, lb, 1e-5, w, b, act=act), a.rounds),
-                2.0 * rows * n * C)
-            rec(f"swin3.chain[{rows},{n},{C}].{act}", timeit(lambda: ops.gemm_nt(ops.layernorm_rows(xs, lw, lb, 1e-5), w, b, act=act),
-                                                          a.rounds), 2.0 * rows * n * C)
     # ---- LN-fused GEMMs
     if want("ln_gemm"):
         x = R(M, 256)

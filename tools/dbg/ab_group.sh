@@ -1,0 +1,9 @@
+# A/B of the launch-group modes in one box: bash tools/dbg/ab_group.sh [rounds]
+O=medical_tri_modal_pilot_amd.ops
+A="--no-cpu-baseline --steps 30 --warmup 10 --probe-launches 0"
+for r in $(seq 1 ${1:-2}); do
+  for m in none small all; do
+    echo -n "GROUP_MODE=$m   "; python tools/dbg/ab_patch.py "$O.GROUP_MODE='$m'" -- $A 2>/dev/null | tail -1 || exit 1
+  done
+  echo -n "per-stream kernels (GROUPED_LAUNCHES=False)   "; python tools/dbg/ab_patch.py "$O.GROUPED_LAUNCHES=False" -- $A 2>/dev/null | tail -1 || exit 1
+done
