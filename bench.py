@@ -23,15 +23,19 @@ reported beside it (ms_per_step_median_host).
 
 The JSON line also carries
   roofline      -- the dominant kernel (key-masked attention forward, vslt stream): algorithmic FLOPs 4*B*H*N^2*64 per
-                   launch / launch duration, against the 2.5 PFLOP/s dense bf16 peak.  The duration is measured AFTER
-                   the timed region on the step's REAL layer-0 tensors (captured from one eager step): K back-to-back
-                   launches between ONE pair of HIP events on an otherwise idle device, so host enqueue latency cannot
-                   leak into it (round 1 bracketed single Python-side launches inside host-bound eager steps and read
-                   2.3x too long).  The rocprofv3 average of the same kernel inside the replayed steps is committed
-                   under profiles/ and quoted as rocprof_avg_us.
-  roofline_more -- the same probe for the attention backward and the weight-gradient GEMM of the vslt stream.
+                   launch / launch duration, against the 2.5 PFLOP/s dense bf16 peak.  `achieved` / `frac` are the IN-STEP
+                   figure, measured live here: after the timed region the step is re-captured with a stream-ordered time
+                   stamp (mtmp_timestamp: HIP events cannot be timed inside a replayed hipGraph) in front of and behind every
+                   attention-forward launch of the vital-sign stream, --instep-steps more steps are replayed, and the
+                   duration is the mean stamp difference minus the stamp pair's own gap (two stamps back to back in the same
+                   step).  `probe_*`: the same kernel on the same tensors, K back-to-back launches between ONE pair of HIP
+                   events on an otherwise idle device (no other stream of the step beside it) -- reported beside the in-step
+                   figure, never as `frac`.  The rocprofv3 average of the same kernel inside replayed steps is committed under
+                   profiles/ and quoted as rocprof_avg_us.
+  roofline_more -- the same two measurements for the attention backward and the weight-gradient GEMM of the vslt stream.
   cpu_baseline  -- the CPU oracle (fp32 PyTorch restatement of the reference, golden-pinned) timed on this host's
-                   cores on a bounded sample (rank 0, N=1 only).
+                   cores: BASELINE.md section 3 protocol (full per-GPU batch when the host has >= 32 GB of RAM, else B = 16
+                   scaled linearly; 1 warm-up + 3 timed steps, median), rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -77,20 +81,31 @@ def make_args(wl, dtype: str, dropout: float, hip_graph: int, graph_stages: int,
                        "--synthetic", "1"])
 
 
-def cpu_baseline(wl, shapes, sample_b: int = 8, timed: int = 2):
-    """Oracle (port of the reference's CPU path) on a bounded sample of the same workload."""
+def cpu_baseline(wl, shapes, budget_s: float = 150.0):
+    """Oracle (port of the reference's CPU path) on the workload's own batch: BASELINE.md section 3 -- the full per-GPU batch
+    when the host has >= 32 GB of RAM (config 2 needs ~22 GB), else B = 16 with linear scaling stated; 1 warm-up + 3 timed
+    steps, median.  The warm-up step is timed too: if three more would not fit `budget_s` (slow hosts; the driver's bench run
+    has ~10 minutes), fewer steps are timed and the sample says so."""
     from medical_tri_modal_pilot_amd import synthetic
     from oracle import tri_mbt_oracle as O
-    _, T, L, multi, K = WORKLOADS[wl][:5]
+    B, T, L, multi, K = WORKLOADS[wl][:5]
+    try:
+        ram_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+    except (ValueError, OSError):
+        ram_gb = 0.0
+    sample_b = B if ram_gb >= 32 else 16
     if wl == "cfg5":
-        sample_b = 2
+        sample_b = 2                                  # the reference formulation needs an 8.2 GB score tensor per layer at B = 128
     torch.manual_seed(0)
     sd = {k: synthetic.fill_tensor(k, torch.zeros(s)) for k, s in shapes.items()}
     sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
     bt = synthetic.make_batch(1234, sample_b, T, ragged=False, missing_mode="none", multiimages=multi, n_images=K)
     tr = O.OracleTrainer(sd, O.Cfg(n_layers=L, dropout=0.1, multiimages=multi), lr_init=1e-5, batch_size=sample_b,
                          iters_per_epoch=100)
+    t0 = time.perf_counter()
     tr.step(bt, 1)                                   # warm-up
+    warm = time.perf_counter() - t0
+    timed = max(1, min(3, int(budget_s // max(warm, 1e-3))))
     ts = []
     for i in range(timed):
         t0 = time.perf_counter()
@@ -98,8 +113,8 @@ def cpu_baseline(wl, shapes, sample_b: int = 8, timed: int = 2):
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
     return {"value": sample_b / t, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle full train step (fwd+BCE+bwd+AdamW), fp32, B={sample_b} of the workload's batch "
-                      f"(T={T}, L={L}), 1 warm-up + {timed} timed, median {t:.2f} s/step"}
+            "sample": f"oracle full train step (fwd+BCE+bwd+AdamW), fp32, B={sample_b} of the workload's batch of {B} "
+                      f"(T={T}, L={L}; host RAM {ram_gb:.0f} GB), 1 warm-up ({warm:.1f} s) + {timed} timed, median {t:.2f} s/step"}
 
 
 def parse():
@@ -118,7 +133,9 @@ def parse():
     ap.add_argument("--packed", type=int, default=0, choices=[0, 1],
                     help="feed the vital-sign events as the ragged PackedTieBatch of builder/data (SURVEY 8 f-1)")
     ap.add_argument("--probe-launches", type=int, default=30,
-                    help="back-to-back launches per kernel of the roofline probe after the timed region (0 = no probe)")
+                    help="back-to-back launches per kernel of the idle-device probe after the timed region (0 = no probe)")
+    ap.add_argument("--instep-steps", type=int, default=12,
+                    help="replayed steps with time stamps around the roofline kernels (the in-step duration; 0 = off)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the RCCL reducer even with one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--print-loss", action="store_true")
@@ -244,7 +261,7 @@ def main():
     loss, per_step = 0.0, []
     for i in range(a.steps):
         ts = time.perf_counter()
-        loss = step(a.warmup + i + 1)            # ends in loss.item(): the step's device work is complete
+        loss = step(a.warmup + i + 1)            # returns with the step's loss; under graph replay the backward / AdamW may still run
         per_step.append(time.perf_counter() - ts)
         if a.print_loss:
             print(f"step {a.warmup + i + 1} loss {loss:.6f}", file=sys.stderr)
@@ -267,12 +284,52 @@ def main():
     if not math.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")
 
-    # ---- roofline probe: the heavy vslt-stream kernels on the step's real tensors, back to back on an idle device
     n_tok = TIE_LEN + 5
+    flops = {"attn_fwd": 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
+             "attn_bwd": 10.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
+             "gemm_tn": 2.0 * B_PER_GPU * n_tok * 768 * 256}
+    # ---- in-step duration of the roofline kernels: the step re-captured with time stamps around them (ops.kernel_marks)
+    instep = {}
+    if a.instep_steps > 0 and graphed and a.dtype == "bf16":
+        ops.marks_enable(dev, 4096, only=("k.", "cal."))
+        if gs is not None:
+            gs.invalidate()                           # drop the captured graphs: the next steps capture the stamped step
+        raw_bce = ops.bce_with_logits
+
+        def bce_cal(*args_, **kws):                   # two stamps back to back inside the step: the stamp pair's own gap
+            ops.mark("cal.0.s")
+            ops.mark("cal.0.e")
+            return raw_bce(*args_, **kws)
+        ops.bce_with_logits = bce_cal
+        acc = {}
+        it0 = a.warmup + a.steps + 1
+        for i in range(a.instep_steps + 6):
+            ops.marks_new_step()
+            step(it0 + i)
+            torch.cuda.synchronize()
+            if i < 6:                                 # eager warm-up of the new signature + the capture itself
+                continue
+            mk = ops.marks_read()
+            for name, t in mk.items():
+                if name.endswith(".s") and name[:-2] + ".e" in mk:
+                    acc.setdefault(name[:-2].rsplit(".", 1)[0], []).append(mk[name[:-2] + ".e"] - t)
+        ops.bce_with_logits = raw_bce
+        ops.marks_disable()
+        if gs is not None:
+            gs.invalidate()
+        gap = statistics.mean(acc.get("cal", [0.0]))
+        for kind, key in (("attn_fwd", f"k.attn_fwd.N{n_tok}"), ("attn_bwd", f"k.attn_bwd.N{n_tok}"),
+                          ("gemm_tn", f"k.gemm_tn768x256.N{B_PER_GPU * n_tok}")):
+            if acc.get(key):
+                instep[kind] = (1e-3 * (statistics.mean(acc[key]) - gap), len(acc[key]), gap)
+        it0 += a.instep_steps + 6
+    else:
+        it0 = a.warmup + a.steps + 1
+    # ---- idle-device probe: the same kernels on the step's real tensors, back to back between one HIP event pair
     probe = {}
     if a.probe_launches > 0:
         grabbed = {}
-        raw = {"attn_fwd": ops.attn_fwd, "attn_bwd": ops.attn_bwd, "gemm_tn": ops.gemm_tn}
+        raw = {"attn_fwd": ops.attn_fwd_grouped, "attn_bwd": ops.attn_bwd_grouped, "gemm_tn": ops.gemm_tn_grouped}
 
         def grab(name, pred):
             def wrapper(*args_, **kws):
@@ -281,18 +338,17 @@ def main():
                 return raw[name](*args_, **kws)
             return wrapper
 
-        ops.attn_fwd = grab("attn_fwd", lambda qkv, *_: qkv.shape[1] == n_tok)
-        ops.attn_bwd = grab("attn_bwd", lambda qkv, *_: qkv.shape[1] == n_tok)
-        ops.gemm_tn = grab("gemm_tn", lambda dy, x, *_: dy.shape[0] >= B_PER_GPU * TIE_LEN and dy.shape[1] == 768)
+        ops.attn_fwd_grouped = grab("attn_fwd", lambda qkvs, *_: qkvs[0].shape[1] == n_tok)
+        ops.attn_bwd_grouped = grab("attn_bwd", lambda qkvs, *_: qkvs[0].shape[1] == n_tok)
+        ops.gemm_tn_grouped = grab("gemm_tn", lambda dys, xs, *_: dys[0].shape[0] >= B_PER_GPU * TIE_LEN and dys[0].shape[1] == 768)
         args.hip_graph = 0
-        step(a.warmup + a.steps + 1)              # one eager step (every rank: it contains the collective)
+        step(it0)                                 # one eager step (every rank: it contains the collective)
         args.hip_graph = a.hip_graph
-        ops.attn_fwd, ops.attn_bwd, ops.gemm_tn = raw["attn_fwd"], raw["attn_bwd"], raw["gemm_tn"]
+        ops.attn_fwd_grouped, ops.attn_bwd_grouped, ops.gemm_tn_grouped = raw["attn_fwd"], raw["attn_bwd"], raw["gemm_tn"]
         torch.cuda.synchronize()
-        flops = {"attn_fwd": 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
-                 "attn_bwd": 10.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
-                 "gemm_tn": 2.0 * B_PER_GPU * n_tok * 768 * 256}
         for name, (args_, kws) in grabbed.items():
+            if name == "gemm_tn":                 # (the deferred-reduction lists are consumed by the step: fresh ones here)
+                args_ = (args_[0], args_[1], [None] * len(args_[0]), [[] for _ in args_[0]])
             for _ in range(3):
                 raw[name](*args_, **kws)
             torch.cuda.synchronize()
@@ -302,14 +358,26 @@ def main():
                 raw[name](*args_, **kws)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / a.probe_launches
-            probe[name] = (ms, flops[name])
+            probe[name] = e0.elapsed_time(e1) / a.probe_launches
         if world > 1:
             dist.barrier()
 
     if rank == 0:
-        k_ms, fl = probe.get("attn_fwd", (0.0, 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64))
-        achieved = fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        def roof(kind, kernel_name):
+            fl = flops[kind]
+            ins = instep.get(kind)
+            pr = probe.get(kind, 0.0)
+            ms = ins[0] if ins else pr                # in-step when measured, else (fp32 / eager runs) the probe
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            d = {"bound": "mfma", "kernel": kernel_name, "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                 "frac": tf / PEAK_BF16_TFLOPS, "flops_per_launch": fl,
+                 "timed_in": ("replayed steps, mtmp_timestamp in front of and behind every launch of this kernel on its stream, "
+                              "minus the stamp pair's own gap" if ins else "idle-device probe (no in-step measurement in this mode)"),
+                 "avg_launch_ms": ms, "launches_timed": ins[1] if ins else (a.probe_launches if pr > 0 else 0),
+                 "timestamp_gap_us": ins[2] if ins else None,
+                 "probe_avg_launch_ms": pr or None, "probe_frac": (fl / (pr * 1e-3) / 1e12 / PEAK_BF16_TFLOPS) if pr > 0 else None,
+                 "probe_timed_in": "back-to-back launches on the step's tensors between one HIP event pair, idle device"}
+            return d
         # HBM traffic and the in-step rocprofv3 average of the same kernel come from separate rocprofv3 runs of this
         # script (counters / traces cannot be read from inside it); committed under profiles/ with their method
         traffic = traffic_src = rocprof_us = rocprof_src = None
@@ -319,6 +387,9 @@ def main():
                 tj = json.load(fh)
             traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/roofline_traffic.json ({tj.get('round')})"
             rocprof_us, rocprof_src = tj.get("rocprof_avg_us"), tj.get("rocprof_source")
+        rf = roof("attn_fwd", f"attn_fwd_kernel<{'bf16' if a.dtype == 'bf16' else 'float'}> (vslt stream, N={n_tok})")
+        rf.update(traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src, rocprof_avg_us=rocprof_us,
+                  rocprof_source=rocprof_src)
         out = {
             "metric": "tri-modal training samples/s (fwd+bwd+AdamW step, per-GPU batch %d)" % B_PER_GPU,
             "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
@@ -330,25 +401,13 @@ def main():
             "config": {"workload": wl_text + f", dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1"
                                    + (" -- events fed as PackedTieBatch" if a.packed else ""),
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": f"attn_fwd_kernel<{'bf16' if a.dtype == 'bf16' else 'float'}> "
-                                                    f"(vslt stream, N={n_tok})",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "launches_timed": a.probe_launches if k_ms > 0 else 0, "avg_launch_ms": k_ms,
-                         "rocprof_avg_us": rocprof_us, "rocprof_source": rocprof_src, "flops_per_launch": fl,
-                         "timed_in": "back-to-back launches on the step's layer-0 tensors between one HIP event pair, "
-                                     "idle device, after the timed region"},
+            "roofline": rf,
         }
-        names = {"attn_bwd": "attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (vslt stream; algorithmic flops = 2.5 x forward)",
-                 "gemm_tn": "gemm_tn_dma_kernel + reduce_batch_kernel (vslt-stream QKV weight gradient, M x 768 x 256)"}
-        out["roofline_more"] = []
-        for key in ("attn_bwd", "gemm_tn"):
-            if key in probe and probe[key][0] > 0:
-                ms, f = probe[key]
-                tf = f / (ms * 1e-3) / 1e12
-                out["roofline_more"].append({"bound": "mfma", "kernel": names[key], "achieved": tf, "peak": PEAK_BF16_TFLOPS,
-                                             "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS,
-                                             "launches_timed": a.probe_launches, "avg_launch_ms": ms, "flops_per_launch": f})
+        out["roofline_more"] = [
+            roof("attn_bwd", "attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (vslt stream; algorithmic flops = 2.5 x forward)"),
+            roof("gemm_tn", "gemm_tn_dma_kernel (vslt-stream QKV weight gradient, M x 768 x 256; its reduction is deferred into "
+                            "the layer's mtmp_reduce_batch launch)")]
+        out["roofline_more"] = [r for r in out["roofline_more"] if r["avg_launch_ms"] > 0]
         if world == 1 and not a.no_cpu_baseline:
             shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.is_floating_point()}
             out["cpu_baseline"] = cpu_baseline(a.workload, shapes)

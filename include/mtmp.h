@@ -213,9 +213,9 @@ int mtmp_head_bwd(const float* d_out, const float* cls, const float* age, const 
  * dlogit[b] = (sigmoid(o_b) - t_b) / n; logits / target / dlogit float[n]. */
 int mtmp_bce_logits_mean(const float* logits, const float* target, float* loss, float* dlogit, int n, void* stream);
 
-/* Diagnostic (tools/dbg/timeline.py): a one-lane kernel on `stream` stores the 100 MHz wall clock into *slot -- a time
- * stamp that also works inside a captured hipGraph, where HIP events cannot be timed. */
-int mtmp_debug_mark(unsigned long long* slot, void* stream);
+/* Stream-ordered time stamp: a one-lane kernel on `stream` stores the 100 MHz wall clock into *slot.  Also works inside a
+ * captured hipGraph, where HIP events cannot be timed -- bench.py brackets the roofline kernel of the replayed steps with it. */
+int mtmp_timestamp(unsigned long long* slot, void* stream);
 
 /* Swin-T patch-embedding stem: Conv2d(1,96,4,stride 4) -> NHWC -> LayerNorm(96)
  * (builder/models/src/swin_transformer.py:559-567,646) as an implicit GEMM.

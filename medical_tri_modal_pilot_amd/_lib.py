@@ -73,7 +73,7 @@ SIGNATURES = {
     "mtmp_head_fwd": (c_int, [c_void_p] * 6 + [c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "mtmp_head_bwd": (c_int, [c_void_p] * 12 + [c_int, c_float, c_int, c_void_p]),
     "mtmp_bce_logits_mean": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
-    "mtmp_debug_mark": (c_int, [c_void_p, c_void_p]),
+    "mtmp_timestamp": (c_int, [c_void_p, c_void_p]),
     "mtmp_swin_ln_linear": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_void_p]),
     "mtmp_swin_mlp": (c_int, [c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_longlong, c_int, c_float, c_void_p]),
     "mtmp_swin_stem_fwd": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),

@@ -830,13 +830,13 @@ extern "C" int mtmp_publish_scalar(const float* value, unsigned* pair, void* str
     return MTMP_OK;
 }
 
-// Diagnostic: one lane stores the 100 MHz wall clock into *slot.  Launched between the kernels of a step (also inside a
-// captured hipGraph, where HIP events cannot be timed) to get an un-profiled per-stream timeline (tools/dbg/timeline.py).
-__global__ void mark_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+// Stream-ordered time stamp: one lane stores the 100 MHz wall clock into *slot.  Works inside a captured hipGraph, where HIP
+// events cannot be timed: bench.py brackets the roofline kernel of the replayed steps with two of these (its in-step duration).
+__global__ void timestamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
 
-extern "C" int mtmp_debug_mark(unsigned long long* slot, void* stream) {
-    MTMP_CHECK_ARG(slot, "mtmp_debug_mark: null slot");
-    hipLaunchKernelGGL(mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
-    MTMP_CHECK_LAUNCH("mtmp_debug_mark");
+extern "C" int mtmp_timestamp(unsigned long long* slot, void* stream) {
+    MTMP_CHECK_ARG(slot, "mtmp_timestamp: null slot");
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+    MTMP_CHECK_LAUNCH("mtmp_timestamp");
     return MTMP_OK;
 }

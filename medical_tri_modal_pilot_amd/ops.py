@@ -46,24 +46,61 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Diagnostic time stamps (tools/dbg/timeline.py): off unless marks_enable() was called.  mark(name) launches a one-lane kernel
-# on the current stream that stores the wall clock into the slot of `name`; inside a captured step the launches become graph
-# nodes, so every replay refreshes the slots.
+# Stream-ordered time stamps (mtmp_timestamp): off unless marks_enable() was called.  mark(name) launches a one-lane kernel on
+# the current stream that stores the wall clock into the slot of `name`; inside a captured step the launches become graph
+# nodes, so every replay refreshes the slots.  Users: bench.py (in-step duration of the roofline kernels: kernel_marks brackets
+# the grouped attention / weight-gradient launches) and tools/dbg/timeline.py (un-profiled per-stream timeline).
 _marks: Optional[torch.Tensor] = None
 _mark_slots: dict = {}
+_mark_only: Optional[tuple] = None
+_mark_seq: dict = {}
 
 
-def marks_enable(device, n: int = 1024):
-    global _marks
+def marks_enable(device, n: int = 1024, only: Optional[tuple] = None):
+    """only: name prefixes to record (None = every mark)."""
+    global _marks, _mark_only
     _marks = torch.zeros(n, dtype=torch.int64, device=device)
+    _mark_only = only
     _mark_slots.clear()
+    _mark_seq.clear()
+
+
+def marks_disable():
+    global _marks
+    _marks = None
+
+
+def marks_new_step():
+    """restart the per-step launch counters of kernel_marks (call before every eager step / before a capture)"""
+    _mark_seq.clear()
 
 
 def mark(name: str):
-    if _marks is None:
+    if _marks is None or (_mark_only is not None and not name.startswith(_mark_only)):
         return
     i = _mark_slots.setdefault(name, len(_mark_slots))
-    call("mtmp_debug_mark", _p(_marks, 8 * i), _stream())
+    call("mtmp_timestamp", _p(_marks, 8 * i), _stream())
+
+
+class kernel_marks:
+    """with kernel_marks("attn_fwd", N): <launch>  -- stamps "k.attn_fwd.N<N>.<i>.s / .e" around the i-th such launch of a step"""
+
+    def __init__(self, kind: str, n_rows: int):
+        self.name = None
+        if _marks is not None:
+            key = f"k.{kind}.N{n_rows}"
+            i = _mark_seq.get(key, 0)
+            _mark_seq[key] = i + 1
+            self.name = f"{key}.{i}"
+
+    def __enter__(self):
+        if self.name is not None:
+            mark(self.name + ".s")
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            mark(self.name + ".e")
+        return False
 
 
 def marks_read() -> dict:
@@ -377,9 +414,10 @@ def attn_fwd_grouped(qkvs, kv_lens, ress, knorms):
     o = [torch.empty(B, N, D_MODEL, dtype=dt, device=dev) for N in Ns]
     o_res = [None if r is None else torch.empty(B, N, D_MODEL, dtype=dt, device=dev) for N, r in zip(Ns, ress)]
     lse = [torch.empty(B, N_HEAD, N, dtype=torch.float32, device=dev) for N in Ns]
-    call("mtmp_attn_fwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(o),
-         _ptrs(ress), _ptrs(o_res), _ptrs(lse), _ptrs(kv_lens), _ptrs(knorms), _ints(Ns), _ints([q.stride(1) for q in qkvs]),
-         _ints([D_MODEL] * n), B, N_HEAD, D_HEAD ** -0.5, _stream())
+    with kernel_marks("attn_fwd", Ns[0]):
+        call("mtmp_attn_fwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(o),
+             _ptrs(ress), _ptrs(o_res), _ptrs(lse), _ptrs(kv_lens), _ptrs(knorms), _ints(Ns), _ints([q.stride(1) for q in qkvs]),
+             _ints([D_MODEL] * n), B, N_HEAD, D_HEAD ** -0.5, _stream())
     return o, o_res, lse
 
 
@@ -391,10 +429,11 @@ def attn_bwd_grouped(qkvs, os_, d_os, lses, kv_lens):
     Ns = [q.shape[1] for q in qkvs]
     dqkv = [torch.empty_like(q) for q in qkvs]
     delta = [torch.empty(B * N_HEAD * N, dtype=torch.float32, device=qkvs[0].device) for N in Ns]
-    call("mtmp_attn_bwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(os_),
-         _ptrs(d_os), _ptrs(lses), _ptrs(kv_lens), _ptrs(dqkv), _ptrs(dqkv, D_MODEL * es), _ptrs(dqkv, 2 * D_MODEL * es),
-         _ptrs(delta), _ints(Ns), _ints([q.stride(1) for q in qkvs]), _ints([o.stride(1) for o in os_]),
-         _ints([d.stride(1) for d in d_os]), _ints([d.stride(1) for d in dqkv]), B, N_HEAD, D_HEAD ** -0.5, _stream())
+    with kernel_marks("attn_bwd", Ns[0]):
+        call("mtmp_attn_bwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(os_),
+             _ptrs(d_os), _ptrs(lses), _ptrs(kv_lens), _ptrs(dqkv), _ptrs(dqkv, D_MODEL * es), _ptrs(dqkv, 2 * D_MODEL * es),
+             _ptrs(delta), _ints(Ns), _ints([q.stride(1) for q in qkvs]), _ints([o.stride(1) for o in os_]),
+             _ints([d.stride(1) for d in d_os]), _ints([d.stride(1) for d in dqkv]), B, N_HEAD, D_HEAD ** -0.5, _stream())
     return dqkv
 
 
@@ -492,8 +531,9 @@ def gemm_tn_grouped(dys, xs, outs, defers):
             db = torch.empty(N, dtype=torch.float32, device=dev)
         res.append((dw, db))
         wss.append(torch.empty(splits[i] * (N * K + N), dtype=torch.float32, device=dev))
-    call("mtmp_gemm_tn_grouped", _dt(dys[0]), n, _ptrs(dys), _ptrs(xs), _ptrs(wss), _ints(Ms), N, K,
-         _ints([d.stride(0) for d in dys]), _ints([x.stride(0) for x in xs]), splits, _stream())
+    with kernel_marks(f"gemm_tn{N}x{K}", Ms[0]):
+        call("mtmp_gemm_tn_grouped", _dt(dys[0]), n, _ptrs(dys), _ptrs(xs), _ptrs(wss), _ints(Ms), N, K,
+             _ints([d.stride(0) for d in dys]), _ints([x.stride(0) for x in xs]), splits, _stream())
     for i in range(n):
         defers[i].append((wss[i], int(splits[i]), N * K + N, res[i][0], N * K, res[i][1]))
     return res

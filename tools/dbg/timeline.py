@@ -1,4 +1,4 @@
-"""Un-profiled timeline of one replayed training step: wall-clock stamps (ops.mark -> mtmp_debug_mark, one-lane kernels that
+"""Un-profiled timeline of one replayed training step: wall-clock stamps (ops.mark -> mtmp_timestamp, one-lane kernels that
 are captured into the hipGraph like any other launch) at the start/end of the frozen image encoder, of every fusion
 layer of every modality stream (forward and backward), around the graph replay and the AdamW kernel.
 
