@@ -173,9 +173,11 @@ class TRI_MBT_VSLTCLS(nn.Module):
         images, so its stream is forked HERE -- not behind zero_grad, the dropout-seed update and the text projection, ~75 us
         of small launches in front of the first encoder kernel -- and the StochasticDepth draws (four small launches) run on
         the caller's stream beside the patch embedding instead of in front of it.  forward() then skips its own fork."""
-        side = (img.is_cuda and getattr(self, "side_input_chains", True) and self.training
-                and getattr(self.fusion_transformer, "_side_streams", None) is not None)
-        if not side or self.args.img_model_type != "swin":
+        self._preforked = False
+        # the same predicate as forward(): the fork only exists when the input chains run on the encoder's side streams
+        side = (None if (not img.is_cuda or not getattr(self, "side_input_chains", True))
+                else self.fusion_transformer._side_streams(img.device))
+        if side is None or self.args.img_model_type != "swin":
             return
         cur = torch.cuda.current_stream()
         if getattr(self, "_swin_stream", None) is None or self._swin_stream.device != img.device:
@@ -189,6 +191,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
                 txt_time, flow_type, reports_tokens, reports_lengths):
         dt = self.compute_dtype
         ops.mark("fwd.s")
+        preforked, self._preforked = getattr(self, "_preforked", False), False     # (cleared whatever branch runs below)
         if isinstance(x, PackedTie):
             if self.args.vslt_type == "carryforward":
                 raise ValueError("a packed TIE batch needs --vslt-type TIE or QIE")
@@ -229,9 +232,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # stream's first layer) beside the encoder's small-M stages, which cannot fill the chip on their own.
         if side is not None:
             # stages 1-2 on a third stream, stages 3-4 as two half batches on the two side streams (result valid on side[0])
-            if getattr(self, "_preforked", False):
-                self._preforked = False                   # prefork() joined the encoder's stream at the head of the step
-            else:
+            if not preforked:                             # (prefork() joined the encoder's stream at the head of the step)
                 if getattr(self, "_swin_stream", None) is None or self._swin_stream.device != img.device:
                     self._swin_stream = torch.cuda.Stream(device=img.device)
                 self._swin_stream.wait_stream(cur)

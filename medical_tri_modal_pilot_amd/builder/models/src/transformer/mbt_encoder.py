@@ -265,6 +265,11 @@ class BimodalTransformerEncoder_MBT(nn.Module):
         if not missing.is_cuda and missing.numel() and (int(missing.max()) > 1 or int(missing.min()) < 0):
             raise IndexError("BimodalTransformerEncoder_MBT: missing must be 0 (both streams) or 1 (stream 0 only)")
         missing = missing.to(dev).long()
+        if missing.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # device-resident flags outside a capture: an asynchronous device-side assert instead of the host check (the
+            # reference's gather all_bottleneck_stack[missing, idx_order] raises; the exchange kernel alone would clamp)
+            torch._assert_async(((missing >= 0) & (missing <= 1)).all(),
+                                "BimodalTransformerEncoder_MBT: missing must be 0 (both streams) or 1 (stream 0 only)")
         pattern = 1 + 2 * missing
         fl = list(self.layer_stacks)
         all_fused = iter(type(fl[0][0]).fused_weights_of([layer for layers in fl for layer in layers], dt))

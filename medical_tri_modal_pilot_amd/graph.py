@@ -82,18 +82,30 @@ class GraphedTrainStep:
             self.expected_seq += 1
 
     def wait_loss(self, timeout_s: float = 60.0) -> float:
-        """The loss published by the step function of the last run() (host spin on the pinned pair; full device sync as a
-        fallback after timeout_s)."""
+        """The loss published by the step function of the last run() (host poll of the pinned pair; full device sync as a
+        fallback after timeout_s).  NOTE for callers: this returns as soon as the FORWARD pass of the step has published
+        its loss -- the backward, the gradient all-reduce and the optimizer step may still be running.  Work enqueued on
+        the device afterwards is stream-ordered behind them as always; host-side timing or readers that are not stream
+        ordered must synchronise themselves.  The pair is (value, sequence): the sequence word is polled first and the
+        value is read again after it matched (the 8-byte copy is not assumed to land atomically); the poll yields the GIL
+        between probes (loader / pin threads keep running)."""
         if not self.published:
             raise RuntimeError("wait_loss: the step function of the last run() did not call publish_loss")
         want, pair = self.expected_seq & 0xFFFFFFFF, self._loss_np
         t0 = time.perf_counter()
-        while (int(pair[1]) & 0xFFFFFFFF) != want:
-            if time.perf_counter() - t0 > timeout_s:
-                torch.cuda.synchronize(self.device)
-                if (int(pair[1]) & 0xFFFFFFFF) != want:
-                    raise RuntimeError(f"wait_loss: sequence number {int(pair[1])} after a device sync, expected {want}")
-        return float(pair[:1].view("float32")[0])
+        spins = 0
+        while True:
+            while (int(pair[1]) & 0xFFFFFFFF) != want:
+                spins += 1
+                if spins & 63 == 0:
+                    time.sleep(0)                      # yield the GIL
+                    if time.perf_counter() - t0 > timeout_s:
+                        torch.cuda.synchronize(self.device)
+                        if (int(pair[1]) & 0xFFFFFFFF) != want:
+                            raise RuntimeError(f"wait_loss: sequence number {int(pair[1])} after a device sync, expected {want}")
+            v = float(pair[:1].view("float32")[0])
+            if (int(pair[1]) & 0xFFFFFFFF) == want and float(pair[:1].view("float32")[0]) == v:
+                return v
 
     @staticmethod
     def signature(inputs: Dict[str, torch.Tensor]) -> tuple:

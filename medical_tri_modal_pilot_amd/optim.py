@@ -213,7 +213,7 @@ class FusedAdamW(torch.optim.Optimizer):
         where = {q: j for j, q in enumerate(posn)}
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
-        steps = set()
+        steps, seen = set(), set()
         for idx, st in state_dict["state"].items():
             j = where.get(int(idx))
             if j is None:
@@ -222,6 +222,15 @@ class FusedAdamW(torch.optim.Optimizer):
             self.exp_avg[lo:hi].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
+            seen.add(j)
+        if steps and max(steps) > 0 and len(seen) < len(self.flat.params):
+            # torch.optim.AdamW creates a parameter's state at its first gradient: a trained parameter WITHOUT an entry would
+            # resume at step 0 there, but this optimizer keeps ONE step count for the flat buffer (its bias correction would be
+            # the checkpoint's global step, with zero moments) -- refuse instead of resuming differently from the reference
+            missing_names = [self.flat.names[j] if hasattr(self.flat, "names") else str(j)
+                             for j in range(len(self.flat.params)) if j not in seen]
+            raise ValueError(f"optimizer state at step {max(steps)} has no entry for {len(missing_names)} trained parameter(s) "
+                             f"(e.g. {missing_names[:3]}): they would resume with another bias correction than in the reference")
         if len(steps) > 1:
             raise ValueError(f"parameters were stepped a different number of times ({sorted(steps)}): the fused AdamW "
                              "keeps one step count for its flat buffer")

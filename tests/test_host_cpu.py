@@ -383,6 +383,12 @@ def test_fused_adamw_state_dict_speaks_the_reference_layout():
     for j in range(len(opt.flat.params)):                    # (alignment padding between slices belongs to nobody)
         lo, hi = opt.flat.slice_of(j)
         assert torch.equal(opt2.exp_avg[lo:hi], opt.exp_avg[lo:hi]) and torch.equal(opt2.exp_avg_sq[lo:hi], opt.exp_avg_sq[lo:hi])
+    # a stepped checkpoint WITHOUT the entry of a trained parameter (torch creates state at the first gradient): that parameter
+    # would resume at step 0 in the reference, here at the global step -- refused
+    partial = ref.state_dict()
+    del partial["state"][4]
+    with pytest.raises(ValueError, match="no entry for 1 trained parameter"):
+        FusedAdamW(hot, lr=1e-3, reference_params=list(net.parameters())).load_state_dict(partial)
 
 
 def test_grad_reducer_two_ranks_gloo(tmp_path):

@@ -14,7 +14,7 @@ if [ "$2" != "quick" ]; then
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/${T}_prof -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 8 --probe-launches 0 > $O/${T}_prof_bench.json 2> $O/${T}_prof.err
+rocprofv3 --kernel-trace --stats -d $O/${T}_prof -o x --output-format csv -- python3 $R/bench.py --no-cpu-baseline --steps 20 --warmup 8 --probe-launches 0 --instep-steps 0 > $O/${T}_prof_bench.json 2> $O/${T}_prof.err
 cd $R
 tail -1 $O/${T}_prof_bench.json | cut -c1-200
 python tools/trace_summary.py $O/${T}_prof/x_kernel_trace.csv --json $O/${T}_trace_summary.json > /dev/null 2>&1
