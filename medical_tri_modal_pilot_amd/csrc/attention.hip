@@ -466,26 +466,78 @@ template <typename T> __global__ __launch_bounds__(256) void key_norms_kernel(co
 // ---- helpers of the backward kernels ----
 
 // 32x32 tile: C + A(rows through swz23 from an LDS row-major tile) * B(register fragments over dh = 64)
-template <typename T>
-MTMP_DEV f32x16 tile_qk_c(const f32x16& c, const T* lds_rows, int r, int half, const Frag<T> (&bf)[4]) {
-    const T* arow = lds_rows + swz23(r) * LDT + 8 * half;
-    f32x16 acc = mma_c<T>(frag_load<T>(arow), bf[0], c);     // D != C: no copy of the shared C registers
-#pragma unroll
-    for (int cc = 1; cc < 4; ++cc) mma<T>(acc, frag_load<T>(arow + 16 * cc), bf[cc]);
-    return acc;
-}
+// (the row constants -LSE / -delta are the C operand: D != C, no copy of the shared C registers)
 
-// One thread's share (2 x 16 bytes) of a stream of 64-row x 64-column tiles over rows [0, limit) of a
-// [limit][ld] matrix.  Full tiles are fetched through two running pointers (no address arithmetic in the
-// loop); the ragged last tile clamps its rows to limit - 1 (a finite stand-in row; the kernels make such
-// rows inert through their row constants or masks, never by reading past `limit`).
+// A staged 64-row x 64-column tile that is read in BOTH roles: row fragments (8 consecutive columns of one row: the A
+// operand of the score products) and transposed fragments (8 consecutive ROWS of one column: dQ's K, dK / dV's Q and dO).
+//   bf16: ONE unpadded 8 KiB image.  Byte offset of 16-byte chunk ch of row `row` (cdna_hip_programming.md T10, image (a),
+//         for 128-byte rows): 1024 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)) -- 8-row x
+//         32-column subtiles of 512 B whose 16-byte chunks are XOR-ed with bits 2-3 of the row.  ds_read_b128 row reads (rows
+//         through swz23 or not) and ds_read_b64_tr_b16 reads are both conflict-free on it (bank simulation,
+//         tools/dbg/banksim.py; the two padded images of round 1-2 were each conflict-free for ONE role only), so a tile is
+//         written once instead of twice and takes 8 KiB instead of 21.5.  A thread stages chunks c and 4 + c of ONE row
+//         (row = tid >> 2, c = tid & 3): the eight lanes of a ds_write_b128 service group then cover 2 rows x 4 chunks of one
+//         subtile -- no write conflicts (8 chunks of one row would put chunks c and c + 4 on the same banks).
+//   fp32 (parity build): no 32-bit transposing read exists: a row image [64][LDT] plus a transposed image written
+//         [col][row] with 8-byte stores, as before.
+template <typename T> struct DualTile;
+template <> struct DualTile<bf16> {
+    static constexpr int BYTES = 8192;
+    static MTMP_DEV void map(int tid, int& ra, int& rb, int& ca, int& cb) { ra = rb = tid >> 2; ca = 8 * (tid & 3); cb = 32 + 8 * (tid & 3); }
+    static MTMP_DEV int off(int row, int ch) {
+        return 1024 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
+    }
+    static MTMP_DEV void put(char* img, const TileR<bf16>& t, int tid) {
+        const int row = tid >> 2, c = tid & 3;
+        *reinterpret_cast<bf16x8*>(img + off(row, c)) = t.a.v;
+        *reinterpret_cast<bf16x8*>(img + off(row, 4 + c)) = t.b.v;
+    }
+    // k-step c of the row operand: row `row`, elements 16 c + 8 half .. + 7
+    static MTMP_DEV Frag<bf16> row_frag(const char* img, int row, int c, int half) {
+        Frag<bf16> f;
+        f.v = *reinterpret_cast<const bf16x8*>(img + off(row, 2 * c + half));
+        return f;
+    }
+    // transposed operand: element j = tile[row0 + 8 * (lane >> 5) + j][col0 + (lane & 31)]
+    static MTMP_DEV Frag<bf16> tr_frag(const char* img, int row0, int col0, int lane) {
+        const int G = lane >> 4, i = lane & 15;
+        const int row = row0 + 8 * (G >> 1) + (i >> 2), col = col0 + 16 * (G & 1) + 4 * (i & 3);
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off(row, col >> 3) + 2 * (col & 7)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + off(row + 4, col >> 3) + 2 * (col & 7)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        Frag<bf16> f;
+        f.v = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+        return f;
+    }
+};
+template <> struct DualTile<float> {
+    static constexpr int BYTES = (KT * LDT + DH * LDT) * 4;
+    static MTMP_DEV void map(int tid, int& ra, int& rb, int& ca, int& cb) { ra = (tid & 31) * 2; rb = ra + 1; ca = cb = (tid >> 5) * 8; }
+    static MTMP_DEV void put(char* img, const TileR<float>& t, int tid) {
+        float* rows = reinterpret_cast<float*>(img);
+        put_rows_r<float>(rows, t, tid);
+        put_tr_r(rows + KT * LDT, t, tid);
+    }
+    static MTMP_DEV Frag<float> row_frag(const char* img, int row, int c, int half) {
+        return frag_load<float>(reinterpret_cast<const float*>(img) + row * LDT + 16 * c + 8 * half);
+    }
+    static MTMP_DEV Frag<float> tr_frag(const char* img, int row0, int col0, int lane) {
+        return frag_tr(reinterpret_cast<const float*>(img) + KT * LDT, row0, col0, lane);
+    }
+};
+
+// One thread's share (two 8-element pieces) of a stream of 64-row x 64-column tiles over rows [0, limit) of a [limit][ld]
+// matrix, in DualTile<T>'s thread mapping.  Full tiles are fetched through two running pointers (no address arithmetic in the
+// loop); the ragged last tile clamps its rows to limit - 1 (a finite stand-in row; the kernels make such rows inert through
+// their row constants or masks, never by reading past `limit`).
 template <typename T> struct TileStream {
     const T* base; const T* pa; const T* pb;
-    size_t step; int ld, limit, ra, rb, col, nfull;
+    size_t step; int ld, limit, ra, rb, ca, cb, nfull;
     MTMP_DEV void init(const T* src, int ld_, int limit_, int tid) {
-        tile_map<T>(tid, ra, rb, col);
+        DualTile<T>::map(tid, ra, rb, ca, cb);
         base = src; ld = ld_; limit = limit_; nfull = limit_ / KT; step = (size_t)KT * ld_;
-        pa = src + (size_t)ra * ld_ + col; pb = src + (size_t)rb * ld_ + col;
+        pa = src + (size_t)ra * ld_ + ca; pb = src + (size_t)rb * ld_ + cb;
     }
     MTMP_DEV TileR<T> fetch(int t) {                 // t must run 0, 1, 2, ... (running pointers)
         TileR<T> x;
@@ -493,10 +545,17 @@ template <typename T> struct TileStream {
             x.a = frag_load<T>(pa); x.b = frag_load<T>(pb);
             pa += step; pb += step;
         } else {
-            x.a = frag_load<T>(base + (size_t)min(t * KT + ra, limit - 1) * ld + col);
-            x.b = frag_load<T>(base + (size_t)min(t * KT + rb, limit - 1) * ld + col);
+            x.a = frag_load<T>(base + (size_t)min(t * KT + ra, limit - 1) * ld + ca);
+            x.b = frag_load<T>(base + (size_t)min(t * KT + rb, limit - 1) * ld + cb);
         }
         return x;
+    }
+    // rows >= limit of tile t -> 0 (ragged key tiles of the dQ kernel)
+    MTMP_DEV TileR<T> zero_tail(const TileR<T>& x, int t) const {
+        TileR<T> y;
+        y.a = frag_keep(x.a, t * KT + ra < limit);
+        y.b = frag_keep(x.b, t * KT + rb < limit);
+        return y;
     }
 };
 // =============================== backward ===================================
@@ -509,30 +568,23 @@ template <typename T> struct AttnBwdArgs {
     const T* o; int ld_o;
 };
 
-// rows >= limit - row0 of a fetched tile -> 0 (ragged key tiles of the dQ kernel)
-template <typename T> MTMP_DEV TileR<T> tile_zero_rows(const TileR<T>& x, int row0, int limit, int tid) {
-    int ra, rb, col;
-    tile_map<T>(tid, ra, rb, col);
-    TileR<T> y;
-    y.a = frag_keep(x.a, row0 + ra < limit);
-    y.b = frag_keep(x.b, row0 + rb < limit);
-    return y;
-}
-
 // Both backward kernels fold the row constants into the matrix pipe (cdna_hip_programming.md, 'Attention
 // backward': row constants as the initial accumulator): with the softmax scale folded into one operand
 // (K in dK/dV, Q in dQ) and  -LSE  /  -delta  loaded as the C operand of the two score products,
 //     S' = (c2 K) Q^T - LSE     -> p  = exp2(S')          (no fma, no subtraction)
 //     dP' = V dO^T - delta      -> dS = p * dP'           (one multiply)
 // which leaves exp2 + mul + the bf16 conversions as the only per-score vector work.
+// Round 3: K / V (dQ) and Q / dO (dK/dV) tiles live in double-buffered DualTile images -- ONE barrier per tile, the next
+// tile's global loads two tiles ahead in registers, each tile written to LDS once -- and the two 32-row units of a tile are
+// software-pipelined inside the wave in both kernels (round-2 counters: vector and matrix pipe busy together only 9 % / 15 %
+// of the time, 40 % of the wave-cycles in issue stalls).
 
 // dQ: workgroup = 128 query rows, loops over key tiles (S^T and dP^T with the query on the lane).
+template <typename T> constexpr int dq_stage_bytes() { return 2 * DualTile<T>::BYTES; }          // K | V
 template <typename T>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(Grouped<AttnBwdArgs<T>> grp) {
+    using DT = DualTile<T>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sK = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]
-    T* sV = sK + KT * LDT;                    // [KT][LDT]
-    T* sKt = sV + KT * LDT;                   // K image for the transposed role (frag_tr)
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int seg = grp_find(grp, wg);
     const AttnBwdArgs<T>& p = grp.seg[seg];
@@ -581,50 +633,88 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     TileStream<T> ks, vs;
     ks.init(Kb, p.ld_qkv, kvl, tid);
     vs.init(Vb, p.ld_qkv, kvl, tid);
-    TileR<T> kreg = ks.fetch(0), vreg = vs.fetch(0);
+    TileR<T> kreg, vreg;
+    auto fetch = [&](int t) { kreg = ks.fetch(t); vreg = vs.fetch(t); };
+    auto put = [&](int t) {                    // dQ += dS K: keys past kv_len are staged as zero rows (they add exactly 0)
+        char* st_ = smem_raw + (t & 1) * dq_stage_bytes<T>();
+        DT::put(st_, t >= nfull ? ks.zero_tail(kreg, t) : kreg, tid);
+        DT::put(st_ + DT::BYTES, vreg, tid);
+    };
+    if (ntiles > 0) { fetch(0); put(0); }
+    if (ntiles > 1) fetch(1);
+    struct Unit { f32x16 st, dp; };
     auto body = [&](int it, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = it * KT;
-        __syncthreads();
-        if (TAIL) kreg = tile_zero_rows<T>(kreg, k0, kvl, tid);   // dQ += dS K: masked keys add exactly 0
-        put_rows_r<T>(sK, kreg, tid);
-        put_tr_r(sKt, kreg, tid);
-        put_rows_r<T>(sV, vreg, tid);
-        __syncthreads();
-        if (it + 1 < ntiles) { kreg = ks.fetch(it + 1); vreg = vs.fetch(it + 1); }
+        __syncthreads();                       // tile `it` visible; the other stage is free for tile it + 1
+        if (it + 1 < ntiles) put(it + 1);
+        if (it + 2 < ntiles) fetch(it + 2);
+        const char* sK = smem_raw + (it & 1) * dq_stage_bytes<T>();
+        const char* sV = sK + DT::BYTES;
+        auto scores = [&](int kb, Unit& u) {
+            Frag<T> ka[4], va[4];
+            const int row = 32 * kb + swz23(r);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            // transposed K fragments of the dQ product requested before the score math (see the dK/dV kernel)
+            for (int c = 0; c < 4; ++c) { ka[c] = DT::row_frag(sK, row, c, half); va[c] = DT::row_frag(sV, row, c, half); }
+            u.st = mma_c<T>(ka[0], qf[0], cL);
+            u.dp = mma_c<T>(va[0], dof[0], cD);
+#pragma unroll
+            for (int c = 1; c < 4; ++c) { mma<T>(u.st, ka[c], qf[c]); mma<T>(u.dp, va[c], dof[c]); }
+        };
+        auto soft = [&](int kb, Unit& u, Frag<T> (&dsf)[2]) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float ds = fast_exp2(u.st[t]) * u.dp[t];
+                if (TAIL) ds = (k0 + 32 * kb + acc_row_swz(t, half) < kvl) ? ds : 0.f;
+                u.st[t] = ds;
+            }
+            dsf[0] = frag_from_acc<T>(u.st, 0);
+            dsf[1] = frag_from_acc<T>(u.st, 1);
+        };
+        auto grad = [&](int kb, const Frag<T> (&dsf)[2]) {       // dQ^T += K^T dS^T (transposed K fragments of the same image)
             Frag<T> trf[2][2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                trf[s][0] = frag_tr(sKt, 32 * kb + 16 * s, 0, lane);
-                trf[s][1] = frag_tr(sKt, 32 * kb + 16 * s, 32, lane);
-            }
-            Frag<T> ka[4], va[4];              // ... and so are the row fragments of the two score products
-            {
-                const int ro = (32 * kb + swz23(r)) * LDT + 8 * half;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { ka[c] = frag_load<T>(sK + ro + 16 * c); va[c] = frag_load<T>(sV + ro + 16 * c); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 st = mma_c<T>(ka[0], qf[0], cL);
-            f32x16 dp = mma_c<T>(va[0], dof[0], cD);
-#pragma unroll
-            for (int c = 1; c < 4; ++c) { mma<T>(st, ka[c], qf[c]); mma<T>(dp, va[c], dof[c]); }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float ds = fast_exp2(st[t]) * dp[t];
-                if (TAIL) ds = (k0 + 32 * kb + acc_row_swz(t, half) < kvl) ? ds : 0.f;
-                st[t] = ds;
+                trf[s][0] = DT::tr_frag(sK, 32 * kb + 16 * s, 0, lane);
+                trf[s][1] = DT::tr_frag(sK, 32 * kb + 16 * s, 32, lane);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const Frag<T> dsf = frag_from_acc<T>(st, s);
-                mma<T>(dq0, trf[s][0], dsf);
-                mma<T>(dq1, trf[s][1], dsf);
+                mma<T>(dq0, trf[s][0], dsf[s]);
+                mma<T>(dq1, trf[s][1], dsf[s]);
+            }
+        };
+        // the two key blocks of the tile, pipelined: S,dP(1) beside exp/mul/cvt(0); dQ(0) beside exp/mul/cvt(1)
+        Unit u0, u1;
+        Frag<T> d0[2], d1[2];
+        scores(0, u0);
+        __builtin_amdgcn_sched_barrier(0);
+        scores(1, u1);
+        soft(0, u0, d0);
+        if (sizeof(T) == 2) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        grad(0, d0);
+        soft(1, u1, d1);
+        if (sizeof(T) == 2) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);         // under the LDS latency
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        grad(1, d1);
     };
     for (int it = 0; it < min(nfull, ntiles); ++it) body(it, std::false_type{});
     if (ntiles > nfull) body(nfull, std::true_type{});
@@ -647,15 +737,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
 // No masks in the loop: a lane whose key is past kv_len computes garbage that stays in its own output
 // rows (the contraction runs over queries), and those rows are written as zeros; query rows past N carry
 // -LSE = -inf, so their p and dS are exactly 0.
+template <typename T> constexpr int dkdv_stage_bytes() { return 2 * DualTile<T>::BYTES + 2 * KT * (int)sizeof(float); }   // Q | dO | -lse | -delta
 template <typename T>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_kernel(Grouped<AttnBwdArgs<T>> grp) {
+    using DT = DualTile<T>;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sQ = reinterpret_cast<T*>(smem_raw);   // [KT][LDT]  q x dh
-    T* sdO = sQ + KT * LDT;                   // [KT][LDT]
-    T* sQt = sdO + KT * LDT;                  // Q image for the transposed role (frag_tr)
-    T* sdOt = sQt + tr_elems<T>();             // dO image for the transposed role
-    float* sL = reinterpret_cast<float*>(sdOt + tr_elems<T>());   // [KT] -lse (log2 units), -inf past N
-    float* sD = sL + KT;                                     // [KT] -delta
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int seg = grp_find(grp, wg);
     const AttnBwdArgs<T>& p = grp.seg[seg];
@@ -688,38 +774,44 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
         TileStream<T> qs, os;
         qs.init(Qb, p.ld_qkv, p.N, tid);
         os.init(dOb, p.ld_do, p.N, tid);
-        TileR<T> qreg = qs.fetch(0), oreg = os.fetch(0);
+        TileR<T> qreg, oreg;
         // lse / delta of the tile's 64 query rows ride along in wave 0.  The loads are unconditional (clamped
         // address) and their values are not touched before the put: a guarded load, or any arithmetic on the
         // loaded value here, makes the compiler wait for it (vmcnt(0): ALL the tile loads just issued) on the
-        // spot, wave 0 then reaches the next barrier a full memory latency late and the other three wait --
-        // 100 of the kernel's 200 us went there.
+        // spot, wave 0 then reaches the next barrier a full memory latency late and the other three wait.
         const int lrow = tid & (KT - 1);
-        float lreg = Lb[min(lrow, p.N - 1)], dreg = Db[min(lrow, p.N - 1)];
-        for (int it = 0; it < nq; ++it) {
-            const int q0 = it * KT;
-            __syncthreads();
-            put_rows_r<T>(sQ, qreg, tid);
-            put_tr_r(sQt, qreg, tid);
-            put_rows_r<T>(sdO, oreg, tid);
-            put_tr_r(sdOt, oreg, tid);
+        float lreg, dreg;
+        auto fetch = [&](int t) {
+            qreg = qs.fetch(t);
+            oreg = os.fetch(t);
+            const int qn = min(t * KT + lrow, p.N - 1);
+            lreg = Lb[qn];
+            dreg = Db[qn];
+        };
+        auto put = [&](int t) {
+            char* st_ = smem_raw + (t & 1) * dkdv_stage_bytes<T>();
+            DT::put(st_, qreg, tid);
+            DT::put(st_ + DT::BYTES, oreg, tid);
             if (tid < KT) {                    // C operands of the score products: -lse (-inf past N), -delta
-                sL[tid] = (q0 + tid < p.N) ? -lreg : -INFINITY;
-                sD[tid] = (q0 + tid < p.N) ? -dreg : 0.f;
+                float* sL = reinterpret_cast<float*>(st_ + 2 * DT::BYTES);
+                sL[tid] = (t * KT + tid < p.N) ? -lreg : -INFINITY;
+                sL[KT + tid] = (t * KT + tid < p.N) ? -dreg : 0.f;
             }
-            __syncthreads();
-            if (it + 1 < nq) {
-                qreg = qs.fetch(it + 1);
-                oreg = os.fetch(it + 1);
-                const int qn = min(q0 + KT + lrow, p.N - 1);
-                lreg = Lb[qn];
-                dreg = Db[qn];
-            }
+        };
+        fetch(0);
+        put(0);
+        if (nq > 1) fetch(1);
+        for (int it = 0; it < nq; ++it) {
+            __syncthreads();                   // tile `it` visible; the other stage is free for tile it + 1
+            if (it + 1 < nq) put(it + 1);
+            if (it + 2 < nq) fetch(it + 2);
             if (kw0 < kvl) {                   // wave-uniform
+                const char* sQ = smem_raw + (it & 1) * dkdv_stage_bytes<T>();
+                const char* sdO = sQ + DT::BYTES;
+                const float* sL = reinterpret_cast<const float*>(sQ + 2 * DT::BYTES);
+                const float* sD = sL + KT;
                 // A 64-query tile = two 32-query blocks, software-pipelined INSIDE the wave so that the matrix pipe
-                // and the vector ALU run side by side (one wave's chain  reads -> S,dP -> exp/mul -> dV,dK  is serial,
-                // and two waves per SIMD do not cover it: with the blocks done one after the other every unit sat at
-                // 40-50 %):
+                // and the vector ALU run side by side:
                 //   phase 0:  S,dP(block 0)                          8 MFMA   (+ LDS reads of block 1's operands)
                 //   phase 1:  S,dP(block 1)  ||  exp/mul/cvt(block 0)  8 MFMA beside 48 VALU
                 //   phase 2:  dV,dK(block 0) ||  exp/mul/cvt(block 1)  8 MFMA beside 48 VALU
@@ -738,18 +830,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
                         }
                 };
                 auto load_rows = [&](int qb, Frag<T> (&qa)[4], Frag<T> (&oa)[4]) {
-                    const int ro = (32 * qb + swz23(r)) * LDT + 8 * half;
+                    const int row = 32 * qb + swz23(r);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { qa[c] = frag_load<T>(sQ + ro + 16 * c); oa[c] = frag_load<T>(sdO + ro + 16 * c); }
+                    for (int c = 0; c < 4; ++c) { qa[c] = DT::row_frag(sQ, row, c, half); oa[c] = DT::row_frag(sdO, row, c, half); }
                 };
                 auto load_tr = [&](int qb, Frag<T> (&trf)[2][4]) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const int q16 = 32 * qb + 16 * s;
-                        trf[s][0] = frag_tr(sdOt, q16, 0, lane);
-                        trf[s][1] = frag_tr(sdOt, q16, 32, lane);
-                        trf[s][2] = frag_tr(sQt, q16, 0, lane);
-                        trf[s][3] = frag_tr(sQt, q16, 32, lane);
+                        trf[s][0] = DT::tr_frag(sdO, q16, 0, lane);
+                        trf[s][1] = DT::tr_frag(sdO, q16, 32, lane);
+                        trf[s][2] = DT::tr_frag(sQ, q16, 0, lane);
+                        trf[s][3] = DT::tr_frag(sQ, q16, 32, lane);
                     }
                 };
                 auto scores = [&](f32x16& st, f32x16& ds, const f32x16& cL, const f32x16& cD, const Frag<T> (&qa)[4],
@@ -849,8 +941,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
 }
 
 template <typename T> size_t fwd_smem() { return (size_t)2 * fwd_stage_elems<T>() * sizeof(T); }   // >= 4 x 64 x LDT staging rows
-template <typename T> size_t dq_smem() { return (size_t)(2 * KT * LDT + tr_elems<T>()) * sizeof(T); }
-template <typename T> size_t dkdv_smem() { return (size_t)(2 * KT * LDT + 2 * tr_elems<T>()) * sizeof(T) + 2 * KT * sizeof(float); }
+template <typename T> size_t dq_smem() { return (size_t)2 * dq_stage_bytes<T>(); }
+template <typename T> size_t dkdv_smem() { return (size_t)2 * dkdv_stage_bytes<T>(); }
 
 template <typename K> int set_smem(K kern, size_t bytes) {
     if (bytes > 48 * 1024) {
