@@ -1204,23 +1204,77 @@ def test_packed_batch_training_steps_vs_golden(ops, graph):
     assert abs(tl - float(Gd["test_loss"])) < 1e-4
 
 
+BF16_STEP_GATES = dict(loss=1.5e-3, grad_norm=0.12, grad_digest=0.12, test_loss=1.5e-3)     # ~2 x the worst measured on MI355X (see the test)
+
+
 def test_full_training_step_bf16_tolerance(ops):
-    """bf16 MFMA build against the fp32 golden: reported tolerance (not the 1e-4 gate)."""
+    """bf16 MFMA build against the fp32 golden of the reference: the benchmarked build runs its own kernels for the heaviest
+    GEMMs (LDS-DMA row-panel / weight-gradient kernels), so its step is gated per tensor at about twice the error measured on
+    MI355X (round 3: loss |diff| 6.2e-4, test loss 7.1e-4; worst tensor -- a query-projection BIAS gradient, a sum with heavy
+    cancellation -- 6.0e-2 in L2 norm and in its sampled entries; the median tensor is far below), not at a blanket figure."""
     Gd, model, grads, params1, loss1, loss2, tl, lg, _ = _run_steps("bf16", 0, "model_step", True)
-    REPORT["step[bf16].loss_abs_err"] = {"rel_err": abs(loss1 - float(Gd["loss"])), "tol": 3e-2}
-    assert abs(loss1 - float(Gd["loss"])) < 3e-2
+    gt = BF16_STEP_GATES
+    REPORT["step[bf16].loss_abs_err"] = {"rel_err": abs(loss1 - float(Gd["loss"])), "tol": gt["loss"]}
     names = [str(s) for s in Gd["grad_names"]]
-    worst = 0.0
+    worst_n = worst_d = 0.0
+    worst_name = ""
     med = float(np.median(Gd["grad_digest"][:, 0]))
     for n_, gd in zip(names, Gd["grad_digest"]):
-        got, ref = float(_digest(grads[n_])[0]), float(gd[0])          # gradient L2 norms
+        dg = _digest(grads[n_])
+        got, ref = float(dg[0]), float(gd[0])          # gradient L2 norms
         if ref < 1e-4 * med:                                           # mathematically-zero gradients: noise
             assert got < 1e-2 * med, n_
             continue
-        worst = max(worst, abs(got - ref) / abs(ref))
-    REPORT["step[bf16].worst_grad_norm_rel_err"] = {"rel_err": worst, "tol": 0.15}
-    assert worst < 0.15
-    assert abs(tl - float(Gd["test_loss"])) < 5e-2
+        en = abs(got - ref) / abs(ref)
+        ed = _rel(dg, torch.from_numpy(gd))                            # norm + 8 sampled entries, relative to the largest
+        if ed > worst_d:
+            worst_d, worst_name = ed, n_
+        worst_n = max(worst_n, en)
+    REPORT["step[bf16].worst_grad_norm_rel_err"] = {"rel_err": worst_n, "tol": gt["grad_norm"]}
+    REPORT["step[bf16].worst_grad_digest_rel_err"] = {"rel_err": worst_d, "tol": gt["grad_digest"], "tensor": worst_name}
+    REPORT["step[bf16].test_loss_abs_err"] = {"rel_err": abs(tl - float(Gd["test_loss"])), "tol": gt["test_loss"]}
+    assert abs(loss1 - float(Gd["loss"])) < gt["loss"]
+    assert worst_n < gt["grad_norm"], worst_n
+    assert worst_d < gt["grad_digest"], (worst_d, worst_name)
+    assert abs(tl - float(Gd["test_loss"])) < gt["test_loss"]
+
+
+@pytest.mark.parametrize("M", [64320, 4990, 300])
+def test_bf16_row_panel_kernels_vs_fp32_kernels_on_identical_inputs(ops, M):
+    """the bf16 build's heaviest GEMMs are their own kernels (LDS-DMA row panels), not the fp32 kernels with
+    another MFMA.  Same bf16-representable inputs through both builds: ln_gemm (QKV and FFN1 + ReLU), the sign-gated dH
+    product and gemm_lnbwd agree to bf16 rounding of the outputs (2^-8 of the tensor's scale, + accumulation order)."""
+    g = torch.Generator().manual_seed(M + 5)
+    bf, f32 = torch.bfloat16, torch.float32
+    x = torch.randn(M, 256, generator=g).to(DEV, bf)
+    gm, bt = (1 + 0.1 * torch.randn(256, generator=g)).to(DEV), (0.1 * torch.randn(256, generator=g)).to(DEV)
+    for n_out, relu in ((768, False), (1024, True)):
+        w = (torch.randn(n_out, 256, generator=g) * 0.06).to(DEV, bf)
+        b = (torch.randn(n_out, generator=g) * 0.2).to(DEV)
+        yb, xnb, stb = ops.ln_gemm(x, gm, bt, w, b, n_out, relu=relu)[:3]
+        yf, xnf, stf = ops.ln_gemm(x.float(), gm, bt, w.float(), b, n_out, relu=relu)[:3]
+        check(f"bf16_vs_fp32.ln_gemm[M={M},N={n_out}].y", yb.float(), yf, 8e-3)                # measured <= 3.7e-3
+        check(f"bf16_vs_fp32.ln_gemm[M={M},N={n_out}].xn", xnb.float(), xnf, 6e-3)              # measured <= 3.0e-3
+        check(f"bf16_vs_fp32.ln_gemm[M={M},N={n_out}].stats", stb, stf, 1e-5)
+    # dH = (dY W2) gated by h > 0: sign bits (bf16 kernel) against the stored activation (fp32 kernel)
+    w1 = (torch.randn(1024, 256, generator=g) * 0.06).to(DEV, bf)
+    h, _, _, sg = ops.ln_gemm(x, gm, bt, w1, None, 1024, relu=True, want_signs=True)
+    dy = torch.randn(M, 256, generator=g).to(DEV, bf)
+    w2t = (torch.randn(1024, 256, generator=g) * 0.05).to(DEV, bf)
+    dhb = ops.gemm_nt_signs(dy, w2t, sg, 1.25)
+    dhf = ops.gemm_nt(dy.float(), w2t.float(), gate=h.float(), gate_scale=1.25)
+    check(f"bf16_vs_fp32.gemm_nt_signs[M={M}]", dhb.float(), dhf, 6.5e-3)                        # measured <= 3.2e-3
+    # dz = LNbackward(dY Wt^T) + d_res
+    for K in (768, 1024):
+        dyk = torch.randn(M, K, generator=g).to(DEV, bf)
+        wt = (torch.randn(256, K, generator=g) * 0.05).to(DEV, bf)
+        st = torch.stack([x.float().mean(-1), 1 / (x.float().std(-1) + 1e-6)], 1).contiguous()
+        dres = torch.randn(M, 256, generator=g).to(DEV, bf)
+        zb, ggb, gbb = ops.gemm_lnbwd(dyk, wt, x, st, gm, d_res2d=dres)
+        zf, ggf, gbf = ops.gemm_lnbwd(dyk.float(), wt.float(), x.float(), st, gm, d_res2d=dres.float())
+        check(f"bf16_vs_fp32.gemm_lnbwd[M={M},K={K}].dz", zb.float(), zf, 1e-2)                  # measured <= 5.1e-3
+        check(f"bf16_vs_fp32.gemm_lnbwd[M={M},K={K}].dgamma", ggb, ggf, 5e-3)                      # measured <= 2.2e-3
+        check(f"bf16_vs_fp32.gemm_lnbwd[M={M},K={K}].dbeta", gbb, gbf, 5e-3)                       # measured <= 2.5e-3
 
 
 # ------------------------------------------------------------------ hipGraph replay of the step
@@ -1399,9 +1453,77 @@ def test_cfg5_shape_four_images_twelve_layers_vs_oracle(ops):
     # 2.5e-3 on a w_1.bias; the 2-layer golden step stays at 1.9e-5): the typical gradient is held to 1e-4, the worst
     # to 1e-2
     worst, typical = errs[0][0], errs[len(errs) // 2][0]
-    REPORT["cfg5_k4_L12[fp32].worst_grad"] = {"rel_err": worst, "tol": 1e-2}
+    REPORT["cfg5_k4_L12[fp32].worst_grad"] = {"rel_err": worst, "tol": 3e-3}
     REPORT["cfg5_k4_L12[fp32].median_grad"] = {"rel_err": typical, "tol": 1e-4}
-    assert worst < 1e-2 and typical < 1e-4, errs[:8]
+    assert worst < 3e-3 and typical < 1e-4, errs[:8]                 # measured 1.35e-3 / 3.1e-5
+    # The explanation above, SHOWN: the hidden units whose ReLU gate differs between the two machines are
+    # found from the gradients themselves -- a flipped gate moves ONE entry of that layer's w_1.bias gradient by a whole
+    # token's dh, orders of magnitude above rounding -- and with exactly those units masked out (w_1 rows / w_1.bias entries /
+    # w_2 columns) every FFN gradient agrees to 3.5e-4 (measured: 2 flipped units among 23 x 1024, 1.7e-4 -- what is left is
+    # the flipped token's dx travelling on into the layers below, which no mask of hidden units removes).
+    flips = 0
+    worst_masked = 0.0
+    for n_, g_ref in ref_grads.items():
+        if not n_.endswith("feed_forward.w_1.bias"):
+            continue
+        pre = n_[:-len("w_1.bias")]
+        d = (grads[n_].cpu() - g_ref).abs()
+        flipped = d > 1e-4 * g_ref.abs().max()                      # units off by more than the gate of 1e-4
+        flips += int(flipped.sum())
+        keep = ~flipped
+        for suffix, sel in (("w_1.bias", lambda t: t[keep]), ("w_1.weight", lambda t: t[keep]), ("w_2.weight", lambda t: t[:, keep])):
+            a_, b_ = sel(grads[pre + suffix].cpu()), sel(ref_grads[pre + suffix])
+            e = float((a_ - b_).abs().max() / (ref_grads[pre + suffix].abs().max() + 1e-30))
+            worst_masked = max(worst_masked, e)
+    REPORT["cfg5_k4_L12[fp32].ffn_grads_with_flipped_gates_masked"] = {"rel_err": worst_masked, "tol": 3.5e-4, "flipped_units": flips}
+    assert flips <= 12, flips                                        # a handful among 23 x 1024 hidden units x 180 tokens
+    assert worst_masked < 3.5e-4, worst_masked
+
+
+def test_cfg5_full_size_properties(ops):
+    """BASELINE configs[4] at FULL size on one GPU (B 128, TIE-len 2000 -> N_v 2005, 12 layers, 4 images -> N_i 201, bf16):
+    size-independent properties of the whole training step -- finite loss that moves under AdamW, events past a sample's
+    length never read (poisoned pad rows: bit-identical losses and parameters), hipGraph replay == eager."""
+    from medical_tri_modal_pilot_amd import synthetic
+    from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    L, K, B, T = 12, 4, 128, 2000
+
+    def run(hip_graph, poison):
+        torch.manual_seed(11)
+        args, model = _product_model(L, 1, "bf16", hip_graph=hip_graph, n_images=K, batch_size=B, TIE_len=T, dropout=0.0)
+        model.train()
+        model.img_encoder.eval()                  # (no StochasticDepth draws: eager and replayed steps must see the same numbers)
+        opt = FusedAdamW(model.hot_parameters(), lr=1e-4, weight_decay=args.weight_decay)
+        sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=100, cycle_mult=1, max_lr=1e-3, min_lr=1e-6,
+                                              warmup_steps=10, gamma=1.0)
+        bt = synthetic.make_batch(99, B, T, ragged=True, missing_mode="none", multiimages=1, n_images=K)
+        assert int(bt["input_lengths"].max()) == T
+        x = bt["x"].clone()
+        if poison:                                # rows past each sample's length: never read by the forward; a FINITE value (the
+            for b_ in range(B):                   # inputs pass through fp16): 0 x poison in the backward stays 0 as in the reference
+                x[b_, int(bt["input_lengths"][b_]):] = 3e4
+        static = torch.stack([bt["gen"], bt["age"]], 1)
+        losses = []
+        for it in range(3):
+            _, loss = get_trainer(args=args, iteration=it + 1, x=x, static=static, y=bt["y"], output_lengths=None, model=model,
+                                  logger=_Logger(), device=torch.device(DEV), scheduler=sched, optimizer=opt,
+                                  criterion=torch.nn.BCEWithLogitsLoss(), x_txt=bt["txt"], x_img=bt["img"],
+                                  imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None, missing=bt["missing"],
+                                  input_lengths=bt["input_lengths"], txt_lengths=bt["txt_lengths"], flow_type="train",
+                                  reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+            losses.append(loss)
+        torch.cuda.synchronize()
+        return losses, opt.flat.data.detach().clone()
+
+    le, pe = run(0, False)
+    assert all(math.isfinite(v) for v in le) and le[0] != le[2], le
+    lp, pp = run(0, True)
+    assert le == lp and torch.equal(pe, pp), (le, lp)             # poisoned pad events change nothing, bit for bit
+    lg, pg = run(1, False)
+    assert le == lg and torch.equal(pe, pg), (le, lg)             # graph replay == eager
+    REPORT["cfg5_full_size[bf16].properties"] = {"rel_err": 0.0, "tol": 0.0, "losses": le}
 
 
 def test_cfg1_sample_data_windows_product_vs_oracle(ops):
