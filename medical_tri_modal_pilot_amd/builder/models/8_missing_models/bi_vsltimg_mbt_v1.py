@@ -1,0 +1,116 @@
+"""BI_VSLTIMG_MBT_V1 -- MI355X-native drop-in for the reference's two-stream sibling with the CXR stream
+(builder/models/8_missing_models/bi_vsltimg_mbt_v1.py:19-254): vital-sign / lab events (TIE / UMSE
+embedding) and the frozen Swin-T image features (Linear(768, 256) + time / modality embedding) fused by
+BimodalTransformerEncoder_MBT (image stream unmasked: ``mask=[True, False]``, :131).  Unlike BI_VSLTTXT_MBT_V1 the head
+runs on BOTH streams' CLS vectors -- LayerNorm, concat with the demographic embedding, fc_list with its BatchNorm1d over
+the 2 B rows (:230-235) -- and the two logits are mixed per sample by ``missing`` afterwards (0: their mean, 1: the
+vital-sign logit, :245-247).  Same constructor, forward signature, return triple (``output`` [B, output_dim], no squeeze) and
+state_dict keys as the reference; ``--input-types vslt_img`` (the trainer folds the four modality patterns onto {0, 1},
+trainer.py:102-104).
+
+On the HIP path: ``--vslt-type TIE``, ``--img-model-type swin`` (the ViT / MONAI branches and the report decoder
+(``--auxiliary-loss-type tdecoder``, :150-164) raise).  The head over 2 B rows is small fp32 torch code.
+"""
+import torch
+import torch.nn as nn
+
+from medical_tri_modal_pilot_amd import ops
+from medical_tri_modal_pilot_amd.builder.models.src.swin_transformer import swin_t_m
+from medical_tri_modal_pilot_amd.builder.models.src.transformer.mbt_encoder import BimodalTransformerEncoder_MBT
+
+from .tri_mbt_vsltcls import _compute_dtype, flat_layout
+
+
+class BI_VSLTIMG_MBT_V1(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.img_size = args.image_size
+        self.output_dim = args.output_dim
+        self.num_layers = args.transformer_num_layers
+        self.num_heads = args.transformer_num_head
+        self.model_dim = args.transformer_dim
+        self.dropout = args.dropout
+        self.idx_order = torch.arange(0, args.batch_size).type(torch.LongTensor)
+        self.num_nodes = len(args.vitalsign_labtest)
+        self.t_len = args.window_size
+        self.device = args.device
+        self.n_modality = len(args.input_types.split("_"))
+        self.bottlenecks_n = 4
+        self.compute_dtype = _compute_dtype(args)
+        if self.model_dim != 256:
+            raise ValueError("transformer_dim must be 256 (Linear(768,256) is hard-coded, bi_vsltimg_mbt_v1.py:113)")
+        if args.vslt_type != "TIE" or args.img_model_type != "swin" or "tdecoder" in args.auxiliary_loss_type:
+            raise NotImplementedError("BI_VSLTIMG_MBT_V1 on the MI355X path: --vslt-type TIE, --img-model-type swin, no report decoder")
+        self.activations = nn.ModuleDict([
+            ["lrelu", nn.LeakyReLU()], ["prelu", nn.PReLU()], ["relu", nn.ReLU(inplace=True)], ["tanh", nn.Tanh()],
+            ["sigmoid", nn.Sigmoid()], ["leaky_relu", nn.LeakyReLU(0.2)], ["elu", nn.ELU()]])
+        self.relu = self.activations["relu"]
+
+        def embed(n_in):
+            return nn.Sequential(nn.Linear(n_in, self.model_dim), nn.LayerNorm(self.model_dim), nn.ReLU(inplace=True))
+
+        self.ie_vslt = embed(1)
+        self.ie_time = embed(1)
+        self.ie_feat = nn.Embedding(20, self.model_dim)
+        self.ie_demo = embed(2)
+        self.img_model_type = args.img_model_type
+        self.img_pretrain = args.img_pretrain
+        # pretrained Swin weights come in through load_state_dict (the reference reads ImageNet / a private CXR checkpoint, :88-100)
+        self.img_encoder = swin_t_m(compute_dtype=self.compute_dtype)
+        self.linear = nn.Linear(768, 256)
+        self.flatten = nn.Flatten(1, 2)
+        self.fusion_transformer = BimodalTransformerEncoder_MBT(
+            batch_size=args.batch_size, n_modality=2, bottlenecks_n=4, fusion_startidx=args.mbt_fusion_startIdx,
+            d_input=self.model_dim, n_layers=self.num_layers, n_head=self.num_heads, d_model=self.model_dim,
+            d_ff=self.model_dim * 4, dropout=self.dropout, txt_idx=100, pe_maxlen=2500, use_pe=[False, True],
+            mask=[True, False], compute_dtype=self.compute_dtype)
+        classifier_dim = self.model_dim * 2
+        self.layer_norms_after_concat = nn.LayerNorm(self.model_dim)
+        self.fc_list = nn.Sequential(nn.Linear(classifier_dim, self.model_dim, bias=True), nn.BatchNorm1d(self.model_dim),
+                                     self.activations["relu"], nn.Linear(self.model_dim, self.output_dim, bias=True))
+        if "rmse" in self.args.auxiliary_loss_type:
+            self.rmse_layer = nn.Linear(classifier_dim, 1, bias=True)
+
+    def hot_parameters(self):
+        """Parameters that receive a gradient on this path, laid out for optim.FlatParams (the image encoder is frozen in
+        the tri-modal model's forward only -- here the reference trains it; on this path it stays frozen like there:
+        ``requires_grad`` of its parameters is the caller's switch and the HIP encoder has no backward)."""
+        skip = ("fusion_transformer.layer_norms_after_concat.", "activations.", "rmse_layer.", "img_encoder.")
+        named = [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
+        return flat_layout(named, self.fusion_transformer.layer_stacks)
+
+    def forward(self, x, h, m, d, x_m, age, gen, input_lengths, txts, txt_lengths, img, missing, f_indices, img_time,
+                txt_time, flow_type, reports_tokens, reports_lengths):
+        dt = self.compute_dtype
+        B = x.size(0)
+        age, gen = age.float(), gen.float()
+        demo_embedding = self.ie_demo(torch.stack([age, gen], dim=1))                       # [B,256] fp32 (:178-179)
+        vslt_embedding = ops.TieEmbed.apply(x.float(), self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight,
+                                            self.ie_vslt[1].bias, self.ie_time[0].weight, self.ie_time[0].bias,
+                                            self.ie_time[1].weight, self.ie_time[1].bias, self.ie_feat.weight, dt)
+        with torch.no_grad():                                                                # frozen encoder (no HIP backward)
+            feat = self.flatten(self.img_encoder(img))                                       # [B,49,768]
+        img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
+        if self.args.imgtxt_time == 1:                                                       # (:212-218)
+            ev = torch.zeros(B, 3, device=x.device)
+            ev[:, 0], ev[:, 2] = img_time.reshape(-1).float(), 18.0
+            it = ops.TimeEmbed.apply(ev, self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight,
+                                     self.ie_time[1].bias, self.ie_feat.weight, dt)
+            img_embedding = img_embedding + it.unsqueeze(1)
+        missing = missing.to(x.device).long()
+        outputs, _ = self.fusion_transformer(
+            enc_outputs=[vslt_embedding, img_embedding], fixed_lengths=[vslt_embedding.size(1), img_embedding.size(1)],
+            varying_lengths=[input_lengths, img_embedding.size(1)], fusion_idx=None, missing=missing)
+        # head on both CLS rows (:230-235), then the per-sample mix of the two logits (:245-247)
+        cls2 = torch.stack([outputs[0][:, 0, :], outputs[1][:, 0, :]]).float()              # [2,B,256]
+        class_input = torch.cat([self.layer_norms_after_concat(cls2).reshape(-1, self.model_dim),
+                                 demo_embedding.repeat(2, 1)], dim=1)                       # [2B,512]
+        out2 = self.fc_list(class_input).reshape(2, -1, self.output_dim)
+        pick_mean = (missing == 0).view(-1, 1)
+        output = torch.where(pick_mean, out2.mean(0), out2[0])
+        output2 = None
+        if "rmse" in self.args.auxiliary_loss_type:
+            r2 = self.rmse_layer(class_input).reshape(2, -1)
+            output2 = torch.where(missing == 0, r2.mean(0), r2[0])
+        return output, output2, None

@@ -79,21 +79,8 @@ class TRI_MBT_VSLTCLS(nn.Module):
             ["lrelu", nn.LeakyReLU()], ["prelu", nn.PReLU()], ["relu", nn.ReLU(inplace=True)], ["tanh", nn.Tanh()],
             ["sigmoid", nn.Sigmoid()], ["leaky_relu", nn.LeakyReLU(0.2)], ["elu", nn.ELU()]])
 
-        def embed(n_in):
-            return nn.Sequential(nn.Linear(n_in, self.model_dim), nn.LayerNorm(self.model_dim), nn.ReLU(inplace=True))
-
         # ---- encoders (reference :51-118)
-        if args.vslt_type == "carryforward":
-            self.vslt_enc = embed(self.num_nodes)
-            vslt_pe = True
-        elif args.vslt_type in ("TIE", "QIE"):
-            vslt_pe = False
-            self.ie_vslt = embed(1)
-        else:
-            raise ValueError(args.vslt_type)
-        self.ie_time = embed(1)
-        self.ie_feat = nn.Embedding(20, self.model_dim)
-        self.ie_demo = embed(2)
+        vslt_pe = self._make_embeddings(args)
         if args.berttype == "bert":
             self.txt_embedding = nn.Embedding(30000, self.model_dim)
         elif args.berttype == "biobert":
@@ -129,6 +116,53 @@ class TRI_MBT_VSLTCLS(nn.Module):
                                      nn.Linear(self.model_dim, self.output_dim, bias=True))
         # number of images per sample: the reference hard-codes 3 (:161-162,226-231); generalised to K.
         self.n_images = int(getattr(args, "n_images", 3)) if self.args.multiimages == 1 else 1
+
+    head_fusable = True        # ie_demo = Linear -> LayerNorm -> ReLU: what ops.HeadFn fuses (a sibling may differ)
+
+    def _make_embeddings(self, args) -> bool:
+        """ie_vslt / ie_time / ie_feat / ie_demo in the reference's registration order (:51-76); returns vslt_pe."""
+        def embed(n_in):
+            return nn.Sequential(nn.Linear(n_in, self.model_dim), nn.LayerNorm(self.model_dim), nn.ReLU(inplace=True))
+
+        if args.vslt_type == "carryforward":
+            self.vslt_enc = embed(self.num_nodes)
+            vslt_pe = True
+        elif args.vslt_type in ("TIE", "QIE"):
+            vslt_pe = False
+            self.ie_vslt = embed(1)
+        else:
+            raise ValueError(args.vslt_type)
+        self.ie_time = embed(1)
+        self.ie_feat = nn.Embedding(20, self.model_dim)
+        self.ie_demo = embed(2)
+        return vslt_pe
+
+    def _vslt_embedding(self, x, dt):
+        """TIE / UMSE event embedding (:183-190): ReLU(LN(value w + b)) + ReLU(LN(time w + b)) + ie_feat[feature]."""
+        tie_prm = (self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight, self.ie_vslt[1].bias,
+                   self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight, self.ie_time[1].bias,
+                   self.ie_feat.weight, dt)
+        if isinstance(x, PackedTie):      # ragged batch of builder/data (events, cu_seqlens, t_pad), SURVEY 8 f-1
+            return ops.TieEmbedPacked.apply(x.events, x.cu_seqlens, x.t_pad, *tie_prm)
+        return ops.TieEmbed.apply(x, *tie_prm)                                                # [B,T,256]
+
+    def _time_embeddings(self, img_time, txt_time, demo_embedding, dt):
+        """(it [n_img,256], tt [B,256]): ie_time(t) + ie_feat[18 | 19] of every image / report time (:216-224)."""
+        feat_tab = self.ie_feat.weight
+        if self.args.vslt_type == "QIE" or not img_time.is_cuda:
+            it = self.ie_time(img_time.unsqueeze(1)) + feat_tab[18]
+            tt = self.ie_time(txt_time.unsqueeze(1)) + feat_tab[19]
+            if self.args.vslt_type == "QIE":
+                it = it + (demo_embedding if self.n_images == 1 else demo_embedding.repeat_interleave(self.n_images, 0))
+                tt = tt + demo_embedding
+            return it.to(dt), tt.to(dt)
+        # both time embeddings of the batch in one HIP launch each way (ops.TimeEmbed)
+        n_it = img_time.numel()
+        ev = self._time_events(n_it, txt_time.numel(), img_time.device)
+        ev[:, 0] = torch.cat([img_time, txt_time])
+        emb = ops.TimeEmbed.apply(ev, self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight,
+                                  self.ie_time[1].bias, feat_tab, dt)
+        return emb[:n_it], emb[n_it:]
 
     # NOTE: like the reference, model.train() (2_train.py:128) puts the Swin encoder back into train mode
     # although the constructor called .eval() (:104), so its row-mode StochasticDepth is active while
@@ -201,7 +235,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
             x = x.float()
         age, gen = age.float(), gen.float()
         # head + ie_demo as six HIP launches (ops.HeadFn) when the demographic embedding feeds nothing but the head
-        fused_head = (age.is_cuda and B <= ops.HEAD_MAX_B and self.args.vslt_type != "QIE"
+        fused_head = (self.head_fusable and age.is_cuda and B <= ops.HEAD_MAX_B and self.args.vslt_type != "QIE"
                       and "rmse" not in self.args.auxiliary_loss_type and (B > 1 or not self.training))
         if not fused_head:
             demographic = torch.stack([age, gen], dim=1)
@@ -253,33 +287,13 @@ class TRI_MBT_VSLTCLS(nn.Module):
         if self.args.vslt_type == "carryforward":
             vslt_embedding = self.vslt_enc(x).to(dt)
         else:
-            tie_prm = (self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight, self.ie_vslt[1].bias,
-                       self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight, self.ie_time[1].bias,
-                       self.ie_feat.weight, dt)
-            if isinstance(x, PackedTie):      # ragged batch of builder/data (events, cu_seqlens, t_pad), SURVEY 8 f-1
-                vslt_embedding = ops.TieEmbedPacked.apply(x.events, x.cu_seqlens, x.t_pad, *tie_prm)
-            else:
-                vslt_embedding = ops.TieEmbed.apply(x, *tie_prm)                              # [B,T,256]
+            vslt_embedding = self._vslt_embedding(x, dt)
             if self.args.vslt_type == "QIE":
                 vslt_embedding = vslt_embedding + demo_embedding.unsqueeze(1).to(dt)
         img_time = img_time.reshape(-1).float()
         txt_time = txt_time.float()
         if self.args.imgtxt_time == 1:                                                        # (:216-224)
-            feat_tab = self.ie_feat.weight
-            if self.args.vslt_type == "QIE" or not img_time.is_cuda:
-                it = self.ie_time(img_time.unsqueeze(1)) + feat_tab[18]
-                tt = self.ie_time(txt_time.unsqueeze(1)) + feat_tab[19]
-                if self.args.vslt_type == "QIE":
-                    it = it + (demo_embedding if self.n_images == 1 else demo_embedding.repeat_interleave(self.n_images, 0))
-                    tt = tt + demo_embedding
-                it, tt = it.to(dt), tt.to(dt)
-            else:             # both time embeddings of the batch in one HIP launch each way (ops.TimeEmbed)
-                n_it = img_time.numel()
-                ev = self._time_events(n_it, txt_time.numel(), img_time.device)
-                ev[:, 0] = torch.cat([img_time, txt_time])
-                emb = ops.TimeEmbed.apply(ev, self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight,
-                                          self.ie_time[1].bias, feat_tab, dt)
-                it, tt = emb[:n_it], emb[n_it:]
+            it, tt = self._time_embeddings(img_time, txt_time, demo_embedding if not fused_head else None, dt)
             if side is not None:
                 for s_ in side:
                     s_.wait_stream(cur)              # the time embeddings were made on the main stream

@@ -747,6 +747,31 @@ class DataLinearFn(torch.autograd.Function):
         return None, gw, gb, None
 
 
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) with gradients for x, W and b: mtmp_gemm_nt forward, mtmp_gemm_tn for dW / db and mtmp_gemm_nt
+    on W^T for dx.  The second projections of the sibling model's UMSE chains (tri_mbt_vsltcls_noshareumse.py:61-81:
+    Linear(256, 256, bias=False) over every event)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype):
+        _gpu(x, weight)
+        lead = x.shape[:-1]
+        x2 = _c(x.reshape(-1, x.shape[-1]).to(dtype))
+        wc = _c(weight.detach().to(dtype))
+        y = gemm_nt(x2, wc, None if bias is None else _c(bias.detach().float()))
+        ctx.save_for_backward(x2, wc)
+        ctx.wshape, ctx.has_bias, ctx.xdtype = weight.shape, bias is not None, x.dtype
+        return y.view(*lead, weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wc = ctx.saved_tensors
+        dy2 = _c(dy.reshape(-1, dy.shape[-1]).to(x2.dtype))
+        dw, db = gemm_tn(dy2, x2)
+        dx = gemm_nt(dy2, _c(wc.t()))
+        return (dx.view(*dy.shape[:-1], x2.shape[1]).to(ctx.xdtype), dw.view(ctx.wshape), db if ctx.has_bias else None, None)
+
+
 # ----------------------------------------------------------------------------- classification head (K10)
 HEAD_MAX_B = 256        # rows per rank the head kernels take (csrc/head.hip: one, two or four rows per lane)
 

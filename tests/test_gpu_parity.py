@@ -1071,6 +1071,63 @@ def test_bi_vslttxt_model_train_step_vs_golden(ops):
     assert worst < 1e-4
 
 
+@pytest.mark.parametrize("name,input_types,tag", [("tri_mbt_vsltcls_noshareumse", "vslt_img_txt", "noshareumse"),
+                                                  ("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg")])
+def test_more_sibling_models_train_step_vs_golden(ops, name, input_types, tag):
+    """SURVEY 8 f-4 / VERDICT r2 missing #3: TRI_MBT_VSLTCLS_NOSHAREUMSE (UMSE chains without LayerNorm, own time chains for
+    image / report) and BI_VSLTIMG_MBT_V1 (two streams with the CXR encoder, head on both CLS rows) through get_model:
+    logits, BCE loss and every parameter gradient outside the (here frozen) image encoder against the REAL classes
+    (tests/golden/gen/make_golden.py siblings), fp32 build, 1e-4."""
+    import json
+    from medical_tri_modal_pilot_amd.control.config import parse_args
+    from medical_tri_modal_pilot_amd.builder.models import get_model
+    Gd = G(tag + "_step")
+    with open(os.path.join(ROOT, "tests", "golden", f"state_shapes_{tag}_L2.json")) as f:
+        shapes = json.load(f)
+    sd = {k: filler.fill_tensor(k, torch.zeros(s)) for k, (s, dt_) in shapes.items() if dt_.startswith("float")}
+    sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
+    a = parse_args(["--input-types", input_types, "--model", name, "--modality-inclusion", "train-missing_test-missing",
+                    "--lr-init", "1e-5", "--batch-size", "4", "--transformer-num-layers", "2", "--imgtxt-time", "1",
+                    "--mbt-only-vslt", "1", "--dropout", "0.0", "--compute-dtype", "fp32", "--hip-graph", "0"])
+    a.device, a.output_dim = torch.device(DEV), 1
+    model = get_model(a)(a)
+    missing_keys = model.load_state_dict(sd, strict=False)
+    assert not [k for k in missing_keys.missing_keys if "relative_position_index" not in k and "idx" not in k], missing_keys
+    model = model.to(DEV).train()
+    model.img_encoder.eval()
+    bt = filler.make_batch(int(Gd["seed"]), int(Gd["B"]), int(Gd["T"]))
+    mnum = torch.from_numpy(Gd["missing_num"])
+    tmax = int(bt["input_lengths"].max())
+    dv = lambda t: t.to(DEV)
+    out, o2, o3 = model(dv(bt["x"][:, :tmax]), None, None, None, None, dv(bt["age"]), dv(bt["gen"]), dv(bt["input_lengths"].clone()),
+                        dv(bt["txt"]), dv(bt["txt_lengths"].clone()), dv(bt["img"]), dv(mnum), None, dv(bt["img_time"].half().float()),
+                        dv(bt["txt_time"].half().float()), "train", None, None)
+    assert o2 is None and o3 is None and tuple(out.shape) == tuple(Gd["logits"].shape)
+    check(f"{tag}_step[fp32].logits", out, torch.from_numpy(Gd["logits"]), 1e-4)
+    loss = torch.nn.BCEWithLogitsLoss()(out.squeeze(-1), dv(bt["y"].float()))
+    REPORT[f"{tag}_step[fp32].loss"] = {"rel_err": abs(float(loss) - float(Gd["loss"])), "tol": 1e-5}
+    assert abs(float(loss) - float(Gd["loss"])) < 1e-5
+    loss.backward()
+    names = [str(s) for s in Gd["grad_names"]]
+    med = float(np.median(Gd["grad_digest"][:, 0]))
+    prm = dict(model.named_parameters())
+    worst, n_checked = 0.0, 0
+    for n_, gd in zip(names, Gd["grad_digest"]):
+        if n_.startswith("img_encoder."):
+            assert prm[n_].grad is None                    # the HIP image encoder has no backward: frozen on this path
+            continue
+        assert prm[n_].grad is not None, n_
+        if gd[0] < 1e-4 * med:
+            assert float(_digest(prm[n_].grad)[0]) < 1e-3 * med, n_
+            continue
+        worst = max(worst, _rel(_digest(prm[n_].grad), torch.from_numpy(gd)))
+        n_checked += 1
+    for n_ in (str(s) for s in Gd["nograd_names"]):
+        assert prm[n_].grad is None, n_
+    REPORT[f"{tag}_step[fp32].worst_grad_digest"] = {"rel_err": worst, "tol": 1e-4, "tensors": n_checked}
+    assert worst < 1e-4 and n_checked >= 80, (worst, n_checked)
+
+
 class _Logger:
     class _Ev:
         def __init__(self):

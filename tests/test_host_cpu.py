@@ -331,6 +331,27 @@ def test_bi_vslttxt_model_surface_matches_reference():
         get_model(a)
 
 
+@pytest.mark.parametrize("name,input_types,tag", [("tri_mbt_vsltcls_noshareumse", "vslt_img_txt", "noshareumse"),
+                                                  ("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg")])
+def test_more_sibling_model_surfaces_match_reference(name, input_types, tag):
+    """SURVEY 8 f-4 / VERDICT r2 missing #3: the other two siblings whose forward returns -- state_dict keys / shapes of the
+    real classes, parameter ORDER (what torch.optim.AdamW(model.parameters()) state is indexed by), gradient set."""
+    from medical_tri_modal_pilot_amd.builder.models import get_model
+    a = _args()
+    a.input_types, a.model, a.output_dim = input_types, name, 1
+    model = get_model(a)(a)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", f"state_shapes_{tag}_L2.json")))
+    sd = model.state_dict()
+    assert set(sd) == set(ref), set(sd) ^ set(ref)
+    for k, (shape, dtype) in ref.items():
+        assert tuple(sd[k].shape) == tuple(shape) and str(sd[k].dtype).replace("torch.", "") == dtype, k
+    pnames = [n for n, _ in model.named_parameters()]
+    assert pnames == [k for k in ref if k in set(pnames)]               # registration order = the reference's
+    G = np.load(os.path.join(ROOT, "tests", "golden", f"{tag}_step.npz"))
+    want = sorted(str(s) for s in G["grad_names"] if not str(s).startswith("img_encoder."))   # (the image encoder is frozen here)
+    assert sorted(n for n, _ in model.hot_parameters()) == want
+
+
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher environment starts two ranks as children of a GPU-free parent
     (torch.distributed.run on 127.0.0.1) and relays rank 0's JSON line; --dry-run stops before the first GPU call."""
