@@ -313,6 +313,138 @@ print("OK", rank)
 """
 
 
+STAGED_WORKER = r"""
+# Two gloo ranks drive the PRODUCT's staged step (builder/trainer/trainer.py _stage_bounds + _staged_step, the stage
+# callables GraphedTrainStep captures one hipGraph each from) on a CPU stand-in of the model surface those use:
+# fusion_transformer.{n_layers, fusion_idx, graph_segments, segment_boundaries}, backward_stage_params().  The runner
+# below is GraphedTrainStep._eager_on_side_stream without the streams: stage, take_ready(), launch().
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["MTMP_ROOT"])
+from medical_tri_modal_pilot_amd.optim import FlatParams
+from medical_tri_modal_pilot_amd.ddp import GradReducer, broadcast_module_state
+from medical_tri_modal_pilot_amd.builder.trainer import trainer as T
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+D, L = 8, 6
+
+
+class Enc(torch.nn.Module):
+    supports_segments, resbottle = True, False
+
+    def __init__(self):
+        super().__init__()
+        self.n_layers, self.fusion_idx, self.graph_segments, self.segment_boundaries = L, 0, None, []
+        self.layer_stacks = torch.nn.ModuleList(torch.nn.ModuleList(torch.nn.Linear(D, D) for _ in range(3)) for _ in range(L))
+
+    def forward(self, zs):
+        self.segment_boundaries = []
+        cuts = set(self.graph_segments or ())
+        for l, layer in enumerate(self.layer_stacks):
+            if l in cuts:
+                self.segment_boundaries.append(tuple(zs))
+            mix = sum(z.mean(1, keepdim=True) for z in zs) / 3          # the streams meet in every layer, as through the bottleneck
+            zs = [torch.tanh(f(z)) + mix for f, z in zip(layer, zs)]
+        return zs
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inp = torch.nn.ModuleList(torch.nn.Linear(5, D) for _ in range(3))
+        self.bn = torch.nn.BatchNorm1d(D)                              # buffers: running stats + num_batches_tracked
+        self.fusion_transformer = Enc()
+        self.fc_list = torch.nn.Linear(3 * D, 1)
+
+    def forward(self, x):
+        zs = [f(x) for f in self.inp]
+        zs[1] = self.bn(zs[1].transpose(1, 2)).transpose(1, 2)
+        zs = self.fusion_transformer(zs)
+        return self.fc_list(torch.cat([z[:, 0] for z in zs], -1))
+
+    def backward_stage_params(self, lo, hi, head):
+        pre = tuple(f"fusion_transformer.layer_stacks.{l}." for l in range(lo, hi)) + (("fc_list.",) if head else ())
+        return [p for n, p in self.named_parameters() if n.startswith(pre)]
+
+
+torch.manual_seed(100 + rank)
+net = Net()
+with torch.no_grad():
+    net.bn.running_mean.fill_(float(rank + 1))
+    net.bn.num_batches_tracked.fill_(7 * (rank + 1))
+broadcast_module_state(net, 0)
+assert float(net.bn.running_mean[0]) == 1.0 and int(net.bn.num_batches_tracked) == 7      # rank 0's buffers everywhere
+state = [torch.zeros_like(t) for t in list(net.parameters()) + list(net.buffers())]
+for s, t in zip(state, list(net.parameters()) + list(net.buffers())):
+    s.copy_(t)
+    both = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(both, t.data)
+    assert all(torch.equal(both[0], b) for b in both)
+
+flat = FlatParams(net.named_parameters())
+red = GradReducer(flat, bucket_bytes=1024)
+red.staged = True
+opt = types.SimpleNamespace(flat=flat, zero_grad=flat.zero_grad)
+crit = torch.nn.BCEWithLogitsLoss()
+args = types.SimpleNamespace(graph_stages=0, vslt_type="TIE")
+enc = net.fusion_transformer
+bounds = T._stage_bounds(args, enc, True)
+assert bounds == [0, 2, 4, 6], bounds
+assert len(T._stage_bounds(args, enc, False)) == 2                 # single rank: one graph
+enc.graph_segments = bounds[1:-1]
+g = torch.Generator().manual_seed(3)
+xs = [torch.randn(4, 7, 5, generator=g) for _ in range(world)]
+ys = [(torch.rand(4, generator=g) > 0.5).float() for _ in range(world)]
+run_model = lambda t: net(t["data"]).squeeze()
+stages = T._staged_step(net, enc, opt, crit, run_model, bounds)
+assert len(stages) == 3
+
+
+def reference():
+    exp, losses = None, []
+    for r in range(world):
+        m = Net()
+        with torch.no_grad():
+            for q, s in zip(list(m.parameters()) + list(m.buffers()), state):
+                q.copy_(s)
+        loss = crit(m(xs[r]).squeeze(), ys[r])
+        loss.backward()
+        gs = [q.grad.clone() for q in m.parameters()]
+        exp = gs if exp is None else [a + b for a, b in zip(exp, gs)]
+        losses.append(float(loss))
+    return exp, losses
+
+
+exp, losses = reference()
+for step in range(2):                                                # the second step re-arms hooks, buckets and the log
+    with torch.no_grad():
+        for q, s in zip(list(net.parameters()) + list(net.buffers()), state):
+            q.copy_(s)
+    carry, per_stage = {}, []
+    inputs = dict(data=xs[rank], final_target=ys[rank])
+    for st in stages:
+        st(inputs, carry)
+        assert not red.works or per_stage                              # nothing goes out before the first launch()
+        ids = red.take_ready()
+        per_stage.append(list(ids))
+        red.launch(ids)
+    red.wait()
+    assert abs(float(carry["loss"]) - losses[rank]) < 1e-6
+    assert len(carry["bnds"]) == 2
+    sent = [b for ids in per_stage for b in ids]
+    assert sorted(sent) == list(range(len(red.buckets))), (per_stage, len(red.buckets))    # every bucket once
+    assert all(per_stage), per_stage                                   # every stage completed buckets of its own
+    # stage 0 only sent buckets that lie entirely in [first parameter of layer 4, end): layers 4, 5 and the head
+    lo4 = flat.offsets[flat.index_of[id(enc.layer_stacks[4][0].weight)]]
+    assert all(red.buckets[b][0] >= lo4 for b in per_stage[0]), per_stage
+    lo2 = flat.offsets[flat.index_of[id(enc.layer_stacks[2][0].weight)]]
+    assert all(red.buckets[b][0] >= lo2 for b in per_stage[1]), per_stage
+    for (n, p), e in zip(net.named_parameters(), exp):
+        assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6), (rank, step, n)
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
 def test_bi_vslttxt_model_surface_matches_reference():
     """get_model(--model bi_vslttxt_mbt_v1) -> the reference's state_dict keys / shapes and gradient set."""
     from medical_tri_modal_pilot_amd.builder.models import get_model
@@ -416,6 +548,21 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
     script = tmp_path / "ddp_worker.py"
     script.write_text(DDP_WORKER)
     env = dict(os.environ, MTMP_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2",
+               OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o
+
+
+def test_product_staged_step_two_ranks_gloo(tmp_path):
+    """E3: trainer._stage_bounds / _staged_step (the stage callables of the hipGraph step under DDP) with ddp.GradReducer in
+    staged mode on two gloo ranks: three stages, every bucket launched once behind the stage that completed it, gradients =
+    the sum of the single-rank gradients; broadcast_module_state carries the BatchNorm buffers."""
+    script = tmp_path / "staged_worker.py"
+    script.write_text(STAGED_WORKER)
+    env = dict(os.environ, MTMP_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2",
                OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
