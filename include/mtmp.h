@@ -49,16 +49,20 @@ int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* 
 /* Grouped forms: up to three token streams (vital signs / image / text of one fusion layer) in ONE launch -- the blocks of the
  * short streams follow the long stream's in the same grid instead of occupying workgroup slots beside it from other HIP
  * streams.  All pointer / int arrays are HOST arrays of n entries (1 <= n <= 3); res / o_res / kv_len / key_norms may be NULL
- * as a whole or per entry; B, H, scale are common.  Same kernels, same results as n calls of the single forms. */
+ * as a whole or per entry; B, H, scale are common.  Same kernels, same results as n calls of the single forms.
+ * row_start (may be NULL as a whole or per entry): stream i is PACKED -- row_start[i] is int32[B] on the device
+ * (mtmp_row_starts), sample b's kv_len[i][b] tokens are rows row_start[i][b] .. of the q / k / v / o / res / d_o / dq / dk / dv
+ * buffers, with no pad rows between samples (kv_len[i][b] is then also the sample's query count); N[i] is the longest
+ * sample the buffers were sized for, and stays the stride of lse / delta_ws ([B, H, N[i]]). */
 int mtmp_attn_fwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v, void* const* o,
                           const void* const* res, void* const* o_res, float* const* lse, const int32_t* const* kv_len,
-                          const float* const* key_norms, const int* N, const int* ld_qkv, const int* ld_o, int B, int H,
-                          float scale, void* stream);
+                          const int32_t* const* row_start, const float* const* key_norms, const int* N, const int* ld_qkv,
+                          const int* ld_o, int B, int H, float scale, void* stream);
 int mtmp_attn_bwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v,
                           const void* const* o, const void* const* d_o, const float* const* lse, const int32_t* const* kv_len,
-                          void* const* dq, void* const* dk, void* const* dv, float* const* delta_ws, const int* N,
-                          const int* ld_qkv, const int* ld_o, const int* ld_do, const int* ld_dqkv, int B, int H, float scale,
-                          void* stream);
+                          const int32_t* const* row_start, void* const* dq, void* const* dk, void* const* dv,
+                          float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o, const int* ld_do,
+                          const int* ld_dqkv, int B, int H, float scale, void* stream);
 /* out[ceil(rows / 32)][H] = max over each 32-row block of ||k[row, 64h : 64h + 64]||_2 (k: [rows, ld]). */
 long long mtmp_key_norms_floats(long long rows, int H);
 int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream);
@@ -126,6 +130,10 @@ int mtmp_gemm_nt_signs_drop(int dtype, const void* a, const void* w, void* y, in
 long long mtmp_gemm_tn_ws_floats(int M, int N, int K);
 int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K,
                  int ldy, int ldx, void* stream);
+/* The same with rows_live (may be NULL): a DEVICE word with the rows in use (<= M) -- a packed token stream, see the grouped
+ * forms below; split count, workspace and grid stay those of M, the splits share the live rows. */
+int mtmp_gemm_tn_live(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K,
+                      int ldy, int ldx, const int32_t* rows_live, void* stream);
 
 /* g_out[i] = keep(seed,i) ? g_in[i]/(1-p) : 0 over n contiguous elements: backward of the epilogue
  * dropout above (n = M*N of that call, n % 4 == 0). */
@@ -184,14 +192,19 @@ int mtmp_tie_embed_packed_bwd(int dtype, const float* events, const int32_t* cu_
  * cls / gamma / beta float[256], pe float[>= N+1][256] or NULL, bott float[nb][256] (nb <= 4);
  * stats float[B*(N+1)][2] is written by the forward and read by the backward; dropout as in mtmp_dropout_bwd
  * (seed ^ *seed_dev). grads float[7][256] = dgamma, dbeta, dcls, dbott[0..3], overwritten.
- * ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats. */
+ * ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats.
+ * row_start / kv_len (int32 device, NULL together): PACKED output -- row r < kv_len[b] of sample b is written to row
+ * row_start[b] + r of `out` (read from there in dz), the other rows are not written; x / dx keep the padded [B,N,256]
+ * layout (dx rows of pad events are written as zeros). */
 int mtmp_stream_input_ws_floats(int rows);
 int mtmp_stream_input_fwd(int dtype, const void* x, const float* cls, const float* gamma, const float* beta,
                           const float* pe, const float* bott, void* out, float* stats, int B, int N, int nb, float eps,
-                          float p, unsigned seed, const unsigned* seed_dev, void* stream);
+                          float p, unsigned seed, const unsigned* seed_dev, const int32_t* row_start, const int32_t* kv_len,
+                          void* stream);
 int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float* cls, const float* gamma,
                           const float* stats, void* dx, float* grads, float* ws, int B, int N, int nb, float p,
-                          unsigned seed, const unsigned* seed_dev, void* stream);
+                          unsigned seed, const unsigned* seed_dev, const int32_t* row_start, const int32_t* kv_len,
+                          void* stream);
 
 /* Classification head (tri_mbt_vsltcls.py:59-76 ie_demo, :248-255): out[b] = fc3(ReLU(BatchNorm1d(fc0([LN(cls[b]) |
  * ReLU(LN(ie_demo.0(age, gender)))])))), fp32, B <= 256, six launches forward + backward instead of ~65 torch kernels.
@@ -267,12 +280,14 @@ int mtmp_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_
  * gradients on entry and each stream's own bottleneck-output gradient on exit; d_prev_in (may be NULL) /
  * d_prev_out carry the residual path between consecutive exchanges.
  * z_t / dz_t may be NULL: the two-stream encoder (BimodalTransformerEncoder_MBT, mbt_encoder.py:519-634), whose
- * patterns {0: mean of both, 1: stream 0} the caller passes as rows 1 and 3. */
+ * patterns {0: mean of both, 1: stream 0} the caller passes as rows 1 and 3.
+ * row_start_v (int32[B] device, may be NULL): the first buffer is PACKED, its sample b starts at row row_start_v[b]. */
 int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, void* z_t, int B, int n_v, int n_i, int n_t,
-                                 const long long* missing, int resbottle, const float* prev, float* keep, void* stream);
+                                 const long long* missing, int resbottle, const float* prev, float* keep,
+                                 const int32_t* row_start_v, void* stream);
 int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, int B, int n_v, int n_i, int n_t,
                                  const long long* missing, int resbottle, const float* d_prev_in, float* d_prev_out,
-                                 void* stream);
+                                 const int32_t* row_start_v, void* stream);
 
 /* Grouped forms of the fusion layer's row-wise kernels (bf16): the same operation of up to three token streams (vital signs /
  * image / text) in ONE launch -- see mtmp_attn_fwd_grouped.  All pointer / int arrays are HOST arrays of n entries (1 <= n <= 3),
@@ -285,26 +300,33 @@ int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, 
  *   mtmp_gemm_lnbwd_grouped         = mtmp_gemm_lnbwd per stream, partial slabs only (reduce with mtmp_reduce_batch)
  *   mtmp_gemm_tn_grouped            = mtmp_gemm_tn per stream on the LDS-DMA kernel, partial slabs only: ws[i] holds
  *                                     splits[i] x (N K + N) floats with splits from mtmp_gemm_tn_group_plan (non-zero return:
- *                                     these shapes have no grouped form -- call mtmp_gemm_tn per stream) */
+ *                                     these shapes have no grouped form -- call mtmp_gemm_tn per stream)
+ * rows_live (may be NULL as a whole or per entry): rows_live[i] is a DEVICE word holding the rows of stream i that are in use
+ * this step (<= M[i]) -- the packed vital-sign stream (mtmp_row_starts), whose buffers and launch grids keep the padded size
+ * M[i] so that a captured hipGraph replays for any lengths: rows past it are neither read nor written, workgroups that own
+ * none return at once (their gradient partials count as zeros), and mtmp_gemm_tn_grouped's splits share the live rows. */
 int mtmp_ln_gemm_qkv_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
                              const void* const* w, const float* const* bias, void* const* y, void* const* xn, float* const* stats,
-                             float* const* key_norms, const int* M, const int* ldx, float eps, void* stream);
+                             float* const* key_norms, const int* M, const int* ldx, float eps, const int32_t* const* rows_live,
+                             void* stream);
 int mtmp_ln_gemm_signs_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
                                const void* const* w, const float* const* bias, void* const* y, void* const* xn, float* const* stats,
                                void* const* signs, const int* M, int N, const int* ldx, float eps, float drop_p,
-                               const unsigned* seeds, const unsigned* seed_dev, void* stream);
+                               const unsigned* seeds, const unsigned* seed_dev, const int32_t* const* rows_live, void* stream);
 int mtmp_gemm_nt_grouped(int dtype, int n, const void* const* a, const void* const* w, const float* const* bias,
                          const void* const* res, void* const* y, const int* M, int N, int K, const int* lda, const int* ldy,
-                         const int* ldr, int act, float drop_p, const unsigned* seeds, const unsigned* seed_dev, void* stream);
+                         const int* ldr, int act, float drop_p, const unsigned* seeds, const unsigned* seed_dev,
+                         const int32_t* const* rows_live, void* stream);
 int mtmp_gemm_nt_signs_drop_grouped(int dtype, int n, const void* const* a, const void* const* w, void* const* y, const int* M, int N,
                                     const int* lda, const void* const* signs, float gate_scale, float drop_p, const unsigned* seeds,
-                                    const unsigned* seed_dev, void* const* a_out, void* stream);
+                                    const unsigned* seed_dev, void* const* a_out, const int32_t* const* rows_live, void* stream);
 int mtmp_gemm_lnbwd_grouped(int dtype, int n, const void* const* dy, const void* const* wt, const void* const* z, const int* ldz,
                             const float* const* stats, const float* const* gamma, const void* const* d_res, const int* ldr,
-                            void* const* dz, float* const* ws, const int* M, int K, const int* ldy, float eps, void* stream);
+                            void* const* dz, float* const* ws, const int* M, int K, const int* ldy, float eps,
+                            const int32_t* const* rows_live, void* stream);
 int mtmp_gemm_tn_group_plan(int n, const int* M, int N, int K, int* splits_out);
 int mtmp_gemm_tn_grouped(int dtype, int n, const void* const* dy, const void* const* x, float* const* ws, const int* M, int N, int K,
-                         const int* ldy, const int* ldx, const int* splits, void* stream);
+                         const int* ldy, const int* ldx, const int* splits, const int32_t* const* rows_live, void* stream);
 
 /* Deferred reductions: mtmp_gemm_tn with dw == NULL (and db == NULL) and mtmp_gemm_lnbwd with dgamma_dbeta == NULL leave their
  * partial slabs in ws -- [mtmp_gemm_tn_slab_rows(dtype,M,N,K)][N K + N] and [mtmp_gemm_lnbwd_slab_rows(M)][512] floats -- and
@@ -337,6 +359,11 @@ int mtmp_transpose_batch(int elem_bytes, const void* const* src, void* const* ds
  * 3 -> 0; fused = plain + n_bott.  len_*: int64 [B] or NULL (unmasked stream: rows left untouched); out: int32 [2][3][B]. */
 int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const long long* len_t, int* out, int B, int n_bott,
                         int txt_idx, void* stream);
+/* Row map of a PACKED token stream ("skip padded key tiles and padded query rows"; the reference pads every sample to
+ * the batch maximum, trainer.py:41-42, and masks keys, utils.py:79-125): out[b] = sum of min(max(kv_len[0..b), 0), n_max) =
+ * sample b's first row when the samples' valid rows are stored back to back; out[B] = the rows in use (the `rows_live` word of
+ * the grouped kernels).  kv_len: int32[B] device (a fused count of mtmp_stream_lengths); out: int32[B + 1] device. */
+int mtmp_row_starts(const int32_t* kv_len, int32_t* out, int B, int n_max, void* stream);
 
 #ifdef __cplusplus
 }

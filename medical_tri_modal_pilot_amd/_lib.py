@@ -18,8 +18,8 @@ SIGNATURES = {
     "mtmp_abi_version": (c_int, []),
     "mtmp_last_error": (c_char_p, []),
     "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 9 + [c_int] * 5 + [c_float, c_void_p]),
-    "mtmp_attn_fwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 12 + [c_int, c_int, c_float, c_void_p]),
-    "mtmp_attn_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 16 + [c_int, c_int, c_float, c_void_p]),
+    "mtmp_attn_fwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 13 + [c_int, c_int, c_float, c_void_p]),
+    "mtmp_attn_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 17 + [c_int, c_int, c_float, c_void_p]),
     "mtmp_key_norms_floats": (c_longlong, [c_longlong, c_int]),
     "mtmp_key_norms": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mtmp_attn_bwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int] * 7 + [c_float, c_void_p]),
@@ -32,27 +32,29 @@ SIGNATURES = {
     "mtmp_gemm_nt_signs": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_void_p]),
     "mtmp_gemm_nt_signs_drop": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_float, c_uint, c_void_p,
                                                                                    c_void_p, c_void_p]),
-    "mtmp_ln_gemm_qkv_grouped": (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_float, c_void_p]),
+    "mtmp_ln_gemm_qkv_grouped": (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_float, c_void_p, c_void_p]),
     "mtmp_ln_gemm_signs_grouped": (c_int, [c_int, c_int] + [c_void_p] * 10 + [c_int, c_void_p, c_float, c_float, c_void_p, c_void_p,
-                                                                                   c_void_p]),
+                                                                                   c_void_p, c_void_p]),
     "mtmp_gemm_nt_grouped": (c_int, [c_int, c_int] + [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 3 + [c_int, c_float, c_void_p,
-                                                                                                       c_void_p, c_void_p]),
+                                                                                                       c_void_p, c_void_p, c_void_p]),
     "mtmp_gemm_nt_signs_drop_grouped": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_float, c_float,
-                                                                                  c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mtmp_gemm_lnbwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int, c_void_p, c_float, c_void_p]),
+                                                                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtmp_gemm_lnbwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 11 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "mtmp_gemm_tn_group_plan": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p]),
-    "mtmp_gemm_tn_grouped": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 3 + [c_void_p]),
+    "mtmp_gemm_tn_grouped": (c_int, [c_int, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 4 + [c_void_p]),
     "mtmp_gemm_tn_slab_rows": (c_int, [c_int] * 4),
     "mtmp_gemm_lnbwd_slab_rows": (c_int, [c_int]),
     "mtmp_reduce_batch": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),
     "mtmp_publish_scalar": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mtmp_copy_batch": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_stream_lengths": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    "mtmp_row_starts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mtmp_transpose_batch": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mtmp_layernorm_rows": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p]),
     "mtmp_swin_window_attn": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "mtmp_gemm_tn_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "mtmp_gemm_tn": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "mtmp_gemm_tn_live": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_void_p]),
     "mtmp_ln_bwd_ws_floats": (c_int, [c_int]),
     "mtmp_ln_bwd": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                             c_void_p, c_void_p, c_int, c_float, c_void_p]),
@@ -67,8 +69,8 @@ SIGNATURES = {
     "mtmp_tie_embed_packed_fwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_tie_embed_packed_bwd": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_stream_input_ws_floats": (c_int, [c_int]),
-    "mtmp_stream_input_fwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 3 + [c_float, c_float, c_uint, c_void_p, c_void_p]),
-    "mtmp_stream_input_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 3 + [c_float, c_uint, c_void_p, c_void_p]),
+    "mtmp_stream_input_fwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 3 + [c_float, c_float, c_uint, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtmp_stream_input_bwd": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 3 + [c_float, c_uint, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_head_ws_floats": (c_int, [c_int]),
     "mtmp_head_fwd": (c_int, [c_void_p] * 6 + [c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "mtmp_head_bwd": (c_int, [c_void_p] * 12 + [c_int, c_float, c_int, c_void_p]),
@@ -78,8 +80,8 @@ SIGNATURES = {
     "mtmp_swin_mlp": (c_int, [c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_longlong, c_int, c_float, c_void_p]),
     "mtmp_swin_stem_fwd": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "mtmp_adamw_step": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 5 + [c_int, c_float, c_void_p]),
-    "mtmp_bottleneck_exchange_fwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "mtmp_bottleneck_exchange_bwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "mtmp_bottleneck_exchange_fwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtmp_bottleneck_exchange_bwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_dropout_bwd": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_uint, c_void_p, c_float, c_void_p]),
 }
 

@@ -107,6 +107,8 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # forward() reads nothing of the encoder's result but the vital-sign stream's CLS row (reference :248), so the last
         # layer's image / text blocks are dead code on this path: the encoder neither runs them nor prepares their weights
         self.fusion_transformer.first_stream_output_only = True
+        # ... which also means no pad row of the vital-sign stream is ever read: the stream may run packed (--pack-rows)
+        self.fusion_transformer.pack_rows = bool(getattr(args, "pack_rows", 1))
         # ---- classifier (reference :147-158)
         classifier_dim = self.model_dim if self.args.vslt_type == "QIE" else self.model_dim * 2
         self.rmse_layer = nn.Linear(classifier_dim, 1, bias=True)

@@ -106,6 +106,23 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         fused_in = (n_pre == 0 and self.n_layers > 0 and enc_outputs[0].is_cuda and len(enc_outputs) == 3
                     and all(x.dtype == dt for x in enc_outputs))
         streams = []
+        if one_launch:
+            kv_plain, kv_fused = ops.stream_lengths([None if v is None else v.contiguous() for v in raw], self.bottlenecks_n,
+                                                    self.txt_idx)
+        else:
+            kv_plain = [None if l is None else l.to(torch.int32).contiguous() for l in lens]
+            kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
+        # PACKED vital-sign stream (``pack_rows``, set by a model that reads nothing of stream 0 but its CLS row): the samples'
+        # valid rows -- bottleneck prefix, CLS, real events -- are stored back to back, so every kernel of the fusion stack
+        # works on sum(kv_len) rows instead of B * (4 + 1 + T) (the reference pads to the batch maximum, trainer.py:41-42, and
+        # masks keys, utils.py:79-125; a pad row's output is never read and its gradient is zero).  Buffer sizes and launch
+        # grids stay those of the padded batch, so hipGraph replays are unaffected (ops.row_starts).
+        first_only_ = bool(getattr(self, "first_stream_output_only", False)) or self.vsltonly == 1
+        pack_v = None
+        if (getattr(self, "pack_rows", False) and fused_in and n_pre == 0 and first_only_ and kv_fused[0] is not None
+                and dt == torch.bfloat16 and ops.GROUPED_LAUNCHES and not return_attns):
+            pack_v = ops.row_starts(kv_fused[0], self.bottlenecks_n + 1 + enc_outputs[0].size(1))
+        self.last_pack = pack_v
         # the model may have produced the image / text embeddings on the two side streams (inputs_on_side_streams):
         # their stream-input kernels stay there, and the main stream joins before the fusion stack
         side_in = self._side_streams(dev) if (fused_in and getattr(self, "inputs_on_side_streams", False)) else None
@@ -116,8 +133,9 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
                 pe = self.positional_encoding(x.size(1) + 1) if self.use_pe[m] else None
                 seed = next_dropout_seed() if pdrop > 0 else 0
                 with (torch.cuda.stream(side_in[m - 1]) if (side_in is not None and m > 0) else contextlib.nullcontext()):
+                    pk = (pack_v, kv_fused[0]) if (m == 0 and pack_v is not None) else (None, None)
                     streams.append(ops.StreamInputFn.apply(x, self.cls_token_per_modality[m], ln.weight, ln.bias, pe,
-                                                           self.bottlenecks, ln.eps, pdrop, seed))
+                                                           self.bottlenecks, ln.eps, pdrop, seed, *pk))
                 continue
             x = torch.cat([self.cls_token_per_modality[m].expand(B, -1, -1).to(x.dtype), x], dim=1)
             y = F.layer_norm(x.float(), (self.d_model,), ln.weight, ln.bias, ln.eps)
@@ -126,12 +144,6 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             streams.append(self.dropout(y).to(dt))
         # (no join here when the inputs live on the side streams: ops.FusionStackFn issues each modality's first layer
         #  on that same stream and joins at the first bottleneck exchange)
-        if one_launch:
-            kv_plain, kv_fused = ops.stream_lengths([None if v is None else v.contiguous() for v in raw], self.bottlenecks_n,
-                                                    self.txt_idx)
-        else:
-            kv_plain = [None if l is None else l.to(torch.int32).contiguous() for l in lens]
-            kv_fused = [None if l is None else (l + self.bottlenecks_n).to(torch.int32).contiguous() for l in lens]
         missing = missing.to(dev).long()
         n_pre = min(max(self.fusion_idx, 0), self.n_layers)
         for li in range(n_pre):                                               # uni-modal layers (:734-737)
@@ -177,16 +189,18 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             cfg = dict(n_layers=len(seg), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
                        prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True, first_only=first_only and final,
                        missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev),
-                       inputs_on_side=side_in is not None and si == 0)
+                       inputs_on_side=side_in is not None and si == 0, pack_v=pack_v)
             out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(zs[0], zs[1], zs[2], self.bottlenecks, *params, cfg)
             zs = (out_v, out_i, out_t)
             if not final:
                 self.segment_boundaries.append(zs)
         nb = self.bottlenecks_n
         self.last_cls = cls_v               # = outs[0][:, 0, :] as its own autograd output (cheap backward)
+        # (a packed stream 0 has no [B, N] view: its reader takes ``last_cls``)
+        out_v = None if pack_v is not None else out_v[:, nb:]
         if self.vsltonly == 1:
-            return [out_v[:, nb:]], 0
-        return [out_v[:, nb:], out_i[:, nb:], out_t[:, nb:]], 0
+            return [out_v], 0
+        return [out_v, out_i[:, nb:], out_t[:, nb:]], 0
 
 
 class BimodalTransformerEncoder_MBT(nn.Module):

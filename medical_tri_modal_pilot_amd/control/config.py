@@ -132,6 +132,10 @@ _BUILD_FLAGS = [
     (("--graph-stages",), dict(type=int, default=0,
                                help="number of hipGraphs the captured step is cut into at fusion-layer boundaries "
                                     "(0 = auto: 3 under --ddp 1 so that the gradient all-reduce overlaps backward, else 1)")),
+    (("--pack-rows",), dict(type=int, default=1, choices=[0, 1],
+                            help="1: the vital-sign stream runs through the fusion layers PACKED -- its samples' valid rows "
+                                 "back to back, no pad rows -- whenever the bf16 kernels and the model allow it (results do "
+                                 "not depend on pad rows); 0: the reference's padded [B, T] layout")),
     (("--n-images",), dict(type=int, default=3, help="images per sample when --multiimages 1 (reference: 3)")),
     (("--synthetic",), dict(type=int, default=0, choices=[0, 1], help="train on synthetic batches (SURVEY.md §8d)")),
 ]

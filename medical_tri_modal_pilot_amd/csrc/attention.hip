@@ -36,6 +36,10 @@ template <typename T> struct AttnArgs {
     const float* knorm;      // [ceil(B N / 32)][H]: max ||k_h||_2 over each 32-row block of the [B N] token rows, or NULL
     int B, N, H, ld_qkv, ld_o;
     float scale;
+    // PACKED stream (NULL = the padded [B, N] layout): sample b's tokens are rows row_start[b] .. row_start[b] + kv_len[b] of the
+    // q / k / v / o / res buffers -- there are no pad rows, so kv_len[b] is also its query count.  N stays the stride of lse
+    // and sizes the grid (workgroups past a sample's rows return at once).
+    const int* row_start = nullptr;
 };
 
 // ---- LDS staging of a 64-row x 64-col tile by 256 threads, split into FETCH (global ->
@@ -160,11 +164,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const int row0 = p.row_start ? p.row_start[b] : b * p.N;     // first token row of sample b
+    const int Nq = p.row_start ? max(kvl, 0) : p.N;              // its query rows
+    if (qt * FWD_QWG >= Nq) return;                              // (packed stream; workgroup-uniform, before any barrier)
     // all keys masked -> the reference's masked_fill(-65504) + softmax gives the uniform average over all N
     // keys: run the ordinary loop with Q = 0 (every score 0, every p = 1).
     const bool uniform = kvl <= 0;
-    if (uniform) kvl = p.N;
-    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
+    if (uniform) kvl = Nq;
+    const size_t base = (size_t)row0 * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int q0w = qt * FWD_QWG + wave * FWD_QW;          // first query row of this wave
     Frag<T> qf[2][4];
@@ -173,8 +180,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
         const int qrow = q0w + 32 * qb + r;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            qf[qb][c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half),
-                                  qrow < p.N && !uniform);
+            qf[qb][c] = frag_keep(frag_load<T>(Qb + (size_t)min(qrow, Nq - 1) * p.ld_qkv + 16 * c + 8 * half),
+                                  qrow < Nq && !uniform);
     }
     const float c2 = p.scale * LOG2E;
     // ---- which body?  (wave-uniform)
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
             qs = fmaxf(qs, s);
         }
         qs = half_sum(qs) ;                                   // >= either row's ||q||^2 (the half-lanes hold half rows)
-        const int blk0 = (b * p.N) >> 5, blk1 = (b * p.N + p.N - 1) >> 5;
+        const int blk0 = row0 >> 5, blk1 = (row0 + Nq - 1) >> 5;
         float km = 0.f;
         for (int i = blk0 + lane; i <= blk1; i += 64) km = fmaxf(km, p.knorm[(size_t)i * p.H + hd]);
         km = wave_max(km);
@@ -408,15 +415,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
                           ov[4 * g + 2] * inv, ov[4 * g + 3] * inv);
             }
         const int qrow = q0w + 32 * qb + r;
-        if (qrow < p.N && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m[qb] + log2f(l[qb]);
+        if (qrow < Nq && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m[qb] + log2f(l[qb]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS, no barrier needed
     constexpr int CH = DH * (int)sizeof(T) / 16, RPP = 64 / CH;       // 16-byte chunks per row, rows per pass
 #pragma unroll
     for (int ps = 0; ps < FWD_QW / RPP; ++ps) {
         const int rl = ps * RPP + lane / CH, ch = lane % CH;
-        if (q0w + rl < p.N) {
-            const size_t off = ((size_t)b * p.N + q0w + rl) * p.ld_o + hd * DH + ch * (16 / (int)sizeof(T));
+        if (q0w + rl < Nq) {
+            const size_t off = ((size_t)row0 + q0w + rl) * p.ld_o + hd * DH + ch * (16 / (int)sizeof(T));
             const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sO + rl * LDT) + 16 * ch);
             *reinterpret_cast<u32x4_t*>(p.o + off) = ov;
             if (p.o_res) {
@@ -566,6 +573,7 @@ template <typename T> struct AttnBwdArgs {
     int B, N, H, ld_qkv, ld_do, ld_dqkv;
     float scale;
     const T* o; int ld_o;
+    const int* row_start = nullptr;    // packed stream, as in AttnArgs (lse / delta keep the [B, H, N] layout)
 };
 
 // Both backward kernels fold the row constants into the matrix pipe (cdna_hip_programming.md, 'Attention
@@ -594,36 +602,39 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const int row0 = p.row_start ? p.row_start[b] : b * p.N;     // (packed stream: AttnArgs::row_start)
+    const int Nq = p.row_start ? max(kvl, 0) : p.N;
+    if (qt * 128 >= Nq) return;
     const bool uniform = kvl <= 0;            // scores are constants -> dQ = 0
-    if (uniform) kvl = p.N;
-    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
+    if (uniform) kvl = Nq;
+    const size_t base = (size_t)row0 * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int qrow = qt * 128 + wave * 32 + r;
     const float c2 = p.scale * LOG2E;
     Frag<T> qf[4], dof[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        qf[c] = frag_keep(frag_scale<T>(frag_load<T>(Qb + (size_t)min(qrow, p.N - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
-                          qrow < p.N);
-        dof[c] = frag_keep(frag_load<T>(p.d_o + ((size_t)b * p.N + min(qrow, p.N - 1)) * p.ld_do + hd * DH + 16 * c + 8 * half),
-                           qrow < p.N);
+        qf[c] = frag_keep(frag_scale<T>(frag_load<T>(Qb + (size_t)min(qrow, Nq - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
+                          qrow < Nq);
+        dof[c] = frag_keep(frag_load<T>(p.d_o + ((size_t)row0 + min(qrow, Nq - 1)) * p.ld_do + hd * DH + 16 * c + 8 * half),
+                           qrow < Nq);
     }
-    const size_t sidx = ((size_t)b * p.H + hd) * p.N + min(qrow, p.N - 1);
+    const size_t sidx = ((size_t)b * p.H + hd) * p.N + min(qrow, Nq - 1);
     // delta[q] = sum_d dO[q,d] O[q,d] (the softmax backward's row constant) is computed here, from the dO fragments
     // this lane already holds and the matching O fragments, and handed to the dK/dV kernel through p.delta -- the
     // separate delta pass (one launch, 66 MB of traffic per call) is gone; the dQ kernel therefore runs FIRST.
     float dsum = 0.f;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const Frag<T> of = frag_load<T>(p.o + ((size_t)b * p.N + min(qrow, p.N - 1)) * p.ld_o + hd * DH + 16 * c + 8 * half);
+        const Frag<T> of = frag_load<T>(p.o + ((size_t)row0 + min(qrow, Nq - 1)) * p.ld_o + hd * DH + 16 * c + 8 * half);
 #pragma unroll
         for (int jx = 0; jx < 8; ++jx) dsum = fmaf(to_f32(dof[c].v[jx]), to_f32(of.v[jx]), dsum);
     }
     dsum = half_sum(dsum);                                 // the two half-lanes hold the two halves of the row
-    if (qrow < p.N && half == 0) p.delta[sidx] = dsum;
+    if (qrow < Nq && half == 0) p.delta[sidx] = dsum;
     // rows past N: -LSE = -inf makes p = 0 whatever the (zero) fragments give
-    const float nL = (qrow < p.N) ? -p.lse[sidx] : -INFINITY;
-    const float nD = (qrow < p.N) ? -dsum : 0.f;
+    const float nL = (qrow < Nq) ? -p.lse[sidx] : -INFINITY;
+    const float nD = (qrow < Nq) ? -dsum : 0.f;
     f32x16 cL, cD;                            // the row constants in every register: C operands
 #pragma unroll
     for (int t = 0; t < 16; ++t) { cL[t] = nL; cD[t] = nD; }
@@ -718,8 +729,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     };
     for (int it = 0; it < min(nfull, ntiles); ++it) body(it, std::false_type{});
     if (ntiles > nfull) body(nfull, std::true_type{});
-    if (qrow < p.N) {
-        const size_t orow = ((size_t)b * p.N + qrow) * p.ld_dqkv + hd * DH;
+    if (qrow < Nq) {
+        const size_t orow = ((size_t)row0 + qrow) * p.ld_dqkv + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -751,11 +762,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const int row0 = p.row_start ? p.row_start[b] : b * p.N;     // (packed stream: AttnArgs::row_start)
+    const int Nq = p.row_start ? max(kvl, 0) : p.N;              // rows of this sample: its queries, and the keys that get a gradient row
+    if (kt * 128 >= Nq) return;
     const bool uniform = kvl <= 0;            // forward = uniform average: p = 1/N (K = 0 below), dS = 0
-    if (uniform) kvl = p.N;
-    const size_t base = (size_t)b * p.N * p.ld_qkv + hd * DH;
+    if (uniform) kvl = Nq;
+    const size_t base = (size_t)row0 * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
-    const T* dOb = p.d_o + (size_t)b * p.N * p.ld_do + hd * DH;
+    const T* dOb = p.d_o + (size_t)row0 * p.ld_do + hd * DH;
     const float* Lb = p.lse + ((size_t)b * p.H + hd) * p.N;
     const float* Db = p.delta + ((size_t)b * p.H + hd) * p.N;
     const int kw0 = kt * 128 + wave * 32;      // first key of this wave
@@ -770,10 +784,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
                               key < kvl && !uniform);
             vf[c] = frag_keep(frag_load<T>(Vb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half), key < kvl);
         }
-        const int nq = (p.N + KT - 1) / KT;
+        const int nq = (Nq + KT - 1) / KT;
         TileStream<T> qs, os;
-        qs.init(Qb, p.ld_qkv, p.N, tid);
-        os.init(dOb, p.ld_do, p.N, tid);
+        qs.init(Qb, p.ld_qkv, Nq, tid);
+        os.init(dOb, p.ld_do, Nq, tid);
         TileR<T> qreg, oreg;
         // lse / delta of the tile's 64 query rows ride along in wave 0.  The loads are unconditional (clamped
         // address) and their values are not touched before the put: a guarded load, or any arithmetic on the
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
         auto fetch = [&](int t) {
             qreg = qs.fetch(t);
             oreg = os.fetch(t);
-            const int qn = min(t * KT + lrow, p.N - 1);
+            const int qn = min(t * KT + lrow, Nq - 1);
             lreg = Lb[qn];
             dreg = Db[qn];
         };
@@ -794,8 +808,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
             DT::put(st_ + DT::BYTES, oreg, tid);
             if (tid < KT) {                    // C operands of the score products: -lse (-inf past N), -delta
                 float* sL = reinterpret_cast<float*>(st_ + 2 * DT::BYTES);
-                sL[tid] = (t * KT + tid < p.N) ? -lreg : -INFINITY;
-                sL[KT + tid] = (t * KT + tid < p.N) ? -dreg : 0.f;
+                sL[tid] = (t * KT + tid < Nq) ? -lreg : -INFINITY;
+                sL[KT + tid] = (t * KT + tid < Nq) ? -dreg : 0.f;
             }
         };
         fetch(0);
@@ -923,12 +937,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     }
     // rows = keys (registers), cols = dh (lanes); keys past kv_len (and the whole dK of a fully masked
     // sample) are written as zeros
-    const size_t obase = (size_t)b * p.N * p.ld_dqkv + hd * DH;
+    const size_t obase = (size_t)row0 * p.ld_dqkv + hd * DH;
     const float kscale = uniform ? 0.f : p.scale;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int krow = kw0 + acc_row(t, half);
-        if (krow < p.N) {
+        if (krow < Nq) {
             const bool live = krow < kvl;
             T* dkp = p.dk + obase + (size_t)krow * p.ld_dqkv;
             T* dvp = p.dv + obase + (size_t)krow * p.ld_dqkv;
@@ -998,32 +1012,36 @@ bool attn_shape_ok(int B, int N, int H, int ld_a, int ld_b) {
 
 template <typename T>
 int fwd_entry(int n, const void* const* q, const void* const* k, const void* const* v, void* const* o, const void* const* res,
-              void* const* o_res, float* const* lse, const int32_t* const* kv_len, const float* const* key_norms, const int* N,
-              const int* ld_qkv, const int* ld_o, int B, int H, float scale, hipStream_t st) {
+              void* const* o_res, float* const* lse, const int32_t* const* kv_len, const int32_t* const* row_start,
+              const float* const* key_norms, const int* N, const int* ld_qkv, const int* ld_o, int B, int H, float scale,
+              hipStream_t st) {
     AttnArgs<T> a[GRP_MAX];
     for (int i = 0; i < n; ++i)
         a[i] = AttnArgs<T>{(const T*)q[i], (const T*)k[i], (const T*)v[i], (T*)o[i], res ? (const T*)res[i] : nullptr,
                            o_res ? (T*)o_res[i] : nullptr, lse[i], kv_len ? kv_len[i] : nullptr, key_norms ? key_norms[i] : nullptr,
-                           B, N[i], H, ld_qkv[i], ld_o[i], scale};
+                           B, N[i], H, ld_qkv[i], ld_o[i], scale, row_start ? row_start[i] : nullptr};
     return launch_fwd<T>(n, a, st);
 }
 
-// n <= 3 streams in ONE launch (all arrays are HOST arrays of n entries; res / o_res / kv_len / key_norms may be NULL as a
-// whole or per entry).  mtmp_attn_fwd is the n = 1 form.
+// n <= 3 streams in ONE launch (all arrays are HOST arrays of n entries; res / o_res / kv_len / row_start / key_norms may be NULL
+// as a whole or per entry).  mtmp_attn_fwd is the n = 1 form.  row_start[i] != NULL: stream i is PACKED -- int32[B] device, sample
+// b's kv_len[i][b] tokens are rows row_start[i][b] .. of the q / k / v / o / res buffers (mtmp_row_starts; AttnArgs::row_start),
+// N[i] is the longest sample the buffers and lse were sized for.
 extern "C" int mtmp_attn_fwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v,
                                      void* const* o, const void* const* res, void* const* o_res, float* const* lse,
-                                     const int32_t* const* kv_len, const float* const* key_norms, const int* N, const int* ld_qkv,
-                                     const int* ld_o, int B, int H, float scale, void* stream) {
+                                     const int32_t* const* kv_len, const int32_t* const* row_start, const float* const* key_norms,
+                                     const int* N, const int* ld_qkv, const int* ld_o, int B, int H, float scale, void* stream) {
     MTMP_CHECK_ARG(n >= 1 && n <= GRP_MAX && q && k && v && o && lse && N && ld_qkv && ld_o, "mtmp_attn_fwd: bad group (n=%d)", n);
     for (int i = 0; i < n; ++i) {
         MTMP_CHECK_ARG(q[i] && k[i] && v[i] && o[i] && lse[i], "mtmp_attn_fwd: null pointer (stream %d)", i);
         MTMP_CHECK_ARG((!res || !res[i]) == (!o_res || !o_res[i]), "mtmp_attn_fwd: res and o_res must be given together");
+        MTMP_CHECK_ARG(!(row_start && row_start[i]) || (kv_len && kv_len[i]), "mtmp_attn_fwd: a packed stream needs kv_len");
         MTMP_CHECK_ARG(attn_shape_ok(B, N[i], H, ld_qkv[i], ld_o[i]), "mtmp_attn_fwd: bad shape B=%d N=%d H=%d ld=%d/%d", B, N[i], H,
                        ld_qkv[i], ld_o[i]);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) return fwd_entry<float>(n, q, k, v, o, res, o_res, lse, kv_len, key_norms, N, ld_qkv, ld_o, B, H, scale, st);
-    if (dtype == 1) return fwd_entry<bf16>(n, q, k, v, o, res, o_res, lse, kv_len, key_norms, N, ld_qkv, ld_o, B, H, scale, st);
+    if (dtype == 0) return fwd_entry<float>(n, q, k, v, o, res, o_res, lse, kv_len, row_start, key_norms, N, ld_qkv, ld_o, B, H, scale, st);
+    if (dtype == 1) return fwd_entry<bf16>(n, q, k, v, o, res, o_res, lse, kv_len, row_start, key_norms, N, ld_qkv, ld_o, B, H, scale, st);
     mtmp_set_error("mtmp_attn_fwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
@@ -1031,41 +1049,42 @@ extern "C" int mtmp_attn_fwd_grouped(int dtype, int n, const void* const* q, con
 extern "C" int mtmp_attn_fwd(int dtype, const void* q, const void* k, const void* v, void* o, const void* res,
                              void* o_res, float* lse, const int32_t* kv_len, const float* key_norms, int B, int N, int H,
                              int ld_qkv, int ld_o, float scale, void* stream) {
-    return mtmp_attn_fwd_grouped(dtype, 1, &q, &k, &v, &o, &res, &o_res, &lse, &kv_len, &key_norms, &N, &ld_qkv, &ld_o, B, H, scale,
-                                 stream);
+    return mtmp_attn_fwd_grouped(dtype, 1, &q, &k, &v, &o, &res, &o_res, &lse, &kv_len, nullptr, &key_norms, &N, &ld_qkv, &ld_o, B, H,
+                                 scale, stream);
 }
 
 template <typename T>
 int bwd_entry(int n, const void* const* q, const void* const* k, const void* const* v, const void* const* o, const void* const* d_o,
-              const float* const* lse, const int32_t* const* kv_len, void* const* dq, void* const* dk, void* const* dv,
-              float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o, const int* ld_do, const int* ld_dqkv, int B,
-              int H, float scale, hipStream_t st) {
+              const float* const* lse, const int32_t* const* kv_len, const int32_t* const* row_start, void* const* dq,
+              void* const* dk, void* const* dv, float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o,
+              const int* ld_do, const int* ld_dqkv, int B, int H, float scale, hipStream_t st) {
     AttnBwdArgs<T> a[GRP_MAX];
     for (int i = 0; i < n; ++i)
         a[i] = AttnBwdArgs<T>{(const T*)q[i], (const T*)k[i], (const T*)v[i], (const T*)d_o[i], lse[i], delta_ws[i],
                               kv_len ? kv_len[i] : nullptr, (T*)dq[i], (T*)dk[i], (T*)dv[i], B, N[i], H, ld_qkv[i], ld_do[i],
-                              ld_dqkv[i], scale, (const T*)o[i], ld_o[i]};
+                              ld_dqkv[i], scale, (const T*)o[i], ld_o[i], row_start ? row_start[i] : nullptr};
     return launch_bwd<T>(n, a, st);
 }
 
 extern "C" int mtmp_attn_bwd_grouped(int dtype, int n, const void* const* q, const void* const* k, const void* const* v,
                                      const void* const* o, const void* const* d_o, const float* const* lse,
-                                     const int32_t* const* kv_len, void* const* dq, void* const* dk, void* const* dv,
-                                     float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o, const int* ld_do,
-                                     const int* ld_dqkv, int B, int H, float scale, void* stream) {
+                                     const int32_t* const* kv_len, const int32_t* const* row_start, void* const* dq,
+                                     void* const* dk, void* const* dv, float* const* delta_ws, const int* N, const int* ld_qkv,
+                                     const int* ld_o, const int* ld_do, const int* ld_dqkv, int B, int H, float scale, void* stream) {
     MTMP_CHECK_ARG(n >= 1 && n <= GRP_MAX && q && k && v && o && d_o && lse && dq && dk && dv && delta_ws && N && ld_qkv && ld_o &&
                        ld_do && ld_dqkv, "mtmp_attn_bwd: bad group (n=%d)", n);
     for (int i = 0; i < n; ++i) {
         MTMP_CHECK_ARG(q[i] && k[i] && v[i] && o[i] && d_o[i] && lse[i] && dq[i] && dk[i] && dv[i] && delta_ws[i],
                        "mtmp_attn_bwd: null pointer (stream %d)", i);
+        MTMP_CHECK_ARG(!(row_start && row_start[i]) || (kv_len && kv_len[i]), "mtmp_attn_bwd: a packed stream needs kv_len");
         MTMP_CHECK_ARG(attn_shape_ok(B, N[i], H, ld_qkv[i], ld_o[i]) && attn_shape_ok(B, N[i], H, ld_do[i], ld_dqkv[i]),
                        "mtmp_attn_bwd: bad shape B=%d N=%d H=%d", B, N[i], H);
     }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        return bwd_entry<float>(n, q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, N, ld_qkv, ld_o, ld_do, ld_dqkv, B, H, scale, st);
+        return bwd_entry<float>(n, q, k, v, o, d_o, lse, kv_len, row_start, dq, dk, dv, delta_ws, N, ld_qkv, ld_o, ld_do, ld_dqkv, B, H, scale, st);
     if (dtype == 1)
-        return bwd_entry<bf16>(n, q, k, v, o, d_o, lse, kv_len, dq, dk, dv, delta_ws, N, ld_qkv, ld_o, ld_do, ld_dqkv, B, H, scale, st);
+        return bwd_entry<bf16>(n, q, k, v, o, d_o, lse, kv_len, row_start, dq, dk, dv, delta_ws, N, ld_qkv, ld_o, ld_do, ld_dqkv, B, H, scale, st);
     mtmp_set_error("mtmp_attn_bwd: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
@@ -1074,8 +1093,8 @@ extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void
                              const float* lse, const int32_t* kv_len, void* dq, void* dk, void* dv, float* delta_ws,
                              int B, int N, int H, int ld_qkv, int ld_o, int ld_do, int ld_dqkv, float scale,
                              void* stream) {
-    return mtmp_attn_bwd_grouped(dtype, 1, &q, &k, &v, &o, &d_o, &lse, &kv_len, &dq, &dk, &dv, &delta_ws, &N, &ld_qkv, &ld_o, &ld_do,
-                                 &ld_dqkv, B, H, scale, stream);
+    return mtmp_attn_bwd_grouped(dtype, 1, &q, &k, &v, &o, &d_o, &lse, &kv_len, nullptr, &dq, &dk, &dv, &delta_ws, &N, &ld_qkv, &ld_o,
+                                 &ld_do, &ld_dqkv, B, H, scale, stream);
 }
 
 extern "C" long long mtmp_key_norms_floats(long long rows, int H) { return ((rows + 31) / 32) * H; }

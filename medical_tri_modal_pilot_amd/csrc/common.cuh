@@ -283,6 +283,11 @@ MTMP_DEV void flush_partials(float (&acc)[NV][4], float* slab_row, float* lds, i
         slab_row[i] = lds[i] + lds[NV * 256 + i] + lds[2 * NV * 256 + i] + lds[3 * NV * 256 + i];
 }
 
+// Row count of a launch on the PACKED vital-sign stream (ops.FusionStackFn, cfg["row_start"]): buffers and grids are sized for the
+// padded maximum M -- static, so a captured hipGraph replays -- and the rows in use this step are read from device memory
+// (mtmp_row_starts writes them); workgroups whose first row lies past them return at once.
+MTMP_DEV int live_rows(int M, const int* m_live) { return m_live ? min(M, *m_live) : M; }
+
 constexpr int RED_GROUPS = 64;            // most row groups of the first level of launch_slab_reduce (sizes its ws tail)
 // two-level column sum [rows][cols] -> out[cols] (elementwise.hip); ws_tail: RED_GROUPS * cols floats
 void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_tail, float* out, hipStream_t st);

@@ -116,7 +116,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const float* cls, const float* gamma,
                                                             const float* beta, const float* pe, const float* bott, T* out,
                                                             float* stats, int B, int N, int nb, float eps, float p,
-                                                            unsigned seed0, const unsigned* seed_dev) {
+                                                            unsigned seed0, const unsigned* seed_dev, const int* row_start,
+                                                            const int* kv_len) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = nb + 1 + N;
     const f32x4 gm = ld4f(gamma + 4 * lane), be = ld4f(beta + 4 * lane);
@@ -125,7 +126,12 @@ __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const fl
     const float sc = 1.0f / (1.0f - p);
     for (int row = blockIdx.x * 4 + wave; row < B * R; row += gridDim.x * 4) {
         const int b = row / R, r = row - b * R;
-        T* o = out + (size_t)row * D + 4 * lane;
+        size_t orow = (size_t)row;
+        if (row_start) {                                                       // packed output: sample b's kv_len[b] rows start at row_start[b]
+            if (r >= kv_len[b]) continue;                                      // (a pad row does not exist there; wave-uniform)
+            orow = (size_t)row_start[b] + r;
+        }
+        T* o = out + orow * D + 4 * lane;
         if (r < nb) {                                                          // wave-uniform
             const f32x4 v = ld4f(bott + r * D + 4 * lane);
             store4<T>(o, v[0], v[1], v[2], v[3]);
@@ -167,7 +173,8 @@ __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const fl
 template <typename T>
 __global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T* x, const float* cls, const float* gamma,
                                                             const float* stats, T* dx, float* slab, int B, int N, int nb,
-                                                            float p, unsigned seed0, const unsigned* seed_dev) {
+                                                            float p, unsigned seed0, const unsigned* seed_dev,
+                                                            const int* row_start, const int* kv_len) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 7 * D];              // 28 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = nb + 1 + N;
@@ -182,7 +189,15 @@ __global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T
         for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
     for (int row = blockIdx.x * 4 + wave; row < B * R; row += gridDim.x * 4) {
         const int b = row / R, r = row - b * R;
-        f32x4 g = load4<T>(dz + (size_t)row * D + 4 * lane);
+        size_t grow = (size_t)row;
+        if (row_start) {                                                       // packed gradient rows (see the forward)
+            if (r >= kv_len[b]) {                                              // a pad row of the padded input x: zero gradient
+                if (r > nb) store4<T>(dx + ((size_t)b * N + r - nb - 1) * D + 4 * lane, 0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
+            grow = (size_t)row_start[b] + r;
+        }
+        f32x4 g = load4<T>(dz + grow * D + 4 * lane);
         if (r < nb) {                                                          // wave-uniform
 #pragma unroll
             for (int k = 0; k < NB_MAX; ++k)
@@ -511,41 +526,46 @@ extern "C" int mtmp_stream_input_ws_floats(int rows) { return (max(1, min((rows 
 
 // z [B, nb+1+N, 256] (dtype) from x [B, N, 256] (dtype); cls, gamma, beta [256], pe [>= N+1][256] or NULL,
 // bott [nb][256] fp32; stats float[B*(N+1)][2] (mean, 1/sqrt(var+eps)) kept for the backward.
+// row_start != NULL (with kv_len, both int32 device, mtmp_row_starts): PACKED output -- rows r < kv_len[b] of sample b go to
+// rows row_start[b] + r of `out` (same allocation), the others are not written.
 extern "C" int mtmp_stream_input_fwd(int dtype, const void* x, const float* cls, const float* gamma, const float* beta,
                                      const float* pe, const float* bott, void* out, float* stats, int B, int N, int nb,
-                                     float eps, float p, unsigned seed, const unsigned* seed_dev, void* stream) {
+                                     float eps, float p, unsigned seed, const unsigned* seed_dev, const int32_t* row_start,
+                                     const int32_t* kv_len, void* stream) {
     MTMP_CHECK_ARG(x && cls && gamma && beta && out && stats && B > 0 && N > 0 && nb >= 0 && nb <= NB_MAX && (nb == 0 || bott) &&
-                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25),
+                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25) && (!row_start || kv_len),
                    "mtmp_stream_input_fwd: bad argument (B=%d N=%d nb=%d p=%f)", B, N, nb, p);
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * (nb + 1 + N), nbk = max(1, min((rows + 3) / 4, 2048));
     if (dtype == 0)
         hipLaunchKernelGGL(stream_in_fwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)x, cls, gamma, beta, pe,
-                           bott, (float*)out, stats, B, N, nb, eps, p, seed, seed_dev);
+                           bott, (float*)out, stats, B, N, nb, eps, p, seed, seed_dev, row_start, kv_len);
     else if (dtype == 1)
         hipLaunchKernelGGL(stream_in_fwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)x, cls, gamma, beta, pe,
-                           bott, (bf16*)out, stats, B, N, nb, eps, p, seed, seed_dev);
+                           bott, (bf16*)out, stats, B, N, nb, eps, p, seed, seed_dev, row_start, kv_len);
     else { mtmp_set_error("mtmp_stream_input_fwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_stream_input_fwd");
     return MTMP_OK;
 }
 
 // dx [B, N, 256] (dtype); grads float[7][256] = dgamma, dbeta, dcls, dbott[0..3] (rows past nb are zero),
-// overwritten; ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats.
+// overwritten; ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats.  row_start / kv_len: dz is PACKED as the forward's output
+// was; dx stays padded (its pad rows are written as zeros).
 extern "C" int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float* cls, const float* gamma,
                                      const float* stats, void* dx, float* grads, float* ws, int B, int N, int nb, float p,
-                                     unsigned seed, const unsigned* seed_dev, void* stream) {
+                                     unsigned seed, const unsigned* seed_dev, const int32_t* row_start, const int32_t* kv_len,
+                                     void* stream) {
     MTMP_CHECK_ARG(dz && x && cls && gamma && stats && dx && grads && ws && B > 0 && N > 0 && nb >= 0 && nb <= NB_MAX &&
-                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25),
+                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25) && (!row_start || kv_len),
                    "mtmp_stream_input_bwd: bad argument (B=%d N=%d nb=%d p=%f)", B, N, nb, p);
     hipStream_t st = (hipStream_t)stream;
     const int rows = B * (nb + 1 + N), nbk = max(1, min((rows + 15) / 16, 1024));
     if (dtype == 0)
         hipLaunchKernelGGL(stream_in_bwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)dz, (const float*)x, cls,
-                           gamma, stats, (float*)dx, ws, B, N, nb, p, seed, seed_dev);
+                           gamma, stats, (float*)dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len);
     else if (dtype == 1)
         hipLaunchKernelGGL(stream_in_bwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)dz, (const bf16*)x, cls,
-                           gamma, stats, (bf16*)dx, ws, B, N, nb, p, seed, seed_dev);
+                           gamma, stats, (bf16*)dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len);
     else { mtmp_set_error("mtmp_stream_input_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_stream_input_bwd");
     launch_slab_reduce(ws, nbk, 7 * D, ws + (size_t)nbk * 7 * D, grads, st);
@@ -590,7 +610,12 @@ template <typename T> struct ExchangeArgs {
     const float* d_prev_in;   // backward: gradient flowing into this exchange's output through the next residual, or null
     float* d_prev_out;        // backward: gradient for the previous exchange's output (resbottle), or null
     int resbottle;
+    const int* row_start0;    // stream 0 PACKED: its sample b starts at row row_start0[b] (else null: b * bstride[0])
 };
+
+template <typename T> MTMP_DEV size_t exchange_base(const ExchangeArgs<T>& p, int m, int b) {
+    return (m == 0 && p.row_start0) ? (size_t)p.row_start0[b] * 256 : (size_t)b * (size_t)p.bstride[m];
+}
 
 template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel(ExchangeArgs<T> p) {
     const int b = blockIdx.x >> 2, r = blockIdx.x & 3, f = threadIdx.x;
@@ -598,7 +623,7 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel
     // caller that skipped the check still cannot read outside the table
     const long long pat = min(max(p.missing[b], 0LL), 3LL);
     const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
-    float v = __fmul_rn(to_f32(p.z[0][b * p.bstride[0] + o]), kExchangeW[pat][0]);
+    float v = __fmul_rn(to_f32(p.z[0][exchange_base(p, 0, b) + o]), kExchangeW[pat][0]);
     v = __fadd_rn(v, __fmul_rn(to_f32(p.z[1][b * p.bstride[1] + o]), kExchangeW[pat][1]));
     // two-stream encoder (BimodalTransformerEncoder_MBT, mbt_encoder.py:629-632): z[2] is NULL and the caller maps its
     // patterns {0: mean of both, 1: stream 0} onto rows {1, 3} of the table, whose third weight is 0
@@ -608,7 +633,7 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_fwd_kernel
     const T t = from_f32<T>(v);
 #pragma unroll
     for (int m = 0; m < 3; ++m)
-        if (p.z[m]) p.z[m][b * p.bstride[m] + o] = t;
+        if (p.z[m]) p.z[m][exchange_base(p, m, b) + o] = t;
 }
 
 // z[m] hold dL/d(input of the next layer): rows 0..3 are the gradients w.r.t. the exchanged tokens as seen by
@@ -618,7 +643,7 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_bwd_kernel
     const int b = blockIdx.x >> 2, r = blockIdx.x & 3, f = threadIdx.x;
     const long long pat = min(max(p.missing[b], 0LL), 3LL);
     const size_t o = (size_t)r * 256 + f, ko = ((size_t)b * 4 + r) * 256 + f;
-    float d = to_f32(p.z[0][b * p.bstride[0] + o]);
+    float d = to_f32(p.z[0][exchange_base(p, 0, b) + o]);
     d = __fadd_rn(d, to_f32(p.z[1][b * p.bstride[1] + o]));
     if (p.z[2]) d = __fadd_rn(d, to_f32(p.z[2][b * p.bstride[2] + o]));
     if (p.d_prev_in) d = __fadd_rn(d, p.d_prev_in[ko]);
@@ -628,26 +653,27 @@ template <typename T> __global__ __launch_bounds__(256) void exchange_bwd_kernel
     }
 #pragma unroll
     for (int m = 0; m < 3; ++m)
-        if (p.z[m]) p.z[m][b * p.bstride[m] + o] = from_f32<T>(__fmul_rn(d, kExchangeW[pat][m]));
+        if (p.z[m]) p.z[m][exchange_base(p, m, b) + o] = from_f32<T>(__fmul_rn(d, kExchangeW[pat][m]));
 }
 
 }  // namespace
 
 // In-place bottleneck exchange over the three stream buffers z_m [B, n_m, 256] (n_m = 4 + tokens, rows 0..3 =
 // bottleneck tokens).  missing: int64[B] in 0..3.  resbottle != 0: new = (mean + prev) / 2 with prev [B,4,256]
-// fp32.  keep (optional) receives the fp32 result.  Replaces mbt_encoder.py:764-779.
+// fp32.  keep (optional) receives the fp32 result.  Replaces mbt_encoder.py:764-779.  row_start_v (int32[B] device, may be NULL): the
+// first buffer is PACKED -- its sample b starts at row row_start_v[b] instead of b * n_v (mtmp_row_starts).
 extern "C" int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, void* z_t, int B, int n_v, int n_i, int n_t,
                                             const long long* missing, int resbottle, const float* prev, float* keep,
-                                            void* stream) {
+                                            const int32_t* row_start_v, void* stream) {
     MTMP_CHECK_ARG(z_v && z_i && missing && B > 0 && n_v >= 4 && n_i >= 4 && (!z_t || n_t >= 4) && (!resbottle || prev),
                    "mtmp_bottleneck_exchange_fwd: bad argument (B=%d rows %d/%d/%d)", B, n_v, n_i, n_t);
     if (dtype == 0) {
         ExchangeArgs<float> a{{(float*)z_v, (float*)z_i, (float*)z_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
-                              missing, prev, keep, nullptr, nullptr, resbottle};
+                              missing, prev, keep, nullptr, nullptr, resbottle, row_start_v};
         hipLaunchKernelGGL(exchange_fwd_kernel<float>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
     } else if (dtype == 1) {
         ExchangeArgs<bf16> a{{(bf16*)z_v, (bf16*)z_i, (bf16*)z_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
-                             missing, prev, keep, nullptr, nullptr, resbottle};
+                             missing, prev, keep, nullptr, nullptr, resbottle, row_start_v};
         hipLaunchKernelGGL(exchange_fwd_kernel<bf16>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         mtmp_set_error("mtmp_bottleneck_exchange_fwd: unknown dtype %d", dtype);
@@ -661,16 +687,16 @@ extern "C" int mtmp_bottleneck_exchange_fwd(int dtype, void* z_v, void* z_i, voi
 // exchange_bwd_kernel.  d_prev_in / d_prev_out: [B,4,256] fp32, used with resbottle (d_prev_in may be null).
 extern "C" int mtmp_bottleneck_exchange_bwd(int dtype, void* dz_v, void* dz_i, void* dz_t, int B, int n_v, int n_i, int n_t,
                                             const long long* missing, int resbottle, const float* d_prev_in,
-                                            float* d_prev_out, void* stream) {
+                                            float* d_prev_out, const int32_t* row_start_v, void* stream) {
     MTMP_CHECK_ARG(dz_v && dz_i && missing && B > 0 && n_v >= 4 && n_i >= 4 && (!dz_t || n_t >= 4) && (!resbottle || d_prev_out),
                    "mtmp_bottleneck_exchange_bwd: bad argument (B=%d rows %d/%d/%d)", B, n_v, n_i, n_t);
     if (dtype == 0) {
         ExchangeArgs<float> a{{(float*)dz_v, (float*)dz_i, (float*)dz_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
-                              missing, nullptr, nullptr, d_prev_in, d_prev_out, resbottle};
+                              missing, nullptr, nullptr, d_prev_in, d_prev_out, resbottle, row_start_v};
         hipLaunchKernelGGL(exchange_bwd_kernel<float>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
     } else if (dtype == 1) {
         ExchangeArgs<bf16> a{{(bf16*)dz_v, (bf16*)dz_i, (bf16*)dz_t}, {(long long)n_v * D, (long long)n_i * D, (long long)n_t * D},
-                             missing, nullptr, nullptr, d_prev_in, d_prev_out, resbottle};
+                             missing, nullptr, nullptr, d_prev_in, d_prev_out, resbottle, row_start_v};
         hipLaunchKernelGGL(exchange_bwd_kernel<bf16>, dim3(B * 4), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         mtmp_set_error("mtmp_bottleneck_exchange_bwd: unknown dtype %d", dtype);
@@ -814,6 +840,37 @@ extern "C" int mtmp_stream_lengths(const long long* len_v, const long long* len_
     hipLaunchKernelGGL(stream_lengths_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, len_v, len_i, len_t, out, B,
                        n_bott, txt_idx);
     MTMP_CHECK_LAUNCH("mtmp_stream_lengths");
+    return MTMP_OK;
+}
+
+// Row map of a PACKED token stream: out[b] = sum of min(max(kv_len[0..b), 0), n_max) -- sample b's first row when the samples'
+// kv_len[b] valid rows (bottleneck prefix + CLS + events) are stored back to back with no pad rows in between -- and out[B] =
+// the rows in use.  That last word is what the row-panel / weight-gradient kernels take as `rows_live`; the buffers and
+// the launch grids keep the padded size B * n_max, so a captured hipGraph replays whatever the lengths are.
+__global__ __launch_bounds__(256) void row_starts_kernel(const int* kv_len, int* out, int B, int n_max) {
+    __shared__ int s[256];
+    int carry = 0;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int b = b0 + (int)threadIdx.x;
+        const int v = b < B ? min(max(kv_len[b], 0), n_max) : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int t = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (b < B) out[b] = carry + s[threadIdx.x] - v;
+        carry += s[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[B] = carry;
+}
+extern "C" int mtmp_row_starts(const int32_t* kv_len, int32_t* out, int B, int n_max, void* stream) {
+    MTMP_CHECK_ARG(kv_len && out && B > 0 && n_max > 0 && (long long)B * n_max < (1ll << 31), "mtmp_row_starts: bad argument (B=%d n_max=%d)", B, n_max);
+    hipLaunchKernelGGL(row_starts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kv_len, out, B, n_max);
+    MTMP_CHECK_LAUNCH("mtmp_row_starts");
     return MTMP_OK;
 }
 

@@ -44,6 +44,7 @@ template <typename T> struct GemmArgs {
     int rows_per_scale;
     unsigned short* signs = nullptr;   // row-panel kernels (bf16): 1 bit per output, "y > 0" -- written by the forward, read as the gate
     float* knorm = nullptr;            // Q/K/V projection (N = 768): [ceil(M / 32)][4] max ||k_h|| per 32-row block (attention.hip, AttnArgs::knorm)
+    const int* m_live = nullptr;       // packed stream: device word holding the rows in use (<= M); common.cuh live_rows
 };
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread).  The loads are
@@ -101,7 +102,7 @@ template <int TM> struct NtGeom {
 };
 
 template <typename T, bool RELU, int TM, bool DROP>
-MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], const GemmArgs<T>& p, T* sOut, int m0, int n0, int tid) {
+MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], const GemmArgs<T>& p, const int M, T* sOut, int m0, int n0, int tid) {
     using G = NtGeom<TM>;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     const int wr = wave % G::WR, foff = (wave / G::WR) * 32 * G::NT;
@@ -116,16 +117,16 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], cons
     if (p.gate) {
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps)
-            gv[ps] = frag_load<T>(p.gate + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.N + gcolc);
+            gv[ps] = frag_load<T>(p.gate + (size_t)min(m0 + (tid >> 4) + 16 * ps, M - 1) * p.N + gcolc);
     }
     if (p.res) {
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps)
-            rv[ps] = frag_load<T>(p.res + (size_t)min(m0 + (tid >> 4) + 16 * ps, p.M - 1) * p.ldr + gcolc);
+            rv[ps] = frag_load<T>(p.res + (size_t)min(m0 + (tid >> 4) + 16 * ps, M - 1) * p.ldr + gcolc);
     }
 #pragma unroll
     for (int rt = 0; rt < G::RT; ++rt) {
-        const int rl = 32 * (G::RT * wr + rt) + r, row = min(m0 + rl, p.M - 1);
+        const int rl = 32 * (G::RT * wr + rt) + r, row = min(m0 + rl, M - 1);
 #pragma unroll
         for (int nt = 0; nt < G::NT; ++nt) {
             if (n0 + foff + 32 * nt >= p.N) continue;
@@ -159,7 +160,7 @@ MTMP_DEV void epilogue(const f32x16 (&acc)[NtGeom<TM>::RT][NtGeom<TM>::NT], cons
     if (gcol < p.N) {
 #pragma unroll
         for (int ps = 0; ps < PS; ++ps) {
-            const int rl = (tid >> 4) + 16 * ps, grow = min(m0 + rl, p.M - 1);
+            const int rl = (tid >> 4) + 16 * ps, grow = min(m0 + rl, M - 1);
             Frag<T> o = frag_load<T>(sOut + rl * LDO + c8);
             if (p.gate || p.row_scale || p.res) {
                 float v[8];
@@ -444,9 +445,10 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf
     const int npanels = p.N / P::NP;
     const int per = (npanels + gridDim.y - 1) / gridDim.y;
     const int j0 = blockIdx.y * per, j1 = min(npanels, j0 + per);
-    if (j0 >= j1) return;
+    const int M = live_rows(p.M, p.m_live);
+    if (j0 >= j1 || bx * BM >= M) return;     // (packed stream: row blocks past the rows in use)
     const int m_wave = bx * BM + wave * 32;
-    const int row = min(m_wave + r, p.M - 1);
+    const int row = min(m_wave + r, M - 1);
     // DMA slot of this lane: piece i of wave w fills LDS bytes [1024 (ND w + i), +1024) of the panel image, i.e. 16-byte slot
     // q = 64 (ND w + i) + lane = position q % (K/8) of panel row q / (K/8), which takes global chunk position ^ (row & 15)
     // (K = 256: rows 16w + 2i + (lane >> 5), position lane & 31)
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf
     constexpr int NG = GATE ? 1 : 0, NS = SIGNS ? 1 : 0;         // gate loads / sign stores per tile
     auto tile_ptr = [&](const T* base, int ld, int jp, int gp, int ps) __attribute__((always_inline)) {
         const int t = tok + ps * (64 / P::LPT);
-        return reinterpret_cast<const char*>(base + (size_t)min(m_wave + t, p.M - 1) * ld + jp * P::NP + 32 * gp) + 16 * ch;
+        return reinterpret_cast<const char*>(base + (size_t)min(m_wave + t, M - 1) * ld + jp * P::NP + 32 * gp) + 16 * ch;
     };
     auto signs_ptr = [&](int j, int g) __attribute__((always_inline)) { return p.signs + ((size_t)(2 * j + g) * p.M + row) * 2 + half; };
     auto drain_load = [&](u32x4_t (&d)[P::PASSES]) __attribute__((always_inline)) {
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf
     }
     epi_alone(j1 - 1, 1, j1 - 1, 0, g1bits);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the repeated last DMA must not outlive the workgroup's LDS)
-    if (KNORM && p.knorm && lane == 0 && m_wave < p.M) {          // heads whose panel this workgroup walked (gridDim.y may split them)
+    if (KNORM && p.knorm && lane == 0 && m_wave < M) {          // heads whose panel this workgroup walked (gridDim.y may split them)
         float* kn = p.knorm + (size_t)(m_wave >> 5) * 4;
         if (j0 <= 4 && 4 < j1) kn[0] = sqrtf(kh0);
         if (j0 <= 5 && 5 < j1) kn[1] = sqrtf(kh1);
@@ -739,8 +741,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) voi
     const int w = wg - grp.first[seg];
     const int m0 = (w / ntn) * TM, n0 = (w % ntn) * BN;
     const int nk = (p.K + BK - 1) / BK;
+    const int M = live_rows(p.M, p.m_live);
+    if (m0 >= M) return;                      // packed stream: row blocks past the rows in use (workgroup-uniform)
     TileRegs<T> areg, wreg;
-    tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, 0, tid, p.K);
+    tile_fetch<T, TM>(areg, p.a, p.lda, m0, M, 0, tid, p.K);
     tile_fetch<T>(wreg, p.w, p.K, n0, p.N, 0, tid, p.K);
     f32x16 acc[G::RT][G::NT];
 #pragma unroll
@@ -767,14 +771,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) voi
         // while step s is multiplied and step s+1 already sits in registers (k steps past the end fetch clamped
         // addresses with ok = 0: zeros that are never multiplied).
         TileRegs<T> areg2, wreg2;
-        tile_fetch<T, TM>(areg2, p.a, p.lda, m0, p.M, BK, tid, p.K);
+        tile_fetch<T, TM>(areg2, p.a, p.lda, m0, M, BK, tid, p.K);
         tile_fetch<T>(wreg2, p.w, p.K, n0, p.N, BK, tid, p.K);
         for (int kc = 0; kc < nk; kc += 2) {
             __syncthreads();
             tile_commit<T, TM>(sA, areg, tid);
             tile_commit<T>(sW, wreg, tid);
             __syncthreads();
-            tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, (kc + 2) * BK, tid, p.K);
+            tile_fetch<T, TM>(areg, p.a, p.lda, m0, M, (kc + 2) * BK, tid, p.K);
             tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 2) * BK, tid, p.K);
             multiply();
             if (kc + 1 >= nk) break;
@@ -782,7 +786,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) voi
             tile_commit<T, TM>(sA, areg2, tid);
             tile_commit<T>(sW, wreg2, tid);
             __syncthreads();
-            tile_fetch<T, TM>(areg2, p.a, p.lda, m0, p.M, (kc + 3) * BK, tid, p.K);
+            tile_fetch<T, TM>(areg2, p.a, p.lda, m0, M, (kc + 3) * BK, tid, p.K);
             tile_fetch<T>(wreg2, p.w, p.K, n0, p.N, (kc + 3) * BK, tid, p.K);
             multiply();
         }
@@ -793,14 +797,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) voi
             tile_commit<T>(sW, wreg, tid);
             __syncthreads();
             if (kc + 1 < nk) {
-                tile_fetch<T, TM>(areg, p.a, p.lda, m0, p.M, (kc + 1) * BK, tid, p.K);
+                tile_fetch<T, TM>(areg, p.a, p.lda, m0, M, (kc + 1) * BK, tid, p.K);
                 tile_fetch<T>(wreg, p.w, p.K, n0, p.N, (kc + 1) * BK, tid, p.K);
             }
             multiply();
         }
     }
     __syncthreads();                          // every wave is done with sA / sW: reuse them as the staging tile
-    epilogue<T, RELU, TM, DROP>(acc, p, sA, m0, n0, tid);
+    epilogue<T, RELU, TM, DROP>(acc, p, M, sA, m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -812,6 +816,7 @@ constexpr int TK = 64, LDX = TK + 8;
 template <typename T> struct TnArgs {
     const T* dy; const T* x; float* slab;
     int M, N, K, ldy, ldx, splits, rows_per_split;
+    const int* m_live = nullptr;       // packed stream (LDS-DMA kernel): rows in use; the splits then share THOSE rows evenly
 };
 
 template <typename T> MTMP_DEV void store_quad(T* p, T a, T b, T c, T d);
@@ -876,7 +881,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs<T> p) {
     const int split = w / (tn * tk);
     w -= split * tn * tk;
     const int n0 = (w / tk) * 128, k0 = (w % tk) * 128;
-    const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
+    const int M = live_rows(p.M, p.m_live);                // (packed stream: see gemm_tn_dma_kernel)
+    const int rps = p.m_live ? ((M + p.splits - 1) / p.splits + TK - 1) / TK * TK : p.rows_per_split;
+    const int m_lo = split * rps, m_end = min(M, m_lo + rps);
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
     f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // column sums of dY (bias gradient)
@@ -1012,7 +1019,9 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 2 : 1) void gemm_tn_tr_kernel(T
     const int split = w / (tn * tk);
     w -= split * tn * tk;
     const int n0 = (w / tk) * 128, k0 = (w % tk) * 128;
-    const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
+    const int M = live_rows(p.M, p.m_live);                // (packed stream: see gemm_tn_dma_kernel)
+    const int rps = p.m_live ? ((M + p.splits - 1) / p.splits + TK - 1) / TK * TK : p.rows_per_split;
+    const int m_lo = split * rps, m_end = min(M, m_lo + rps);
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
     constexpr int ST = NG * TT;                            // tokens per step (all groups)
     const int nsteps = m_end > m_lo ? (m_end - m_lo + ST - 1) / ST : 0;
@@ -1159,7 +1168,10 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(Grouped<TnArgs<bf16
     const int split = w / (tn * tk);
     w -= split * tn * tk;
     const int kt = w % tk, n0 = (w / tk) * 128, k0 = kt * 128 * XT;
-    const int m_lo = split * p.rows_per_split, m_end = min(p.M, m_lo + p.rows_per_split);
+    const int M = live_rows(p.M, p.m_live);
+    // packed stream: the grid (and the slab count) belong to the padded maximum; every split takes its share of the live rows
+    const int rps = p.m_live ? ((M + p.splits - 1) / p.splits + TK - 1) / TK * TK : p.rows_per_split;
+    const int m_lo = split * rps, m_end = min(M, m_lo + rps);
     const int wn = (wave >> 1) * 64, xt = wave & 1;        // matrix wave: dY columns wn .. wn + 63, X tile xt / X columns 64 xt ..
     const int kcol = (XT == 2 ? 128 : 64) * xt;            // its first output column inside the tile
     const int nst = m_end > m_lo ? (m_end - m_lo + DT - 1) / DT : 0;
@@ -1522,6 +1534,7 @@ template <typename T> struct LnBwdGemmArgs {
     const T* dy; const T* wt; const T* z; const float* stats; const float* gamma; const T* d_res; T* dz; float* slab;
     int M, K, ldy, ldz, ldr;
     float eps;
+    const int* m_live = nullptr;       // packed stream: rows in use (common.cuh live_rows)
 };
 
 template <typename T>
@@ -1536,8 +1549,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kern
     const int wr = wave & 1, wc = wave >> 1;
     const int m0 = bx * 128;
     const int nk = (p.K + BK - 1) / BK;
+    const int M = live_rows(p.M, p.m_live);
+    if (m0 >= M) {                            // packed stream, row block past the rows in use: its partial row counts as zeros
+        for (int i = tid; i < 512; i += 256) p.slab[(size_t)bx * 512 + i] = 0.f;
+        return;
+    }
     TileRegs<T> areg, wreg0, wreg1;
-    tile_fetch<T>(areg, p.dy, p.ldy, m0, p.M, 0, tid, p.K);
+    tile_fetch<T>(areg, p.dy, p.ldy, m0, M, 0, tid, p.K);
     tile_fetch<T>(wreg0, p.wt, p.K, 0, 256, 0, tid, p.K);
     tile_fetch<T>(wreg1, p.wt, p.K, 128, 256, 0, tid, p.K);
     f32x16 acc[2][4];
@@ -1552,7 +1570,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kern
         tile_commit<T>(sW + 128 * LDW, wreg1, tid);
         __syncthreads();
         if (kc + 1 < nk) {
-            tile_fetch<T>(areg, p.dy, p.ldy, m0, p.M, (kc + 1) * BK, tid, p.K);
+            tile_fetch<T>(areg, p.dy, p.ldy, m0, M, (kc + 1) * BK, tid, p.K);
             tile_fetch<T>(wreg0, p.wt, p.K, 0, 256, (kc + 1) * BK, tid, p.K);
             tile_fetch<T>(wreg1, p.wt, p.K, 128, 256, (kc + 1) * BK, tid, p.K);
         }
@@ -1589,12 +1607,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kern
     const float rscale = p.d_res ? 1.0f : 0.0f;
     for (int trip = 0; trip < 32 / RPW; ++trip) {
         const int rl0 = wave * 32 + trip * RPW;
-        if (m0 + rl0 >= p.M) break;                        // wave-uniform: whole trips past M do nothing
+        if (m0 + rl0 >= M) break;                        // wave-uniform: whole trips past M do nothing
         f32x4 zv[RPW], dv[RPW], rv[RPW];
         float mu[RPW], rs[RPW];
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
-            const size_t row = (size_t)min(m0 + rl0 + k, p.M - 1);
+            const size_t row = (size_t)min(m0 + rl0 + k, M - 1);
             zv[k] = load4<T>(p.z + row * p.ldz + 4 * lane);
             rv[k] = load4<T>(res + row * ldres + 4 * lane);
             mu[k] = p.stats[2 * row];
@@ -1603,7 +1621,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kern
         }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
-            const float live = m0 + rl0 + k < p.M ? 1.0f : 0.0f;   // rows past M (clamped loads) rewrite row M-1 identically
+            const float live = m0 + rl0 + k < M ? 1.0f : 0.0f;   // rows past M (clamped loads) rewrite row M-1 identically
             const float sigma = 1.0f / rs[k] - p.eps;
             float xh[4], g[4], sg = 0.f, sgx = 0.f;
 #pragma unroll
@@ -1620,7 +1638,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void gemm_lnbwd_kern
             const float kx = sgx / (255.0f * sigma);
             // a clamped row recomputes row M-1 from ITS OWN dxn only when its staged row is that row's copy: the A tile
             // replicates row M-1 for rows past M (tile_fetch), so the staged rows past M equal row M-1's
-            store4<T>(p.dz + (size_t)min(m0 + rl0 + k, p.M - 1) * 256 + 4 * lane,
+            store4<T>(p.dz + (size_t)min(m0 + rl0 + k, M - 1) * 256 + 4 * lane,
                       (g[0] - mg) * rs[k] - xh[0] * kx + rscale * rv[k][0], (g[1] - mg) * rs[k] - xh[1] * kx + rscale * rv[k][1],
                       (g[2] - mg) * rs[k] - xh[2] * kx + rscale * rv[k][2], (g[3] - mg) * rs[k] - xh[3] * kx + rscale * rv[k][3]);
         }
@@ -1679,13 +1697,14 @@ int tn_launch_splits(bool tr, int M, int N, int K, int* mode_out) {
 }
 template <typename T>
 int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N, int K, int ldy, int ldx,
-                   hipStream_t st) {
+                   const int* m_live, hipStream_t st) {
     constexpr bool TR = sizeof(T) == 2;                    // bf16: transposing-read kernels, eight waves per CU
     int mode;
     const int splits = tn_launch_splits(TR, M, N, K, &mode);
     int rps = (M + splits - 1) / splits;
     rps = (rps + TK - 1) / TK * TK;
     TnArgs<T> a{(const T*)dy, (const T*)x, ws, M, N, K, ldy, ldx, splits, rps};
+    a.m_live = m_live;
     // the DMA kernel needs 16-byte aligned rows and 32-bit byte offsets; operands that are not get the register-staged kernel
     // at the same split count
     const bool dma = mode >= 2 && ldy % 8 == 0 && ldx % 8 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0 &&
@@ -1935,14 +1954,22 @@ extern "C" long long mtmp_gemm_tn_ws_floats(int M, int N, int K) {
 // dW[N,K] (fp32) = dY[M,N]^T X[M,K];  db[N] (fp32, optional) = column sums of dY.  N, K multiples of
 // 128.  ws: mtmp_gemm_tn_ws_floats(M,N,K) floats.  The weight / bias gradients of the Linear and
 // k=1 Conv1d layers of attention.py:60-62 and module.py:74-78.
+extern "C" int mtmp_gemm_tn_live(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N,
+                                 int K, int ldy, int ldx, const int32_t* rows_live, void* stream);
 extern "C" int mtmp_gemm_tn(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N,
                             int K, int ldy, int ldx, void* stream) {
+    return mtmp_gemm_tn_live(dtype, dy, x, dw, db, ws, M, N, K, ldy, ldx, nullptr, stream);
+}
+// rows_live (may be NULL): a device word with the rows in use (<= M), see mtmp_gemm_tn_grouped -- the split count, the
+// workspace and the grid stay those of M, every split takes its share of the live rows.
+extern "C" int mtmp_gemm_tn_live(int dtype, const void* dy, const void* x, float* dw, float* db, float* ws, int M, int N,
+                                 int K, int ldy, int ldx, const int32_t* rows_live, void* stream) {
     MTMP_CHECK_ARG(dy && x && ws && (dw || !db), "mtmp_gemm_tn: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && ldy >= N && ldx >= K && ldy % 8 == 0 &&
                        ldx % 8 == 0, "mtmp_gemm_tn: bad shape M=%d N=%d K=%d ldy=%d ldx=%d", M, N, K, ldy, ldx);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) return launch_gemm_tn<float>(dy, x, dw, db, ws, M, N, K, ldy, ldx, st);
-    if (dtype == 1) return launch_gemm_tn<bf16>(dy, x, dw, db, ws, M, N, K, ldy, ldx, st);
+    if (dtype == 0) return launch_gemm_tn<float>(dy, x, dw, db, ws, M, N, K, ldy, ldx, rows_live, st);
+    if (dtype == 1) return launch_gemm_tn<bf16>(dy, x, dw, db, ws, M, N, K, ldy, ldx, rows_live, st);
     mtmp_set_error("mtmp_gemm_tn: unknown dtype %d", dtype);
     return MTMP_ERR_ARG;
 }
@@ -1951,7 +1978,9 @@ namespace {
 // g_out[i] = keep(seed, i) ? g_in[i] / (1-p) : 0 -- backward of the epilogue dropout (same mask).
 // ------------------------------------------------------------------------------------------------------------------------
 // Grouped forms (bf16): the same operation of up to three token streams of one fusion layer in ONE launch (common.cuh, Grouped).
-// All pointer / int arrays are HOST arrays of n entries; scalars are common to the streams.  Same kernels, same results as n
+// All pointer / int arrays are HOST arrays of n entries; scalars are common to the streams.  rows_live (may be NULL, entries may be
+// NULL): per stream a DEVICE word with the rows in use this step (<= M[i]) -- the packed vital-sign stream, whose buffers and
+// grids are sized for the padded maximum M[i] (mtmp_row_starts); rows past it are neither read nor written.  Same kernels, same results as n
 // calls of the single forms.  The parity (fp32) build keeps the single forms.
 #define MTMP_CHECK_GROUP(name, n, dtype)                                                                             \
     MTMP_CHECK_ARG((n) >= 1 && (n) <= GRP_MAX && (dtype) == 1, name ": 1..%d streams, bf16 only (n=%d dtype=%d)", GRP_MAX, n, dtype)
@@ -1959,7 +1988,7 @@ namespace {
 extern "C" int mtmp_ln_gemm_qkv_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
                                         const void* const* w, const float* const* bias, void* const* y, void* const* xn,
                                         float* const* stats, float* const* key_norms, const int* M, const int* ldx, float eps,
-                                        void* stream) {
+                                        const int32_t* const* rows_live, void* stream) {
     MTMP_CHECK_GROUP("mtmp_ln_gemm_qkv_grouped", n, dtype);
     GemmArgs<bf16> a[GRP_MAX];
     for (int i = 0; i < n; ++i) {
@@ -1968,6 +1997,7 @@ extern "C" int mtmp_ln_gemm_qkv_grouped(int dtype, int n, const void* const* x, 
         a[i] = GemmArgs<bf16>{(const bf16*)x[i], (const bf16*)w[i], bias ? bias[i] : nullptr, nullptr, (bf16*)y[i], gamma[i], beta[i],
                               xn ? (bf16*)xn[i] : nullptr, stats ? stats[i] : nullptr, M[i], 768, 256, ldx[i], 768, 0, eps, 0.f, 0u,
                               nullptr, nullptr, 1.f, 0, nullptr, 1, nullptr, key_norms[i]};
+        a[i].m_live = rows_live ? rows_live[i] : nullptr;
     }
     return launch_ln_gemm_dma(n, a, 0, 0, (hipStream_t)stream);
 }
@@ -1976,7 +2006,8 @@ extern "C" int mtmp_ln_gemm_qkv_grouped(int dtype, int n, const void* const* x, 
 extern "C" int mtmp_ln_gemm_signs_grouped(int dtype, int n, const void* const* x, const float* const* gamma, const float* const* beta,
                                           const void* const* w, const float* const* bias, void* const* y, void* const* xn,
                                           float* const* stats, void* const* signs, const int* M, int N, const int* ldx, float eps,
-                                          float drop_p, const unsigned* seeds, const unsigned* seed_dev, void* stream) {
+                                          float drop_p, const unsigned* seeds, const unsigned* seed_dev,
+                                          const int32_t* const* rows_live, void* stream) {
     MTMP_CHECK_GROUP("mtmp_ln_gemm_signs_grouped", n, dtype);
     MTMP_CHECK_ARG(N > 0 && N % PanelDma::NP == 0 && drop_p >= 0.f && drop_p < 1.f, "mtmp_ln_gemm_signs_grouped: bad N=%d / dropout %f", N, drop_p);
     GemmArgs<bf16> a[GRP_MAX];
@@ -1986,6 +2017,7 @@ extern "C" int mtmp_ln_gemm_signs_grouped(int dtype, int n, const void* const* x
         a[i] = GemmArgs<bf16>{(const bf16*)x[i], (const bf16*)w[i], bias ? bias[i] : nullptr, nullptr, (bf16*)y[i], gamma[i], beta[i],
                               xn ? (bf16*)xn[i] : nullptr, stats ? stats[i] : nullptr, M[i], N, 256, ldx[i], N, 0, eps, drop_p,
                               seeds ? seeds[i] : 0u, seed_dev, nullptr, 1.f, 0, nullptr, 1, (unsigned short*)signs[i]};
+        a[i].m_live = rows_live ? rows_live[i] : nullptr;
     }
     return launch_ln_gemm_dma(n, a, 1, 0, (hipStream_t)stream);
 }
@@ -1994,7 +2026,7 @@ extern "C" int mtmp_ln_gemm_signs_grouped(int dtype, int n, const void* const* x
 extern "C" int mtmp_gemm_nt_signs_drop_grouped(int dtype, int n, const void* const* a_in, const void* const* w, void* const* y,
                                                const int* M, int N, const int* lda, const void* const* signs, float gate_scale,
                                                float drop_p, const unsigned* seeds, const unsigned* seed_dev, void* const* a_out,
-                                               void* stream) {
+                                               const int32_t* const* rows_live, void* stream) {
     MTMP_CHECK_GROUP("mtmp_gemm_nt_signs_drop_grouped", n, dtype);
     MTMP_CHECK_ARG(N > 0 && N % PanelDma::NP == 0 && drop_p >= 0.f && drop_p < 1.f, "mtmp_gemm_nt_signs_drop_grouped: bad N=%d / dropout %f", N, drop_p);
     GemmArgs<bf16> g[GRP_MAX];
@@ -2004,6 +2036,7 @@ extern "C" int mtmp_gemm_nt_signs_drop_grouped(int dtype, int n, const void* con
         g[i] = GemmArgs<bf16>{(const bf16*)a_in[i], (const bf16*)w[i], nullptr, nullptr, (bf16*)y[i], nullptr, nullptr,
                               a_out ? (bf16*)a_out[i] : nullptr, nullptr, M[i], N, 256, lda[i], N, 0, 0.f, drop_p, seeds ? seeds[i] : 0u,
                               seed_dev, nullptr, gate_scale, 0, nullptr, 1, (unsigned short*)signs[i]};
+        g[i].m_live = rows_live ? rows_live[i] : nullptr;
     }
     return launch_ln_gemm_dma(n, g, 0, 1, (hipStream_t)stream);
 }
@@ -2012,7 +2045,7 @@ extern "C" int mtmp_gemm_nt_signs_drop_grouped(int dtype, int n, const void* con
 extern "C" int mtmp_gemm_nt_grouped(int dtype, int n, const void* const* a_in, const void* const* w, const float* const* bias,
                                     const void* const* res, void* const* y, const int* M, int N, int K, const int* lda, const int* ldy,
                                     const int* ldr, int act, float drop_p, const unsigned* seeds, const unsigned* seed_dev,
-                                    void* stream) {
+                                    const int32_t* const* rows_live, void* stream) {
     MTMP_CHECK_GROUP("mtmp_gemm_nt_grouped", n, dtype);
     MTMP_CHECK_ARG(N > 0 && K > 0 && K % 8 == 0 && N % 32 == 0 && act >= 0 && act <= 2 && drop_p >= 0.f && drop_p < 1.f,
                    "mtmp_gemm_nt_grouped: bad shape N=%d K=%d act=%d p=%f", N, K, act, drop_p);
@@ -2025,6 +2058,7 @@ extern "C" int mtmp_gemm_nt_grouped(int dtype, int n, const void* const* a_in, c
         g[i] = GemmArgs<bf16>{(const bf16*)a_in[i], (const bf16*)w[i], bias ? bias[i] : nullptr, has_res ? (const bf16*)res[i] : nullptr,
                               (bf16*)y[i], nullptr, nullptr, nullptr, nullptr, M[i], N, K, lda[i], ldy[i], has_res ? ldr[i] : 0, 0.f,
                               drop_p, seeds ? seeds[i] : 0u, seed_dev, nullptr, 1.f, act, nullptr, 1};
+        g[i].m_live = rows_live ? rows_live[i] : nullptr;
     }
     return launch_gemm_nt<bf16>(n, g, 0, (hipStream_t)stream);
 }
@@ -2033,7 +2067,7 @@ extern "C" int mtmp_gemm_nt_grouped(int dtype, int n, const void* const* a_in, c
 extern "C" int mtmp_gemm_lnbwd_grouped(int dtype, int n, const void* const* dy, const void* const* wt, const void* const* z,
                                        const int* ldz, const float* const* stats, const float* const* gamma, const void* const* d_res,
                                        const int* ldr, void* const* dz, float* const* ws, const int* M, int K, const int* ldy, float eps,
-                                       void* stream) {
+                                       const int32_t* const* rows_live, void* stream) {
     MTMP_CHECK_GROUP("mtmp_gemm_lnbwd_grouped", n, dtype);
     MTMP_CHECK_ARG(K > 0 && K % 8 == 0, "mtmp_gemm_lnbwd_grouped: bad K=%d", K);
     LnBwdGemmArgs<bf16> a[GRP_MAX];
@@ -2045,6 +2079,7 @@ extern "C" int mtmp_gemm_lnbwd_grouped(int dtype, int n, const void* const* dy, 
         a[i] = LnBwdGemmArgs<bf16>{(const bf16*)dy[i], (const bf16*)wt[i], (const bf16*)z[i], stats[i], gamma[i],
                                    has_res ? (const bf16*)d_res[i] : nullptr, (bf16*)dz[i], nullptr, M[i], K, ldy[i], ldz[i],
                                    has_res ? ldr[i] : 0, eps};
+        a[i].m_live = rows_live ? rows_live[i] : nullptr;
     }
     return launch_gemm_lnbwd<bf16>(n, a, nullptr, ws, (hipStream_t)stream);
 }
@@ -2058,7 +2093,8 @@ extern "C" int mtmp_gemm_tn_group_plan(int n, const int* M, int N, int K, int* s
     return tn_group_plan(n, M, N, K, splits_out);
 }
 extern "C" int mtmp_gemm_tn_grouped(int dtype, int n, const void* const* dy, const void* const* x, float* const* ws, const int* M,
-                                    int N, int K, const int* ldy, const int* ldx, const int* splits, void* stream) {
+                                    int N, int K, const int* ldy, const int* ldx, const int* splits, const int32_t* const* rows_live,
+                                    void* stream) {
     MTMP_CHECK_GROUP("mtmp_gemm_tn_grouped", n, dtype);
     MTMP_CHECK_ARG(N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0, "mtmp_gemm_tn_grouped: N=%d K=%d must be multiples of 128", N, K);
     TnArgs<bf16> a[GRP_MAX];
@@ -2070,6 +2106,7 @@ extern "C" int mtmp_gemm_tn_grouped(int dtype, int n, const void* const* dy, con
         int rps = (M[i] + splits[i] - 1) / splits[i];
         rps = (rps + TK - 1) / TK * TK;
         a[i] = TnArgs<bf16>{(const bf16*)dy[i], (const bf16*)x[i], ws[i], M[i], N, K, ldy[i], ldx[i], splits[i], rps};
+        a[i].m_live = rows_live ? rows_live[i] : nullptr;
     }
     return launch_gemm_tn_grouped(n, a, (hipStream_t)stream);
 }

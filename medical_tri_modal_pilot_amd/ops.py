@@ -323,12 +323,13 @@ FOLD_DROPOUT_BWD = True         # layer_backward: drop2's backward inside the dH
 DEFER_REDUCTIONS = True        # layer_backward: one mtmp_reduce_batch per layer and stream instead of seven reduction launches
 
 
-def gemm_tn(dy2d, x2d, want_bias=True, out=None, defer=None):
+def gemm_tn(dy2d, x2d, want_bias=True, out=None, defer=None, pack=None):
     """(dW[N,K], db[N] | None) in fp32: dW = dy^T x, db = column sums of dy (split over the M tokens).
     out=(dw, db): write into these fp32 buffers (slices of the flat gradient) instead of allocating.
     defer: a list -- the split-M partials are left in the workspace and the reduction is appended to it; dW / db hold the result
-    only after reduce_batch(defer) (one launch for all of a layer's reductions)."""
+    only after reduce_batch(defer) (one launch for all of a layer's reductions).  pack: row_starts() of a packed stream."""
     _gpu(dy2d, x2d)
+    live = None if pack is None else pack.data_ptr() + 4 * (pack.numel() - 1)
     M, N = dy2d.shape
     K = x2d.shape[1]
     if out is not None:
@@ -338,11 +339,12 @@ def gemm_tn(dy2d, x2d, want_bias=True, out=None, defer=None):
         db = torch.empty(N, dtype=torch.float32, device=dy2d.device) if want_bias else None
     ws = torch.empty(_lib.lib().mtmp_gemm_tn_ws_floats(M, N, K), dtype=torch.float32, device=dy2d.device)
     if defer is not None:
-        call("mtmp_gemm_tn", _dt(dy2d), _p(dy2d), _p(x2d), None, None, _p(ws), M, N, K, dy2d.stride(0), x2d.stride(0), _stream())
+        call("mtmp_gemm_tn_live", _dt(dy2d), _p(dy2d), _p(x2d), None, None, _p(ws), M, N, K, dy2d.stride(0), x2d.stride(0), live,
+             _stream())
         defer.append((ws, _lib.lib().mtmp_gemm_tn_slab_rows(_dt(dy2d), M, N, K), N * K + N, dw, N * K, db))
         return dw, db
-    call("mtmp_gemm_tn", _dt(dy2d), _p(dy2d), _p(x2d), _p(dw), _p(db), _p(ws), M, N, K, dy2d.stride(0),
-         x2d.stride(0), _stream())
+    call("mtmp_gemm_tn_live", _dt(dy2d), _p(dy2d), _p(x2d), _p(dw), _p(db), _p(ws), M, N, K, dy2d.stride(0),
+         x2d.stride(0), live, _stream())
     return dw, db
 
 
@@ -404,9 +406,38 @@ def _ints(vs):
     return (ctypes.c_int * len(vs))(*vs)
 
 
-def attn_fwd_grouped(qkvs, kv_lens, ress, knorms):
+# ---- packed token streams (the ragged vital-sign stream without its pad rows) ------------------------------------------
+# A stream is PACKED when its samples' valid rows (bottleneck prefix + CLS + events = kv_len[b]) sit back to back in the
+# [B * N_max, 256] buffers instead of N_max rows apart: `pack` = row_starts(kv_len, N_max), int32[B + 1] on the device --
+# pack[b] = sample b's first row, pack[B] = the rows in use.  Buffers, launch grids and the hipGraph keep the padded size; the
+# kernels read the live row count from pack[B] (csrc/common.cuh live_rows) and the attention kernels address samples through
+# pack[b].  Nothing behind the live rows is read or written.
+def row_starts(kv_len, n_max: int):
+    """kv_len int32[B] (device) -> int32[B + 1]: exclusive prefix sums of min(kv_len, n_max), total last."""
+    _gpu(kv_len)
+    B = kv_len.shape[0]
+    out = torch.empty(B + 1, dtype=torch.int32, device=kv_len.device)
+    call("mtmp_row_starts", _p(kv_len), _p(out), B, int(n_max), _stream())
+    return out
+
+
+def _starts(packs):
+    """host array of the row_start pointers of a launch's streams (None: no stream is packed)"""
+    if packs is None or all(pk is None for pk in packs):
+        return None
+    return _ptrs(packs)
+
+
+def _lives(packs):
+    """host array of the rows_live words (pack[B]) of a launch's streams (None: no stream is packed)"""
+    if packs is None or all(pk is None for pk in packs):
+        return None
+    return (ctypes.c_void_p * len(packs))(*[None if pk is None else pk.data_ptr() + 4 * (pk.numel() - 1) for pk in packs])
+
+
+def attn_fwd_grouped(qkvs, kv_lens, ress, knorms, packs=None):
     """attn_fwd for up to three streams in ONE launch: lists of qkv [B,N_i,768], kv_len, res, knorm (entries may be None)
-    -> lists (o, o_res, lse)."""
+    -> lists (o, o_res, lse).  packs: per stream the row_starts() tensor of a packed stream, or None."""
     _gpu(*qkvs)
     n, B = len(qkvs), qkvs[0].shape[0]
     es, dt, dev = qkvs[0].element_size(), qkvs[0].dtype, qkvs[0].device
@@ -416,12 +447,13 @@ def attn_fwd_grouped(qkvs, kv_lens, ress, knorms):
     lse = [torch.empty(B, N_HEAD, N, dtype=torch.float32, device=dev) for N in Ns]
     with kernel_marks("attn_fwd", Ns[0]):
         call("mtmp_attn_fwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(o),
-             _ptrs(ress), _ptrs(o_res), _ptrs(lse), _ptrs(kv_lens), _ptrs(knorms), _ints(Ns), _ints([q.stride(1) for q in qkvs]),
+             _ptrs(ress), _ptrs(o_res), _ptrs(lse), _ptrs(kv_lens), _starts(packs), _ptrs(knorms), _ints(Ns),
+             _ints([q.stride(1) for q in qkvs]),
              _ints([D_MODEL] * n), B, N_HEAD, D_HEAD ** -0.5, _stream())
     return o, o_res, lse
 
 
-def attn_bwd_grouped(qkvs, os_, d_os, lses, kv_lens):
+def attn_bwd_grouped(qkvs, os_, d_os, lses, kv_lens, packs=None):
     """attn_bwd for up to three streams in two launches (dQ, dK/dV) -> list of dqkv [B,N_i,768]."""
     _gpu(*qkvs)
     n, B = len(qkvs), qkvs[0].shape[0]
@@ -431,7 +463,8 @@ def attn_bwd_grouped(qkvs, os_, d_os, lses, kv_lens):
     delta = [torch.empty(B * N_HEAD * N, dtype=torch.float32, device=qkvs[0].device) for N in Ns]
     with kernel_marks("attn_bwd", Ns[0]):
         call("mtmp_attn_bwd_grouped", _dt(qkvs[0]), n, _ptrs(qkvs), _ptrs(qkvs, D_MODEL * es), _ptrs(qkvs, 2 * D_MODEL * es), _ptrs(os_),
-             _ptrs(d_os), _ptrs(lses), _ptrs(kv_lens), _ptrs(dqkv), _ptrs(dqkv, D_MODEL * es), _ptrs(dqkv, 2 * D_MODEL * es),
+             _ptrs(d_os), _ptrs(lses), _ptrs(kv_lens), _starts(packs), _ptrs(dqkv), _ptrs(dqkv, D_MODEL * es),
+             _ptrs(dqkv, 2 * D_MODEL * es),
              _ptrs(delta), _ints(Ns), _ints([q.stride(1) for q in qkvs]), _ints([o.stride(1) for o in os_]),
              _ints([d.stride(1) for d in d_os]), _ints([d.stride(1) for d in dqkv]), B, N_HEAD, D_HEAD ** -0.5, _stream())
     return dqkv
@@ -441,7 +474,7 @@ def _uints(vs):
     return (ctypes.c_uint * len(vs))(*[int(v) & 0xFFFFFFFF for v in vs])
 
 
-def ln_gemm_qkv_grouped(xs, gammas, betas, ws, biases):
+def ln_gemm_qkv_grouped(xs, gammas, betas, ws, biases, packs=None):
     """ln_gemm_qkv of up to three streams in one launch (bf16): lists -> lists (qkv, xn, stats, knorm)."""
     _gpu(*xs)
     n, dt, dev = len(xs), xs[0].dtype, xs[0].device
@@ -451,11 +484,11 @@ def ln_gemm_qkv_grouped(xs, gammas, betas, ws, biases):
     st = [torch.empty(M, 2, dtype=torch.float32, device=dev) for M in Ms]
     kn = [torch.empty(_lib.lib().mtmp_key_norms_floats(M, N_HEAD), dtype=torch.float32, device=dev) for M in Ms]
     call("mtmp_ln_gemm_qkv_grouped", _dt(xs[0]), n, _ptrs(xs), _ptrs(gammas), _ptrs(betas), _ptrs(ws), _ptrs(biases), _ptrs(y),
-         _ptrs(xn), _ptrs(st), _ptrs(kn), _ints(Ms), _ints([x.stride(0) for x in xs]), LN_EPS, _stream())
+         _ptrs(xn), _ptrs(st), _ptrs(kn), _ints(Ms), _ints([x.stride(0) for x in xs]), LN_EPS, _lives(packs), _stream())
     return y, xn, st, [k.view(-1, N_HEAD) for k in kn]
 
 
-def ln_gemm_signs_grouped(xs, gammas, betas, ws, biases, n_out, drop_p, seeds):
+def ln_gemm_signs_grouped(xs, gammas, betas, ws, biases, n_out, drop_p, seeds, packs=None):
     """ln_gemm(relu, dropout, sign bits) of up to three streams in one launch (bf16): lists -> lists (y, xn, stats, signs)."""
     _gpu(*xs)
     n, dt, dev = len(xs), xs[0].dtype, xs[0].device
@@ -466,11 +499,11 @@ def ln_gemm_signs_grouped(xs, gammas, betas, ws, biases, n_out, drop_p, seeds):
     sg = [torch.empty(_lib.lib().mtmp_sign_bits_bytes(M, n_out), dtype=torch.uint8, device=dev) for M in Ms]
     call("mtmp_ln_gemm_signs_grouped", _dt(xs[0]), n, _ptrs(xs), _ptrs(gammas), _ptrs(betas), _ptrs(ws), _ptrs(biases), _ptrs(y),
          _ptrs(xn), _ptrs(st), _ptrs(sg), _ints(Ms), n_out, _ints([x.stride(0) for x in xs]), LN_EPS, float(drop_p), _uints(seeds),
-         _p(_seed_word), _stream())
+         _p(_seed_word), _lives(packs), _stream())
     return y, xn, st, sg
 
 
-def gemm_nt_grouped(as_, ws, biases, ress, drop_p, seeds):
+def gemm_nt_grouped(as_, ws, biases, ress, drop_p, seeds, packs=None):
     """gemm_nt (bias, dropout, residual) of up to three streams in one launch (bf16): lists -> list of y."""
     _gpu(*as_)
     n, dt, dev = len(as_), as_[0].dtype, as_[0].device
@@ -478,11 +511,11 @@ def gemm_nt_grouped(as_, ws, biases, ress, drop_p, seeds):
     y = [torch.empty(M, N, dtype=dt, device=dev) for M in Ms]
     call("mtmp_gemm_nt_grouped", _dt(as_[0]), n, _ptrs(as_), _ptrs(ws), _ptrs(biases), _ptrs(ress), _ptrs(y), _ints(Ms), N, K,
          _ints([a.stride(0) for a in as_]), _ints([N] * n), _ints([0 if r is None else r.stride(0) for r in ress]), 0, float(drop_p),
-         _uints(seeds), _p(_seed_word), _stream())
+         _uints(seeds), _p(_seed_word), _lives(packs), _stream())
     return y
 
 
-def gemm_nt_signs_drop_grouped(as_, ws, signs, gate_scale, drop_p, seeds):
+def gemm_nt_signs_drop_grouped(as_, ws, signs, gate_scale, drop_p, seeds, packs=None):
     """gemm_nt_signs (with the dropout backward of the operand folded in when drop_p > 0) of up to three streams in one
     launch: lists -> (list of y, list of dropped operands | the operands themselves when drop_p == 0)."""
     _gpu(*as_)
@@ -492,11 +525,11 @@ def gemm_nt_signs_drop_grouped(as_, ws, signs, gate_scale, drop_p, seeds):
     ad = [torch.empty(M, a.shape[1], dtype=dt, device=dev) for M, a in zip(Ms, as_)] if drop_p > 0 else None
     call("mtmp_gemm_nt_signs_drop_grouped", _dt(as_[0]), n, _ptrs(as_), _ptrs(ws), _ptrs(y), _ints(Ms), N,
          _ints([a.stride(0) for a in as_]), _ptrs(signs), float(gate_scale), float(drop_p), _uints(seeds), _p(_seed_word),
-         None if ad is None else _ptrs(ad), _stream())
+         None if ad is None else _ptrs(ad), _lives(packs), _stream())
     return y, (ad if ad is not None else list(as_))
 
 
-def gemm_lnbwd_grouped(dys, wts, zs, statss, gammas, d_ress, gb_outs, defers):
+def gemm_lnbwd_grouped(dys, wts, zs, statss, gammas, d_ress, gb_outs, defers, packs=None):
     """gemm_lnbwd of up to three streams in one launch, reductions deferred: lists -> list of (dz, dgamma, dbeta);
     defers[i] receives stream i's reduction entry (reduce_batch)."""
     _gpu(*dys)
@@ -507,13 +540,13 @@ def gemm_lnbwd_grouped(dys, wts, zs, statss, gammas, d_ress, gb_outs, defers):
     ws = [torch.empty(_lib.lib().mtmp_gemm_lnbwd_ws_floats(M), dtype=torch.float32, device=dev) for M in Ms]
     call("mtmp_gemm_lnbwd_grouped", _dt(zs[0]), n, _ptrs(dys), _ptrs(wts), _ptrs(zs), _ints([z.stride(0) for z in zs]), _ptrs(statss),
          _ptrs(gammas), _ptrs(d_ress), _ints([0 if r is None else r.stride(0) for r in d_ress]), _ptrs(dz), _ptrs(ws), _ints(Ms), K,
-         _ints([d.stride(0) for d in dys]), LN_EPS, _stream())
+         _ints([d.stride(0) for d in dys]), LN_EPS, _lives(packs), _stream())
     for i in range(n):
         defers[i].append((ws[i], _lib.lib().mtmp_gemm_lnbwd_slab_rows(Ms[i]), 2 * D_MODEL, gb[i], 2 * D_MODEL, None))
     return [(dz[i], gb[i][:D_MODEL], gb[i][D_MODEL:]) for i in range(n)]
 
 
-def gemm_tn_grouped(dys, xs, outs, defers):
+def gemm_tn_grouped(dys, xs, outs, defers, packs=None):
     """gemm_tn of up to three streams in one launch (LDS-DMA kernel), reductions deferred: lists -> list of (dw, db).
     Falls back to one gemm_tn per stream when the shapes have no grouped form (short streams)."""
     _gpu(*dys)
@@ -521,7 +554,7 @@ def gemm_tn_grouped(dys, xs, outs, defers):
     Ms, N, K = [d.shape[0] for d in dys], dys[0].shape[1], xs[0].shape[1]
     splits = (ctypes.c_int * n)()
     if dys[0].dtype != torch.bfloat16 or _lib.lib().mtmp_gemm_tn_group_plan(n, _ints(Ms), N, K, splits) != 0:
-        return [gemm_tn(dys[i], xs[i], out=outs[i], defer=defers[i]) for i in range(n)]
+        return [gemm_tn(dys[i], xs[i], out=outs[i], defer=defers[i], pack=None if packs is None else packs[i]) for i in range(n)]
     res, wss = [], []
     for i in range(n):
         if outs[i] is not None:
@@ -533,7 +566,7 @@ def gemm_tn_grouped(dys, xs, outs, defers):
         wss.append(torch.empty(splits[i] * (N * K + N), dtype=torch.float32, device=dev))
     with kernel_marks(f"gemm_tn{N}x{K}", Ms[0]):
         call("mtmp_gemm_tn_grouped", _dt(dys[0]), n, _ptrs(dys), _ptrs(xs), _ptrs(wss), _ints(Ms), N, K,
-             _ints([d.stride(0) for d in dys]), _ints([x.stride(0) for x in xs]), splits, _stream())
+             _ints([d.stride(0) for d in dys]), _ints([x.stride(0) for x in xs]), splits, _lives(packs), _stream())
     for i in range(n):
         defers[i].append((wss[i], int(splits[i]), N * K + N, res[i][0], N * K, res[i][1]))
     return res
@@ -592,19 +625,21 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, shadow, lr, beta1, beta2, eps, 
          float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
 
 
-def bottleneck_exchange_fwd(z, missing, resbottle=False, prev=None, keep=None):
-    """In place on z = [z_v, z_i, z_t] ([B, n_m, 256] contiguous): rows 0..3 <- exchanged bottleneck tokens."""
+def bottleneck_exchange_fwd(z, missing, resbottle=False, prev=None, keep=None, pack_v=None):
+    """In place on z = [z_v, z_i, z_t] ([B, n_m, 256] contiguous): rows 0..3 <- exchanged bottleneck tokens.
+    pack_v: row_starts() of a packed first stream."""
     _gpu(*[t for t in z if t is not None])
     B = z[0].shape[0]
     call("mtmp_bottleneck_exchange_fwd", _dt(z[0]), _p(z[0]), _p(z[1]), _p(z[2]), B, z[0].shape[1], z[1].shape[1],
-         0 if z[2] is None else z[2].shape[1], _p(missing), int(bool(resbottle)), _p(prev), _p(keep), _stream())
+         0 if z[2] is None else z[2].shape[1], _p(missing), int(bool(resbottle)), _p(prev), _p(keep), _p(pack_v), _stream())
 
 
-def bottleneck_exchange_bwd(dz, missing, resbottle=False, d_prev_in=None, d_prev_out=None):
+def bottleneck_exchange_bwd(dz, missing, resbottle=False, d_prev_in=None, d_prev_out=None, pack_v=None):
     _gpu(*[t for t in dz if t is not None])
     B = dz[0].shape[0]
     call("mtmp_bottleneck_exchange_bwd", _dt(dz[0]), _p(dz[0]), _p(dz[1]), _p(dz[2]), B, dz[0].shape[1], dz[1].shape[1],
-         0 if dz[2] is None else dz[2].shape[1], _p(missing), int(bool(resbottle)), _p(d_prev_in), _p(d_prev_out), _stream())
+         0 if dz[2] is None else dz[2].shape[1], _p(missing), int(bool(resbottle)), _p(d_prev_in), _p(d_prev_out), _p(pack_v),
+         _stream())
 
 
 def sink_param_grads(params, grads):
@@ -857,11 +892,13 @@ def bce_with_logits(criterion, output, target):
 # ----------------------------------------------------------------------------- stream input (K4)
 class StreamInputFn(torch.autograd.Function):
     """mbt_encoder.py:697-729 + the [bottleneck | CLS | tokens] concatenation of :745 as one launch each way.
-    apply(x [B,N,256] compute dtype, cls [1,1,256], ln_w, ln_b, pe [L,256] | None, bott [1,nb,256] | None, eps, p, seed)
-    -> z [B, nb+1+N, 256] (the buffer ops.FusionStackFn reads in place, cfg["prebuilt"])."""
+    apply(x [B,N,256] compute dtype, cls [1,1,256], ln_w, ln_b, pe [L,256] | None, bott [1,nb,256] | None, eps, p, seed
+          [, pack, kv_len])
+    -> z [B, nb+1+N, 256] (the buffer ops.FusionStackFn reads in place, cfg["prebuilt"]).  pack (row_starts(kv_len, nb+1+N))
+    with kv_len: the output is PACKED -- sample b's first kv_len[b] rows at rows pack[b].. of the same allocation."""
 
     @staticmethod
-    def forward(ctx, x, cls, ln_w, ln_b, pe, bott, eps, p, seed):
+    def forward(ctx, x, cls, ln_w, ln_b, pe, bott, eps, p, seed, pack=None, kv_len=None):
         _gpu(x)
         B, N, _ = x.shape
         nb = 0 if bott is None else bott.shape[-2]
@@ -874,7 +911,8 @@ class StreamInputFn(torch.autograd.Function):
         out = torch.empty(B, nb + 1 + N, D_MODEL, dtype=x.dtype, device=x.device)
         stats = torch.empty(B * (N + 1), 2, dtype=torch.float32, device=x.device)
         call("mtmp_stream_input_fwd", _dt(x), _p(x), _p(cls_f), _p(g_f), _p(b_f), _p(pe_f), _p(bott_f), _p(out), _p(stats),
-             B, N, nb, float(eps), float(p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _stream())
+             B, N, nb, float(eps), float(p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _p(pack), _p(kv_len), _stream())
+        ctx.pack = (pack, kv_len)
         ctx.save_for_backward(x, cls_f, g_f, stats)
         ctx.meta = (B, N, nb, float(p), int(seed) & 0xFFFFFFFF, cls.shape, None if bott is None else bott.shape)
         ctx.prm = [cls, ln_w, ln_b]                  # used by this stream only (the bottleneck tokens feed all three)
@@ -889,10 +927,10 @@ class StreamInputFn(torch.autograd.Function):
         grads = torch.empty(7, D_MODEL, dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.lib().mtmp_stream_input_ws_floats(B * (nb + 1 + N)), dtype=torch.float32, device=x.device)
         call("mtmp_stream_input_bwd", _dt(x), _p(dz), _p(x), _p(cls_f), _p(g_f), _p(stats), _p(dx), _p(grads), _p(ws),
-             B, N, nb, p, seed, _p(_seed_word), _stream())
+             B, N, nb, p, seed, _p(_seed_word), _p(ctx.pack[0]), _p(ctx.pack[1]), _stream())
         d_bott = None if bott_shape is None else grads[3:3 + nb].view(bott_shape)
         gc, gw, gb = sink_param_grads(ctx.prm, [grads[2].view(cls_shape), grads[0], grads[1]])
-        return dx, gc, gw, gb, None, d_bott, None, None, None
+        return dx, gc, gw, gb, None, d_bott, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- encoder layer
@@ -964,7 +1002,7 @@ def layer_backward(saved, d_out, sink=None, late=None):
     d_out [B,N,256] contiguous, compute dtype.  Returns (dz [B,N,256], 14 parameter gradients (fp32,
     in PARAMS order; weights as 2-D [out,in])) -- or (dz, None) when the gradients went straight into
     the flat gradient buffer through `sink`."""
-    z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds, hsign = saved
+    z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds, hsign = saved[:19]
     B, N, D = z.shape
     M = B * N
     d_out = d_out.view(M, D)
@@ -1017,21 +1055,25 @@ def grouped_ok(z) -> bool:
     return GROUPED_LAUNCHES and z.dtype == torch.bfloat16
 
 
-def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds):
-    """layer_forward for the active streams of one fusion layer with ONE launch per step (lists, one entry per stream)."""
+def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None):
+    """layer_forward for the active streams of one fusion layer with ONE launch per step (lists, one entry per stream).
+    packs: per stream None or the row_starts() tensor of a PACKED stream (its [B, N, 256] buffers then hold the samples' valid
+    rows back to back: every kernel below works on pack[B] rows instead of B * N)."""
     n = len(zs)
     B, D = zs[0].shape[0], D_MODEL
     Ns = [z.shape[1] for z in zs]
+    packs = [None] * n if packs is None else list(packs)
     z2 = [z.view(B * N, D) for z, N in zip(zs, Ns)]
-    qkv, xn1, st1, knorm = ln_gemm_qkv_grouped(z2, [P[0] for P in Ps], [P[1] for P in Ps], [f[0] for f in fuseds], [f[1] for f in fuseds])
+    qkv, xn1, st1, knorm = ln_gemm_qkv_grouped(z2, [P[0] for P in Ps], [P[1] for P in Ps], [f[0] for f in fuseds], [f[1] for f in fuseds],
+                                               packs)
     qkv = [q.view(B, N, 3 * D) for q, N in zip(qkv, Ns)]
-    o, r1, lse = attn_fwd_grouped(qkv, kv_lens, list(zs), knorm)
+    o, r1, lse = attn_fwd_grouped(qkv, kv_lens, list(zs), knorm, packs)
     r1_2 = [r.view(B * N, D) for r, N in zip(r1, Ns)]
     h, xn2, st2, hsign = ln_gemm_signs_grouped(r1_2, [P[8] for P in Ps], [P[9] for P in Ps], [f[2] for f in fuseds],
-                                               [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds])
-    out = gemm_nt_grouped(h, [f[3] for f in fuseds], [P[13] for P in Ps], r1_2, drop_p, [sd[1] for sd in seeds])
+                                               [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds], packs)
+    out = gemm_nt_grouped(h, [f[3] for f in fuseds], [P[13] for P in Ps], r1_2, drop_p, [sd[1] for sd in seeds], packs)
     saved = [(zs[i], kv_lens[i], Ps[i][0], Ps[i][8], fuseds[i][5], fuseds[i][6], fuseds[i][4], xn1[i], st1[i], qkv[i], o[i], lse[i],
-              r1[i], xn2[i], st2[i], h[i], drop_p, seeds[i], hsign[i]) for i in range(n)]
+              r1[i], xn2[i], st2[i], h[i], drop_p, seeds[i], hsign[i], packs[i]) for i in range(n)]
     return [out[i].view(B, Ns[i], D) for i in range(n)], saved
 
 
@@ -1052,17 +1094,18 @@ def layer_backward_grouped(saveds, d_outs, sinks, late):
                                                                               col(14), col(15), col(18))
     kv = col(1)
     seeds = col(17)
-    dh, dy2 = gemm_nt_signs_drop_grouped(d_out, w2t, hsign, 1.0 / (1.0 - p), p, [sd[1] for sd in seeds])
-    gw2 = gemm_tn_grouped(dy2, h, [(sinks[i].w2, sinks[i].c2) if direct[i] else None for i in range(n)], reds)
-    gw1 = gemm_tn_grouped(dh, xn2, [(sinks[i].w1, sinks[i].c1) if direct[i] else None for i in range(n)], reds)
+    packs = [sv[19] if len(sv) > 19 else None for sv in saveds]
+    dh, dy2 = gemm_nt_signs_drop_grouped(d_out, w2t, hsign, 1.0 / (1.0 - p), p, [sd[1] for sd in seeds], packs)
+    gw2 = gemm_tn_grouped(dy2, h, [(sinks[i].w2, sinks[i].c2) if direct[i] else None for i in range(n)], reds, packs)
+    gw1 = gemm_tn_grouped(dh, xn2, [(sinks[i].w1, sinks[i].c1) if direct[i] else None for i in range(n)], reds, packs)
     r1_2 = [r.view(M, D) for r, M in zip(r1, Ms)]
-    l2 = gemm_lnbwd_grouped(dh, w1t, r1_2, st2, g2, d_out, [sinks[i].gb2 if direct[i] else None for i in range(n)], reds)
+    l2 = gemm_lnbwd_grouped(dh, w1t, r1_2, st2, g2, d_out, [sinks[i].gb2 if direct[i] else None for i in range(n)], reds, packs)
     dr1 = [t[0] for t in l2]
-    dqkv = attn_bwd_grouped(qkv, o, [d.view(B, N, D) for d, N in zip(dr1, Ns)], lse, kv)
+    dqkv = attn_bwd_grouped(qkv, o, [d.view(B, N, D) for d, N in zip(dr1, Ns)], lse, kv, packs)
     dqkv = [d.view(M, 3 * D) for d, M in zip(dqkv, Ms)]
-    gwq = gemm_tn_grouped(dqkv, xn1, [(sinks[i].wqkv, sinks[i].bqkv) if direct[i] else None for i in range(n)], reds)
+    gwq = gemm_tn_grouped(dqkv, xn1, [(sinks[i].wqkv, sinks[i].bqkv) if direct[i] else None for i in range(n)], reds, packs)
     l1 = gemm_lnbwd_grouped(dqkv, wqkvt, [t.view(M, D) for t, M in zip(z, Ms)], st1, g1, dr1,
-                            [sinks[i].gb1 if direct[i] else None for i in range(n)], reds)
+                            [sinks[i].gb1 if direct[i] else None for i in range(n)], reds, packs)
     allred = [e for r_ in reds for e in r_]
     marks = [sinks[i] for i in range(n) if direct[i]]
     if late is not None:
@@ -1204,6 +1247,11 @@ class FusionStackFn(torch.autograd.Function):
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
         saved, active = [], []
+        # the vital-sign stream PACKED (cfg["pack_v"] = row_starts(kv[0], Ns[0]), made by the encoder together with a packed
+        # stream input): bf16 grouped kernels only, and only for a caller that reads nothing of stream 0 but its CLS row
+        pack_v = cfg.get("pack_v")
+        if pack_v is not None and not (cfg.get("prebuilt") and grouped_ok(z[0]) and cfg["kv"][0] is not None):
+            raise ValueError("a packed vital-sign stream needs prebuilt bf16 inputs with key lengths (ops.StreamInputFn)")
         prev_bott = bott.expand(B, -1, -1).float().contiguous() if cfg["resbottle"] else None
         for li in range(L):
             last = final and (cfg["vsltonly"] == 1 or cfg.get("first_only")) and li == L - 1
@@ -1225,7 +1273,8 @@ class FusionStackFn(torch.autograd.Function):
                         go, gsaved = layer_forward_grouped(
                             [z[m] for m in gms], [cfg["kv"][m] for m in gms],
                             [params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER] for m in gms],
-                            [cfg["fused"][li][m] for m in gms], cfg["drop_p"], [cfg["seeds"][li][m] for m in gms])
+                            [cfg["fused"][li][m] for m in gms], cfg["drop_p"], [cfg["seeds"][li][m] for m in gms],
+                            [pack_v if m == 0 else None for m in gms])
                         for i, m in enumerate(gms):
                             outs[m], row[m] = go[i], gsaved[i]
                     else:
@@ -1245,7 +1294,7 @@ class FusionStackFn(torch.autograd.Function):
                 break
             # bottleneck exchange (:764-779) on the [B,4,256] prefixes, written back in place (one kernel)
             keep = torch.empty(B, NB, D_MODEL, dtype=torch.float32, device=dev) if cfg["resbottle"] else None
-            bottleneck_exchange_fwd(outs, cfg["missing"], cfg["resbottle"], prev_bott if cfg["resbottle"] else None, keep)
+            bottleneck_exchange_fwd(outs, cfg["missing"], cfg["resbottle"], prev_bott if cfg["resbottle"] else None, keep, pack_v)
             prev_bott = keep
             z = outs
         if streams is not None and cfg.get("prebuilt"):
@@ -1256,7 +1305,11 @@ class FusionStackFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         outs_full = [z[m] if z[m] is not None else torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) for m in range(3)]
         ctx.mark_non_differentiable(*[o for m, o in enumerate(outs_full) if z[m] is None])
-        cls_v = outs_full[0][:, NB, :].clone() if final else None
+        if pack_v is not None:             # row pack_v[b] + NB of the packed buffer
+            ctx.cls_rows = pack_v[:B].long() + NB
+            cls_v = outs_full[0].view(-1, D_MODEL).index_select(0, ctx.cls_rows) if final else None
+        else:
+            cls_v = outs_full[0][:, NB, :].clone() if final else None
         return outs_full[0], outs_full[1], outs_full[2], cls_v
 
     @staticmethod
@@ -1284,7 +1337,10 @@ class FusionStackFn(torch.autograd.Function):
         for m, g in enumerate((d_v, d_i, d_t)):
             if m in active[-1]:
                 dz[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) if g is None else _c(g).to(dt).clone()
-        if d_cls is not None:
+        pack_v = cfg.get("pack_v")
+        if d_cls is not None and pack_v is not None:
+            dz[0].view(-1, D_MODEL).index_add_(0, ctx.cls_rows, d_cls.to(dt))
+        elif d_cls is not None:
             dz[0][:, NB, :] += d_cls.to(dt)
         pgrads = [None] * len(pshapes)
         d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
@@ -1307,7 +1363,7 @@ class FusionStackFn(torch.autograd.Function):
                 # this layer's outputs went through an exchange before feeding layer li+1: rows 0..3 of the three
                 # gradient buffers are summed and redistributed by the exchange weights, in place (one kernel)
                 d_out_prev = torch.empty(B, NB, D_MODEL, dtype=torch.float32, device=dev) if cfg["resbottle"] else None
-                bottleneck_exchange_bwd(dz, cfg["missing"], cfg["resbottle"], d_prev_bott, d_out_prev)
+                bottleneck_exchange_bwd(dz, cfg["missing"], cfg["resbottle"], d_prev_bott, d_out_prev, pack_v)
                 d_prev_bott = d_out_prev
             nxt = [None, None, None]
             groups = launch_groups(ms, streams, saved[li][ms[0]][0])

@@ -1366,6 +1366,7 @@ def _loop(hip_graph, dropout, dtype, n_steps, lens_per_step, L=2, B=4, T=96, mis
                               reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
         losses.append(loss)
         del miss
+    _loop.last_model = model
     return losses, opt.flat.data.detach().clone(), getattr(model, "_mtmp_graph_step", None)
 
 
@@ -1794,3 +1795,100 @@ def test_resume_from_reference_optimizer_state(ops):
         o.step()
     for a, b in zip(model.parameters(), ref.parameters()):
         check("resume.param", a, b, 1e-6)
+
+
+# ----------------------------------------------------------------------------- packed vital-sign stream (--pack-rows)
+def test_row_starts(ops):
+    """mtmp_row_starts: exclusive prefix sums of min(max(kv_len, 0), n_max), total last (B below / above one scan block)."""
+    for B, n_max in ((1, 7), (64, 1005), (300, 37)):
+        g = torch.Generator().manual_seed(B)
+        kv = torch.randint(-2, n_max + 9, (B,), generator=g, dtype=torch.int32)
+        out = ops.row_starts(kv.to(DEV), n_max).cpu()
+        c = kv.clamp(0, n_max).to(torch.int64)
+        ref = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(c, 0)])
+        assert torch.equal(out.to(torch.int64), ref), (B, out[:5], ref[:5])
+    REPORT["row_starts"] = {"rel_err": 0.0, "tol": 0.0}
+
+
+def _pack_rows(t, kv, pack):
+    """padded [B, N, C] -> the packed layout inside a same-sized buffer (rows behind the live ones poisoned)"""
+    B, N, C = t.shape
+    out = torch.full((B * N, C), float("nan"), dtype=t.dtype, device=t.device)
+    for b in range(B):
+        out[int(pack[b]):int(pack[b]) + int(kv[b])] = t[b, :int(kv[b])]
+    return out.view(B, N, C)
+
+
+def _unpack_rows(t, kv, pack):
+    B, N, C = t.shape
+    out = torch.zeros(B, N, C, dtype=t.dtype, device=t.device)
+    flat = t.reshape(B * N, C)
+    for b in range(B):
+        out[b, :int(kv[b])] = flat[int(pack[b]):int(pack[b]) + int(kv[b])]
+    return out
+
+
+@pytest.mark.parametrize("N,lens", [(200, [200, 5, 64, 129, 1, 77]), (1005, [1005, 6, 700, 333]), (300, [300] * 3)])
+def test_packed_layer_equals_padded_layer(ops, N, lens):
+    """One encoder layer of the grouped bf16 kernels on a PACKED stream (valid rows back to back, every row behind them NaN) against
+    the same layer on the padded [B, N] layout: outputs and input gradients on the valid rows, parameter gradients.  The row-panel
+    kernels are row-local (bit-identical rows); the attention forward may pick the other softmax body for a wave and the weight
+    gradients cut their token range elsewhere, so the comparison is to bf16 rounding."""
+    from medical_tri_modal_pilot_amd.builder.models.src.transformer.encoder import TransformerEncoderLayer
+    torch.manual_seed(3)
+    B = len(lens)
+    kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    layer = TransformerEncoderLayer(d_model=256, num_heads=4, d_ff=1024, dropout_p=0.0).to(DEV)
+    with torch.no_grad():
+        for prm in layer.parameters():
+            if prm.dim() > 1:
+                prm.mul_(3.0)
+    P = layer.param_list()
+    fused = type(layer).fused_weights_of([layer], torch.bfloat16)[0]
+    z = torch.randn(B, N, 256, device=DEV).to(torch.bfloat16)
+    valid = (torch.arange(N, device=DEV)[None, :] < kv[:, None])
+    d_out = torch.randn(B, N, 256, device=DEV).to(torch.bfloat16) * valid[..., None]      # a pad row has no gradient
+    pack = ops.row_starts(kv, N)
+    outs, grads = {}, {}
+    for mode in ("padded", "packed"):
+        pk = [pack] if mode == "packed" else None
+        zin = _pack_rows(z, lens, pack.cpu()) if mode == "packed" else z
+        dout = _pack_rows(d_out, lens, pack.cpu()) if mode == "packed" else d_out
+        (y,), saved = ops.layer_forward_grouped([zin], [kv], [P], [fused], 0.0, [(0, 0)], pk)
+        (dz,), (g,) = ops.layer_backward_grouped(saved, [dout.contiguous()], [None], None)
+        if mode == "packed":
+            y, dz = _unpack_rows(y, lens, pack.cpu()), _unpack_rows(dz, lens, pack.cpu())
+        outs[mode] = (y * valid[..., None], dz * valid[..., None])
+        grads[mode] = g
+    tag = f"packed_layer[N={N},B={B}]"
+    check(tag + ".y", outs["packed"][0].float(), outs["padded"][0].float(), 1e-2)
+    check(tag + ".dz", outs["packed"][1].float(), outs["padded"][1].float(), 2e-2)
+    for k, (a, b) in enumerate(zip(grads["packed"], grads["padded"])):
+        assert torch.isfinite(a).all(), (tag, k)
+        if k in (4, 5):                  # key-projection weight / bias gradients: mathematically ~0 (softmax shift invariance), noise
+            continue
+        check(tag + f".grad{k}", a.float(), b.float(), 2e-2)
+
+
+def test_packed_training_steps_equal_padded_steps(ops):
+    """--pack-rows 1 against --pack-rows 0 through get_trainer (bf16, dropout 0, ragged batches with mixed missing modalities,
+    eager and hipGraph replay with the lengths changing under one captured graph): same losses to bf16 rounding, parameters after
+    four AdamW steps within 2 lr."""
+    lens = [[96, 50, 7, 1], [96, 96, 96, 96], [3, 96, 20, 64], [96, 1, 1, 2]]
+    res = {}
+    for pack in (0, 1):
+        for graph in (0, 1):
+            res[pack, graph] = _loop(graph, 0.0, "bf16", 4, lens, pack_rows=pack)
+            assert (_loop.last_model.fusion_transformer.last_pack is not None) == bool(pack)      # the mode under test really ran
+    gs = res[1, 1][2]
+    assert gs is not None and gs.captures == 1 and gs.replays == 3 and not gs.disabled
+    for graph in (0, 1):
+        lp, l0 = res[1, graph][0], res[0, graph][0]
+        worst = max(abs(a - b) for a, b in zip(lp, l0))
+        REPORT[f"packed_vs_padded[graph={graph}].loss"] = {"rel_err": worst, "tol": 2e-3}
+        assert worst < 2e-3, (lp, l0)
+        dp = float((res[1, graph][1] - res[0, graph][1]).abs().max())
+        REPORT[f"packed_vs_padded[graph={graph}].params"] = {"rel_err": dp, "tol": 8e-4}
+        assert dp < 8e-4, dp                      # lr <= 1e-4: AdamW moves a parameter by at most ~lr per step
+    assert res[1, 0][0] == res[1, 1][0], (res[1, 0][0], res[1, 1][0])       # replay == eager, packed
+    assert torch.equal(res[1, 0][1], res[1, 1][1])
