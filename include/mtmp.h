@@ -362,7 +362,9 @@ int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const lo
 /* Row map of a PACKED token stream ("skip padded key tiles and padded query rows"; the reference pads every sample to
  * the batch maximum, trainer.py:41-42, and masks keys, utils.py:79-125): out[b] = sum of min(max(kv_len[0..b), 0), n_max) =
  * sample b's first row when the samples' valid rows are stored back to back; out[B] = the rows in use (the `rows_live` word of
- * the grouped kernels).  kv_len: int32[B] device (a fused count of mtmp_stream_lengths); out: int32[B + 1] device. */
+ * the grouped kernels); out[B + 1 .. 2 B + 1) = the order in which the attention kernels walk the samples of a packed stream
+ * (ranked by length, dealt round-robin over the eight XCD chunks of their grids).  kv_len: int32[B] device (a fused count of
+ * mtmp_stream_lengths); out: int32[2 B + 1] device -- the `row_start` argument of the packed forms is this whole array. */
 int mtmp_row_starts(const int32_t* kv_len, int32_t* out, int B, int n_max, void* stream);
 
 #ifdef __cplusplus

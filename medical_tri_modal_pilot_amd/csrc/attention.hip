@@ -38,7 +38,8 @@ template <typename T> struct AttnArgs {
     float scale;
     // PACKED stream (NULL = the padded [B, N] layout): sample b's tokens are rows row_start[b] .. row_start[b] + kv_len[b] of the
     // q / k / v / o / res buffers -- there are no pad rows, so kv_len[b] is also its query count.  N stays the stride of lse
-    // and sizes the grid (workgroups past a sample's rows return at once).
+    // and sizes the grid (workgroups past a sample's rows return at once).  The array is mtmp_row_starts' int32[2 B + 1]:
+    // row_start[B + 1 + i] = the sample that the grid's i-th sample slot works on (length-balanced over the XCDs).
     const int* row_start = nullptr;
 };
 
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
     const AttnArgs<T>& p = grp.seg[seg];
     const int w = wg - grp.first[seg];
     const int nqt = (p.N + FWD_QWG - 1) / FWD_QWG;
-    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
+    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H;
+    const int b = p.row_start ? p.row_start[p.B + 1 + bh / p.H] : bh / p.H;      // packed: samples in mtmp_row_starts' balanced order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
@@ -598,7 +600,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     const AttnBwdArgs<T>& p = grp.seg[seg];
     const int w = wg - grp.first[seg];
     const int nqt = (p.N + 127) >> 7;
-    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H, b = bh / p.H;
+    const int qt = w % nqt, bh = w / nqt, hd = bh % p.H;
+    const int b = p.row_start ? p.row_start[p.B + 1 + bh / p.H] : bh / p.H;      // packed: samples in mtmp_row_starts' balanced order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
@@ -758,7 +761,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     const AttnBwdArgs<T>& p = grp.seg[seg];
     const int w = wg - grp.first[seg];
     const int nkt = (p.N + 127) >> 7;
-    const int kt = w % nkt, bh = w / nkt, hd = bh % p.H, b = bh / p.H;
+    const int kt = w % nkt, bh = w / nkt, hd = bh % p.H;
+    const int b = p.row_start ? p.row_start[p.B + 1 + bh / p.H] : bh / p.H;      // packed: samples in mtmp_row_starts' balanced order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, half = lane >> 5;
     int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;

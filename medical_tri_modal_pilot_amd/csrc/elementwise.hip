@@ -847,8 +847,25 @@ extern "C" int mtmp_stream_lengths(const long long* len_v, const long long* len_
 // kv_len[b] valid rows (bottleneck prefix + CLS + events) are stored back to back with no pad rows in between -- and out[B] =
 // the rows in use.  That last word is what the row-panel / weight-gradient kernels take as `rows_live`; the buffers and
 // the launch grids keep the padded size B * n_max, so a captured hipGraph replays whatever the lengths are.
+// out[B + 1 .. 2 B + 1) = the order in which the attention kernels walk the samples: their grids are cut into eight contiguous
+// chunks, one per XCD (common.cuh xcd_remap), and the cost of a sample grows with the square of its length -- in batch order one
+// XCD gets the eight longest samples of a ragged batch and the launch waits for it.  The samples are ranked by length and
+// dealt round-robin: slot i of XCD x (x = 0..7) holds the sample of rank 8 i + x, so every XCD gets the same mix and starts
+// with its longest samples.
 __global__ __launch_bounds__(256) void row_starts_kernel(const int* kv_len, int* out, int B, int n_max) {
     __shared__ int s[256];
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const int v = min(max(kv_len[b], 0), n_max);
+        int rank = 0;
+        for (int c = 0; c < B; ++c) {
+            const int u = min(max(kv_len[c], 0), n_max);
+            rank += (u > v || (u == v && c < b)) ? 1 : 0;
+        }
+        const int x = rank & 7, j = rank >> 3;
+        int pos = j;                                                  // slots of the XCDs in front of x, then j
+        for (int xx = 0; xx < x; ++xx) pos += (B - xx + 7) >> 3;
+        out[B + 1 + pos] = b;
+    }
     int carry = 0;
     for (int b0 = 0; b0 < B; b0 += 256) {
         const int b = b0 + (int)threadIdx.x;

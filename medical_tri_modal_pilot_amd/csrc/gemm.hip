@@ -443,9 +443,9 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf
     float* sG = reinterpret_cast<float*>(smem_raw + P::stage_off);                  // gamma|beta, prologue only (aliases sS)
     float* sB = reinterpret_cast<float*>(smem_raw + P::bias_off);                   // bias of this workgroup's panels
     const int npanels = p.N / P::NP;
+    const int M = live_rows(p.M, p.m_live);
     const int per = (npanels + gridDim.y - 1) / gridDim.y;
     const int j0 = blockIdx.y * per, j1 = min(npanels, j0 + per);
-    const int M = live_rows(p.M, p.m_live);
     if (j0 >= j1 || bx * BM >= M) return;     // (packed stream: row blocks past the rows in use)
     const int m_wave = bx * BM + wave * 32;
     const int row = min(m_wave + r, M - 1);

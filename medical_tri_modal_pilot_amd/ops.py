@@ -329,7 +329,7 @@ def gemm_tn(dy2d, x2d, want_bias=True, out=None, defer=None, pack=None):
     defer: a list -- the split-M partials are left in the workspace and the reduction is appended to it; dW / db hold the result
     only after reduce_batch(defer) (one launch for all of a layer's reductions).  pack: row_starts() of a packed stream."""
     _gpu(dy2d, x2d)
-    live = None if pack is None else pack.data_ptr() + 4 * (pack.numel() - 1)
+    live = None if pack is None else pack.data_ptr() + 4 * (pack.numel() // 2)
     M, N = dy2d.shape
     K = x2d.shape[1]
     if out is not None:
@@ -408,15 +408,16 @@ def _ints(vs):
 
 # ---- packed token streams (the ragged vital-sign stream without its pad rows) ------------------------------------------
 # A stream is PACKED when its samples' valid rows (bottleneck prefix + CLS + events = kv_len[b]) sit back to back in the
-# [B * N_max, 256] buffers instead of N_max rows apart: `pack` = row_starts(kv_len, N_max), int32[B + 1] on the device --
-# pack[b] = sample b's first row, pack[B] = the rows in use.  Buffers, launch grids and the hipGraph keep the padded size; the
+# [B * N_max, 256] buffers instead of N_max rows apart: `pack` = row_starts(kv_len, N_max), int32[2 B + 1] on the device --
+# pack[b] = sample b's first row, pack[B] = the rows in use, pack[B + 1:] = the attention kernels' sample order.  Buffers, launch grids and the hipGraph keep the padded size; the
 # kernels read the live row count from pack[B] (csrc/common.cuh live_rows) and the attention kernels address samples through
 # pack[b].  Nothing behind the live rows is read or written.
 def row_starts(kv_len, n_max: int):
-    """kv_len int32[B] (device) -> int32[B + 1]: exclusive prefix sums of min(kv_len, n_max), total last."""
+    """kv_len int32[B] (device) -> int32[2 B + 1]: exclusive prefix sums of min(kv_len, n_max), their total, and the
+    length-balanced sample order of the attention grids (csrc/elementwise.hip row_starts_kernel)."""
     _gpu(kv_len)
     B = kv_len.shape[0]
-    out = torch.empty(B + 1, dtype=torch.int32, device=kv_len.device)
+    out = torch.empty(2 * B + 1, dtype=torch.int32, device=kv_len.device)
     call("mtmp_row_starts", _p(kv_len), _p(out), B, int(n_max), _stream())
     return out
 
@@ -432,7 +433,7 @@ def _lives(packs):
     """host array of the rows_live words (pack[B]) of a launch's streams (None: no stream is packed)"""
     if packs is None or all(pk is None for pk in packs):
         return None
-    return (ctypes.c_void_p * len(packs))(*[None if pk is None else pk.data_ptr() + 4 * (pk.numel() - 1) for pk in packs])
+    return (ctypes.c_void_p * len(packs))(*[None if pk is None else pk.data_ptr() + 4 * (pk.numel() // 2) for pk in packs])
 
 
 def attn_fwd_grouped(qkvs, kv_lens, ress, knorms, packs=None):

@@ -1806,7 +1806,18 @@ def test_row_starts(ops):
         out = ops.row_starts(kv.to(DEV), n_max).cpu()
         c = kv.clamp(0, n_max).to(torch.int64)
         ref = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(c, 0)])
-        assert torch.equal(out.to(torch.int64), ref), (B, out[:5], ref[:5])
+        assert torch.equal(out[:B + 1].to(torch.int64), ref), (B, out[:5], ref[:5])
+        # the attention grids' sample order: a permutation; rank r (by length, ties by index) sits in XCD chunk r % 8, slot r // 8
+        order = out[B + 1:].tolist()
+        assert sorted(order) == list(range(B))
+        ranked = sorted(range(B), key=lambda b: (-int(c[b]), b))
+        chunks, pos = [], 0
+        for x in range(8):
+            n_x = (B - x + 7) // 8 if x < B else 0
+            chunks.append(order[pos:pos + n_x])
+            pos += n_x
+        for x in range(8):
+            assert chunks[x] == ranked[x::8], (B, x)
     REPORT["row_starts"] = {"rel_err": 0.0, "tol": 0.0}
 
 

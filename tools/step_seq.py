@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--step", type=int, default=-3)
     ap.add_argument("--window", type=float, nargs=2, default=None)
     ap.add_argument("--families", action="store_true")
+    ap.add_argument("--all-queues", action="store_true", help="with --families: one table per queue, not only the busiest")
     a = ap.parse_args()
     rows = sorted(csv.DictReader(open(a.csv)), key=lambda r: int(r["Start_Timestamp"]))
     idx = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
@@ -29,8 +30,9 @@ def main():
     print("kernels", len(step), "wall us", (int(step[-1]["End_Timestamp"]) - t0) / 1e3, "queues",
           dict(collections.Counter(r["Queue_Id"] for r in step)))
     if a.families:
+      qs = [q for q, _ in collections.Counter(r["Queue_Id"] for r in step).most_common()]
+      for main_q in (qs if a.all_queues else qs[:1]):
         tot, cnt = collections.Counter(), collections.Counter()
-        main_q = collections.Counter(r["Queue_Id"] for r in step).most_common(1)[0][0]
         for r in step:
             if r["Queue_Id"] != main_q:
                 continue
@@ -44,10 +46,10 @@ def main():
                 key = short(n).split("I")[0].split("(")[0][:24]
             tot[key] += d
             cnt[key] += 1
-        print("main queue", main_q, "kernel time us", round(sum(tot.values()), 1))
+        print("main queue" if main_q == qs[0] else "queue", main_q, "kernel time us", round(sum(tot.values()), 1))
         for key, v in tot.most_common(40):
             print(f"{v:9.1f} us n={cnt[key]:4d}  {key}")
-        return
+      return
     for r in step:
         s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
         if a.window and not (a.window[0] <= s <= a.window[1]):
