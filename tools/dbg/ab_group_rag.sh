@@ -3,6 +3,6 @@ O=medical_tri_modal_pilot_amd.ops
 A="--no-cpu-baseline --steps 30 --warmup 10 --probe-launches 0 --instep-steps 0 --workload ragged"
 for r in $(seq 1 ${1:-2}); do
   for m in small all none; do
-    echo -n "GROUP_MODE=$m   "; python tools/dbg/ab_patch.py "$O.GROUP_MODE='$m'" -- $A 2>/dev/null | tail -1 | python -c "import sys,json; print(round(json.loads(sys.stdin.read())['ms_per_step'],3))" || exit 1
+    echo -n "GROUP_MODE=$m   "; python tools/dbg/ab_patch.py "$O.GROUP_MODE='$m'" -- $A 2>/dev/null | tail -1 || exit 1
   done
 done
