@@ -359,6 +359,36 @@ int mtmp_transpose_batch(int elem_bytes, const void* const* src, void* const* ds
  * 3 -> 0; fused = plain + n_bott.  len_*: int64 [B] or NULL (unmasked stream: rows left untouched); out: int32 [2][3][B]. */
 int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const long long* len_t, int* out, int B, int n_bott,
                         int txt_idx, void* stream);
+/* The frozen image encoder on a batch in which some samples have no image.  Their encoder output is read by nothing (the
+ * bottleneck exchange gives the image stream weight 0 for missing_num 2 / 3, mbt_encoder.py:764-779; the reference pushes a zero
+ * image through all of swin_transformer.py:503-654 for them).  mtmp_image_slots moves the present images to the front of the
+ * encoder's batch and tabulates the rows in use per encoder stage; the *_live forms of the encoder's kernels take one word of that
+ * table as `rows_live` (DEVICE pointer, may be NULL = all rows): buffers and grids keep the size of the whole batch, so a captured
+ * hipGraph replays for any number of present images; rows past the live ones are neither read nor written.
+ *   present: uint8[B] device.  out: int32[2 B + 16] device:
+ *     out[i], i < B            slot i of the encoder's batch works on image out[i] (present images first, in batch order)
+ *     out[B + b]               the slot of sample b's image, or B (a slot the caller keeps zero) when it has none
+ *     out[2 B]                 number of present images
+ *     out[2 B + 1 + 5 p + s]   rows in use at stage s = 0..3 (hw0 >> 2 s rows per image; s = 4: one row per image), p = 0: the whole
+ *                              batch, p = 1 / 2: its first / second half of B / 2 slots (the encoder's two-stream tail)
+ * mtmp_swin_stem_fwd_live: `order` (= out, may be NULL) maps slot -> image.  mtmp_swin_window_attn_live: rows_live counts token
+ * rows (live images = *rows_live / (H W)). */
+int mtmp_image_slots(const unsigned char* present, int32_t* out, int B, int hw0, void* stream);
+int mtmp_swin_stem_fwd_live(int dtype, const float* img, const float* w, const float* bias, const float* ln_w, const float* ln_b,
+                            void* out, int n_img, int H, int W, const int32_t* order, const int32_t* rows_live, void* stream);
+int mtmp_layernorm_rows_live(int dtype, const void* x, const float* w, const float* b, void* y, long long rows, int C, float eps,
+                             int merge, int H, int W, const int32_t* rows_live, void* stream);
+int mtmp_swin_ln_linear_live(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w, const float* bias,
+                             void* y, long long M, int C, int N, float eps, const int32_t* rows_live, void* stream);
+int mtmp_swin_mlp_live(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                       const void* w2, const float* b2, const float* row_scale, int rows_per_scale, void* y, long long M, int C,
+                       float eps, const int32_t* rows_live, void* stream);
+int mtmp_swin_window_attn_live(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W, int C, int heads,
+                               int shift, float scale, const int32_t* rows_live, void* stream);
+int mtmp_gemm_nt_live(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N, int K,
+                      int lda, int ldy, int ldr, int act, float drop_p, unsigned seed, const unsigned* seed_dev, const void* gate,
+                      float gate_scale, const float* row_scale, int rows_per_scale, const int32_t* rows_live, void* stream);
+
 /* Row map of a PACKED token stream ("skip padded key tiles and padded query rows"; the reference pads every sample to
  * the batch maximum, trainer.py:41-42, and masks keys, utils.py:79-125): out[b] = sum of min(max(kv_len[0..b), 0), n_max) =
  * sample b's first row when the samples' valid rows are stored back to back; out[B] = the rows in use (the `rows_live` word of

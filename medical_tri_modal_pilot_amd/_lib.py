@@ -27,6 +27,8 @@ SIGNATURES = {
     "mtmp_ln_gemm_qkv": (c_int, [c_int] + [c_void_p] * 9 + [c_int, c_int, c_float, c_void_p]),
     "mtmp_gemm_nt": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_void_p, c_float, c_void_p, c_int,
                              c_void_p]),
+    "mtmp_gemm_nt_live": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 7 + [c_float, c_uint, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                             c_void_p, c_void_p]),
     "mtmp_sign_bits_bytes": (c_longlong, [c_int, c_int]),
     "mtmp_ln_gemm_signs": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 4 + [c_float, c_float, c_uint, c_void_p, c_void_p, c_void_p]),
     "mtmp_gemm_nt_signs": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_float, c_void_p]),
@@ -49,9 +51,12 @@ SIGNATURES = {
     "mtmp_copy_batch": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_stream_lengths": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     "mtmp_row_starts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mtmp_image_slots": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mtmp_transpose_batch": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mtmp_layernorm_rows": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p]),
+    "mtmp_layernorm_rows_live": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mtmp_swin_window_attn": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
+    "mtmp_swin_window_attn_live": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p, c_void_p]),
     "mtmp_gemm_tn_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "mtmp_gemm_tn": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "mtmp_gemm_tn_live": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_void_p]),
@@ -77,8 +82,11 @@ SIGNATURES = {
     "mtmp_bce_logits_mean": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_timestamp": (c_int, [c_void_p, c_void_p]),
     "mtmp_swin_ln_linear": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_void_p]),
+    "mtmp_swin_ln_linear_live": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mtmp_swin_mlp": (c_int, [c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_longlong, c_int, c_float, c_void_p]),
+    "mtmp_swin_mlp_live": (c_int, [c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p]),
     "mtmp_swin_stem_fwd": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
+    "mtmp_swin_stem_fwd_live": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p, c_void_p, c_void_p]),
     "mtmp_adamw_step": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 5 + [c_int, c_float, c_void_p]),
     "mtmp_bottleneck_exchange_fwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mtmp_bottleneck_exchange_bwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

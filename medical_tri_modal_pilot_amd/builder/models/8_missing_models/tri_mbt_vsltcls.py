@@ -266,6 +266,17 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # The frozen encoder itself runs on the image side stream: nothing of the vital-sign stream depends on it before
         # the first bottleneck exchange, so the main stream goes on (TIE embedding, stream input, the vital-sign
         # stream's first layer) beside the encoder's small-M stages, which cannot fill the chip on their own.
+        # Samples without an image (missing_num 2 / 3: the bottleneck exchange gives their image stream weight 0, and this
+        # model reads nothing else of it) are not encoded: the present images take the first slots of the encoder's batch
+        # (ops.image_slots), the others come back as zero features.  The reference encodes a zero image for them.
+        skip = (bool(getattr(self.args, "skip_missing_images", 1)) and img.is_cuda and self.args.multiimages != 1
+                and self.args.img_model_type == "swin" and torch.is_tensor(missing) and missing.dim() == 1)
+
+        def encode(**kw):
+            slots = None
+            if skip:
+                slots = ops.image_slots(missing.to(img.device) < 2, (img.shape[-2] // 4) * (img.shape[-1] // 4))
+            return self.img_encoder(img, slots=slots, **kw)
         if side is not None:
             # stages 1-2 on a third stream, stages 3-4 as two half batches on the two side streams (result valid on side[0])
             if not preforked:                             # (prefork() joined the encoder's stream at the head of the step)
@@ -274,14 +285,14 @@ class TRI_MBT_VSLTCLS(nn.Module):
                 self._swin_stream.wait_stream(cur)
             with torch.cuda.stream(self._swin_stream), torch.no_grad():
                 ops.mark("swin.s")
-                feat = self.img_encoder(img, tail_streams=(side[0], side[1]))
+                feat = encode(tail_streams=(side[0], side[1]))
             side[0].wait_stream(self._swin_stream)        # (already implied when the encoder split its tail)
             with on_side(0):
                 feat = self.flatten(feat)
                 ops.mark("swin.e")
         else:
             with torch.no_grad():
-                feat = self.img_encoder(img)
+                feat = encode()
             feat = self.flatten(feat)
         with on_side(0):
             img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)

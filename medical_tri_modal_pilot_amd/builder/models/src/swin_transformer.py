@@ -16,6 +16,7 @@ the host and cached.  Feature maps whose side is not a multiple of 7 (e.g. --ima
 the reference's zero-padding of windows, which the window kernel does not implement: that case
 raises NotImplementedError.
 """
+import contextlib
 from typing import List
 
 import torch
@@ -256,8 +257,15 @@ class SwinTransformer(nn.Module):
         ev.record(torch.cuda.current_stream())
         self._predrawn_ev = (ev, n)
 
-    def forward(self, x, tail_streams=None):
+    def forward(self, x, tail_streams=None, slots=None):
         """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] in the compute dtype.
+
+        slots = ops.image_slots(present, (H/4)(W/4)): only the PRESENT images are encoded (the reference pushes a zero image
+        through the whole encoder for a sample without one, and nothing reads the result: the bottleneck exchange gives the
+        image stream weight 0 for it).  The present images are processed in the first slots of every buffer, every launch
+        reads its live row count from the slot table (ops.rows_live), and the result comes back in batch order with ZEROS
+        for the samples without an image.  Shapes and grids stay those of the whole batch (hipGraph replay).  A sample's
+        StochasticDepth draws are those of its slot.
 
         tail_streams=(s0, s1): two HIP streams OTHER than the caller's.  Stages 3-4 (12.5 k / 3.1 k tokens for 64 images:
         launches of 15-35 us that cannot fill 256 CUs and are bound by one workgroup's latency chain) then run as two half
@@ -269,7 +277,14 @@ class SwinTransformer(nn.Module):
         drawn = getattr(self, "_predrawn_ev", None)
         if drawn is None:
             draw_row_scales(self, n, x.device)
-        x = ops.swin_stem(x, stem[0].weight, stem[0].bias, stem[2].weight, stem[2].bias, self.compute_dtype)
+        # the slot table is read through raw pointers by launches on this stream AND on the tail streams: it must outlive all of
+        # them (the caching allocator only knows the stream it was made on), so this module keeps it until the next forward
+        self._slots_keepalive = slots
+        live = (lambda part, s: ops.rows_live(slots, 2 * n + 1 + 5 * part + s)) if slots is not None else \
+               (lambda part, s: contextlib.nullcontext())
+        res_of = [0, 1, 1, 2, 2, 3, 3]        # resolution index (rows per image = (H/4)(W/4) >> 2 r) of each feature layer's OUTPUT
+        with live(0, 0):
+            x = ops.swin_stem(x, stem[0].weight, stem[0].bias, stem[2].weight, stem[2].bias, self.compute_dtype, order=slots)
         if drawn is not None:                 # predraw(): the draws were issued on another stream, beside the patch embedding
             if drawn[1] != n:
                 raise RuntimeError("SwinTransformer.predraw() was made for %d images, forward() got %d" % (drawn[1], n))
@@ -277,8 +292,16 @@ class SwinTransformer(nn.Module):
             self._predrawn_ev = None
         layers = list(self.features)[1:]
         split = tail_streams is not None and _SPLIT_TAIL and n >= 16 and n % 2 == 0 and len(layers) == 7
-        for layer in layers[:4] if split else layers:
-            x = layer(x)
+        if slots is not None and len(layers) != 7:
+            raise NotImplementedError("slots: Swin-T layout (four stages) only")
+
+        def finish(out_ext):
+            """[n + 1, ...] with the encoder's result in slots 0..n-1 -> batch order, zeros for samples without an image"""
+            out_ext[n].zero_()
+            return out_ext.index_select(0, slots[n:2 * n])
+        for k, layer in enumerate(layers[:4] if split else layers):
+            with live(0, res_of[k] if slots is not None else 0):
+                x = layer(x)
         if split:
             tail = []                 # (module, per-block scale pairs) in execution order; all draws happen once, here
             for layer in layers[4:]:
@@ -290,8 +313,12 @@ class SwinTransformer(nn.Module):
             s0, s1 = tail_streams
             s0.wait_stream(head)
             s1.wait_stream(head)
+            if slots is not None and not torch.cuda.is_current_stream_capturing():
+                slots.record_stream(s0)
+                slots.record_stream(s1)
             with torch.cuda.stream(s0):       # s0 owns the result: nothing allocated on s1 is read by another stream
-                out = torch.empty(n, x.shape[1] // 2, x.shape[2] // 2, 2 * x.shape[3], dtype=x.dtype, device=x.device)   # one merge left
+                out = torch.empty(n + (slots is not None), x.shape[1] // 2, x.shape[2] // 2, 2 * x.shape[3], dtype=x.dtype,
+                                  device=x.device)   # one merge left
             # (Under rocprofv3 --kernel-trace the second half starts ~600 us after the first, as if serialised; the step's own
             #  one-lane mark kernels -- tools/dbg/timeline.py, no profiler attached -- show both halves starting within 0.1 us
             #  of each other and ending 12 us apart.  Issuing the halves module by module, alternating streams, changes nothing.)
@@ -300,13 +327,23 @@ class SwinTransformer(nn.Module):
                 with torch.cuda.stream(st):
                     ops.mark("swin.tail%d.s" % k)          # (nothing is launched unless marks are enabled)
                     y = x[lo:hi]
-                    for mod, sc in tail:
-                        y = mod(y) if sc is None else mod(y, tuple(None if v is None else v[lo:hi] for v in sc))
-                    ops.layernorm_rows(y, self.norm.weight, self.norm.bias, self.norm.eps, out=out[lo:hi])
+                    for j, (mod, sc) in enumerate(tail):
+                        with live(1 + k, 3 if j >= 6 else 2):      # (six stage-3 blocks; the merge and the two stage-4 blocks write the coarser map)
+                            y = mod(y) if sc is None else mod(y, tuple(None if v is None else v[lo:hi] for v in sc))
+                    with live(1 + k, 3):
+                        ops.layernorm_rows(y, self.norm.weight, self.norm.bias, self.norm.eps, out=out[lo:hi])
                     ops.mark("swin.tail%d.e" % k)
             s0.wait_stream(s1)
+            if slots is not None:
+                with torch.cuda.stream(s0):
+                    return finish(out)
             return out
-        return ops.layernorm_rows(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        if slots is None:
+            return ops.layernorm_rows(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        out = torch.empty(n + 1, *x.shape[1:], dtype=x.dtype, device=x.device)
+        with live(0, 3):
+            ops.layernorm_rows(x, self.norm.weight, self.norm.bias, self.norm.eps, out=out[:n])
+        return finish(out)
 
 
 def swin_t_m(*, weights=None, progress: bool = True, compute_dtype=torch.bfloat16, **kwargs) -> SwinTransformer:

@@ -136,6 +136,10 @@ _BUILD_FLAGS = [
                             help="1: the vital-sign stream runs through the fusion layers PACKED -- its samples' valid rows "
                                  "back to back, no pad rows -- whenever the bf16 kernels and the model allow it (results do "
                                  "not depend on pad rows); 0: the reference's padded [B, T] layout")),
+    (("--skip-missing-images",), dict(type=int, default=1, choices=[0, 1],
+                                      help="1: the frozen image encoder runs on the samples that HAVE an image only (the others' "
+                                           "features are read by nothing); 0: a zero image goes through the encoder as in the "
+                                           "reference")),
     (("--n-images",), dict(type=int, default=3, help="images per sample when --multiimages 1 (reference: 3)")),
     (("--synthetic",), dict(type=int, default=0, choices=[0, 1], help="train on synthetic batches (SURVEY.md §8d)")),
 ]

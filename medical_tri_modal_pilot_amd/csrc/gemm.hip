@@ -1864,10 +1864,22 @@ extern "C" int mtmp_gemm_nt_signs_drop(int dtype, const void* a, const void* w, 
 
 // Y[M,N] = drop(act(A[M,K] W[N,K]^T + bias)) (+ R[M,N]).  Replaces module.py:78-80 + encoder.py:32
 // (Conv1d(1024,256,1) + drop2 + residual) and is the generic NT projection of the path.
+extern "C" int mtmp_gemm_nt_live(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
+                                 int M, int N, int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed,
+                                 const unsigned* seed_dev, const void* gate, float gate_scale, const float* row_scale,
+                                 int rows_per_scale, const int32_t* rows_live, void* stream);
 extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
                             int M, int N, int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed,
                             const unsigned* seed_dev, const void* gate, float gate_scale, const float* row_scale,
                             int rows_per_scale, void* stream) {
+    return mtmp_gemm_nt_live(dtype, a, w, bias, res, y, M, N, K, lda, ldy, ldr, act, drop_p, seed, seed_dev, gate, gate_scale,
+                             row_scale, rows_per_scale, nullptr, stream);
+}
+// rows_live (may be NULL): a device word with the rows in use (<= M), see the grouped forms
+extern "C" int mtmp_gemm_nt_live(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y,
+                                 int M, int N, int K, int lda, int ldy, int ldr, int act, float drop_p, unsigned seed,
+                                 const unsigned* seed_dev, const void* gate, float gate_scale, const float* row_scale,
+                                 int rows_per_scale, const int32_t* rows_live, void* stream) {
     MTMP_CHECK_ARG(a && w && y, "mtmp_gemm_nt: null pointer");
     MTMP_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 32 == 0 && lda >= K && lda % 8 == 0 && ldy >= N &&
                        ldy % 8 == 0 && (!res || (ldr >= N && ldr % 8 == 0)),
@@ -1879,12 +1891,14 @@ extern "C" int mtmp_gemm_nt(int dtype, const void* a, const void* w, const float
         GemmArgs<float> g{(const float*)a, (const float*)w, bias, (const float*)res, (float*)y, nullptr, nullptr,
                           nullptr, nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, seed_dev, (const float*)gate, gate_scale, act, row_scale,
                           rows_per_scale};
+        g.m_live = rows_live;
         return launch_gemm_nt<float>(1, &g, 0, st);
     }
     if (dtype == 1) {
         GemmArgs<bf16> g{(const bf16*)a, (const bf16*)w, bias, (const bf16*)res, (bf16*)y, nullptr, nullptr, nullptr,
                          nullptr, M, N, K, lda, ldy, ldr, 0.f, drop_p, seed, seed_dev, (const bf16*)gate, gate_scale, act, row_scale,
                          rows_per_scale};
+        g.m_live = rows_live;
         return launch_gemm_nt<bf16>(1, &g, 0, st);
     }
     mtmp_set_error("mtmp_gemm_nt: unknown dtype %d", dtype);

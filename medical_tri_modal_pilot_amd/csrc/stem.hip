@@ -23,12 +23,14 @@ template <typename T> MTMP_DEV Frag<T> frag_from_f32(const f32x4& a, const f32x4
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* img, const float* w, const float* bias, const float* ln_w,
-                                                   const float* ln_b, T* out, int n_img, int H, int W) {
+                                                   const float* ln_b, T* out, int n_img, int H, int W, const int* order,
+                                                   const int* rows_live) {
     __shared__ __attribute__((aligned(16))) float sp[3 * C];     // bias | ln_w | ln_b
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     for (int i = tid; i < 3 * C; i += 256) sp[i] = i < C ? bias[i] : (i < 2 * C ? ln_w[i - C] : ln_b[i - 2 * C]);
     const int pw = W >> 2, ph = H >> 2, per_img = pw * ph;
-    const long long total = (long long)n_img * per_img;
+    long long total = (long long)n_img * per_img;
+    if (rows_live) total = min(total, (long long)*rows_live);     // (patches of the slots in use; see mtmp_image_slots)
     Frag<T> wf[3];
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) {
@@ -41,7 +43,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* img, const float
     Frag<T> pf = frag_zero<T>();
     if (ok) {
         const int b = (int)(P / per_img), rem = (int)(P - (long long)b * per_img), pi = rem / pw, pj = rem - pi * pw;
-        const float* src = img + ((size_t)b * H + 4 * pi + 2 * half) * W + 4 * pj;   // rows p = 2*half, 2*half+1
+        const int bs = order ? order[b] : b;                     // slot b holds image order[b] of the batch
+        const float* src = img + ((size_t)bs * H + 4 * pi + 2 * half) * W + 4 * pj;   // rows p = 2*half, 2*half+1
         pf = frag_from_f32<T>(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + W));
     }
     f32x16 acc[3] = {{0}, {0}, {0}};
@@ -85,15 +88,25 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* img, const float
 
 // out[n_img, H/4, W/4, 96] = LayerNorm(Conv2d_4x4s4(img[n_img,1,H,W]) NHWC); weights/params fp32.
 // Replaces swin_transformer.py:559-567 (features[0]) with the 1-channel stem of :646.
+extern "C" int mtmp_swin_stem_fwd_live(int dtype, const float* img, const float* w, const float* bias, const float* ln_w,
+                                       const float* ln_b, void* out, int n_img, int H, int W, const int32_t* order,
+                                       const int32_t* rows_live, void* stream);
 extern "C" int mtmp_swin_stem_fwd(int dtype, const float* img, const float* w, const float* bias, const float* ln_w,
                                   const float* ln_b, void* out, int n_img, int H, int W, void* stream) {
+    return mtmp_swin_stem_fwd_live(dtype, img, w, bias, ln_w, ln_b, out, n_img, H, W, nullptr, nullptr, stream);
+}
+// order (int32[n_img] device, may be NULL): output slot i is made from image order[i]; rows_live (may be NULL): a device word
+// with the patch rows in use (live slots x (H/4)(W/4)) -- mtmp_image_slots: present images first, the rest not computed.
+extern "C" int mtmp_swin_stem_fwd_live(int dtype, const float* img, const float* w, const float* bias, const float* ln_w,
+                                       const float* ln_b, void* out, int n_img, int H, int W, const int32_t* order,
+                                       const int32_t* rows_live, void* stream) {
     MTMP_CHECK_ARG(img && w && bias && ln_w && ln_b && out, "mtmp_swin_stem_fwd: null pointer");
     MTMP_CHECK_ARG(n_img > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0, "mtmp_swin_stem_fwd: bad shape %dx%dx%d", n_img, H, W);
     const long long total = (long long)n_img * (H / 4) * (W / 4);
     const int nb = (int)((total + 127) / 128);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) hipLaunchKernelGGL(stem_kernel<float>, dim3(nb), dim3(256), 0, st, img, w, bias, ln_w, ln_b, (float*)out, n_img, H, W);
-    else if (dtype == 1) hipLaunchKernelGGL(stem_kernel<bf16>, dim3(nb), dim3(256), 0, st, img, w, bias, ln_w, ln_b, (bf16*)out, n_img, H, W);
+    if (dtype == 0) hipLaunchKernelGGL(stem_kernel<float>, dim3(nb), dim3(256), 0, st, img, w, bias, ln_w, ln_b, (float*)out, n_img, H, W, order, rows_live);
+    else if (dtype == 1) hipLaunchKernelGGL(stem_kernel<bf16>, dim3(nb), dim3(256), 0, st, img, w, bias, ln_w, ln_b, (bf16*)out, n_img, H, W, order, rows_live);
     else { mtmp_set_error("mtmp_swin_stem_fwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_swin_stem_fwd");
     return MTMP_OK;

@@ -22,9 +22,10 @@ constexpr float LOG2E = 1.4426950408889634f;
 // A wave is split into 64/G groups of G lanes; a group normalises one row, a lane owns NCH chunks of
 // 8 consecutive channels (16-byte loads/stores).  C = 96 -> 4 rows per wave, 192 -> 2, >= 384 -> 1.
 template <typename T, int G, int NCH>
-__global__ __launch_bounds__(256) void ln_rows_kernel(const T* x, const float* w, const float* b, T* y, long long rows,
-                                                      int C, float eps, int merge, int H, int W) {
+__global__ __launch_bounds__(256) void ln_rows_kernel(const T* x, const float* w, const float* b, T* y, long long rows_max,
+                                                      int C, float eps, int merge, int H, int W, const int* rows_live) {
     constexpr int RPW = 64 / G;
+    const long long rows = rows_live ? min(rows_max, (long long)*rows_live) : rows_max;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gl = lane & (G - 1), grp = lane / G;
     const int chunks = C >> 3;
     const int Cs = merge ? (C >> 2) : C;           // channels of one source pixel
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const T* x, const float* w
 
 template <typename T>
 int launch_ln_rows(const void* x, const float* w, const float* b, void* y, long long rows, int C, float eps, int merge, int H,
-                   int W, hipStream_t st) {
+                   int W, const int* rows_live, hipStream_t st) {
     const int chunks = C / 8;
     int G = 16;
     while (G < chunks && G < 64) G <<= 1;
@@ -100,7 +101,7 @@ int launch_ln_rows(const void* x, const float* w, const float* b, void* y, long 
 #define MTMP_LN_CASE(g, n)                                                                                          \
     if (G == g && nch == n) {                                                                                       \
         hipLaunchKernelGGL((ln_rows_kernel<T, g, n>), dim3(nb), dim3(256), 0, st, (const T*)x, w, b, (T*)y, rows, C, eps, \
-                           merge, H, W);                                                                            \
+                           merge, H, W, rows_live);                                                                 \
         return MTMP_OK;                                                                                             \
     }
     MTMP_LN_CASE(16, 1) MTMP_LN_CASE(32, 1) MTMP_LN_CASE(64, 1) MTMP_LN_CASE(64, 2) MTMP_LN_CASE(64, 3)
@@ -115,8 +116,9 @@ template <> MTMP_DEV void store_pair2<bf16>(bf16* p, bf16 a, bf16 b) { *reinterp
 template <> MTMP_DEV void store_pair2<float>(float* p, float a, float b) { *reinterpret_cast<f32x2*>(p) = f32x2{a, b}; }
 
 template <typename T>
-__global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* table, T* out, int n_img, int H, int W,
-                                                         int C, int heads, int shift, float scale) {
+__global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* table, T* out, int n_img_max, int H, int W,
+                                                         int C, int heads, int shift, float scale, const int* rows_live) {
+    const int n_img = rows_live ? min(n_img_max, *rows_live / (H * W)) : n_img_max;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     T* sVt = reinterpret_cast<T*>(smem_raw) + wave * DH * LDV;          // this wave's [32 d][LDV keys]
@@ -286,9 +288,11 @@ MTMP_DEV void mlp_commit(bf16* s1, bf16* s2, const MlpRegs<C, HP>& g, int tid) {
 template <int C, int HP>
 __global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const float* ln_w, const float* ln_b, const bf16* w1,
                                                           const float* b1, const bf16* w2, const float* b2,
-                                                          const float* row_scale, int rows_per_scale, bf16* y, long long M,
-                                                          float eps) {
+                                                          const float* row_scale, int rows_per_scale, bf16* y, long long M_max,
+                                                          float eps, const int* rows_live) {
     using G = MlpGeom<C, HP>;
+    const long long M = rows_live ? min(M_max, (long long)*rows_live) : M_max;
+    if ((long long)blockIdx.x * 128 >= M) return;                 // (workgroup-uniform, in front of every barrier)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     bf16* sP = reinterpret_cast<bf16*>(smem_raw);                                  // [2][P1 + P2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const f
 template <int C, int HP>
 int launch_swin_mlp(const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1, const void* w2,
                     const float* b2, const float* row_scale, int rows_per_scale, void* y, long long M, float eps,
-                    hipStream_t st) {
+                    const int* rows_live, hipStream_t st) {
     using G = MlpGeom<C, HP>;
     const void* fn = (const void*)swin_mlp_kernel<C, HP>;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes) != hipSuccess) {
@@ -403,7 +407,7 @@ int launch_swin_mlp(const void* x, const float* ln_w, const float* ln_b, const v
         return MTMP_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((swin_mlp_kernel<C, HP>), dim3((unsigned)((M + 127) / 128)), dim3(256), G::lds_bytes, st, (const bf16*)x,
-                       ln_w, ln_b, (const bf16*)w1, b1, (const bf16*)w2, b2, row_scale, rows_per_scale, (bf16*)y, M, eps);
+                       ln_w, ln_b, (const bf16*)w1, b1, (const bf16*)w2, b2, row_scale, rows_per_scale, (bf16*)y, M, eps, rows_live);
     return MTMP_OK;
 }
 
@@ -417,8 +421,10 @@ int launch_swin_mlp(const void* x, const float* ln_w, const float* ln_b, const v
 // 64-byte row pieces.  The next group's weight fragments are requested before the current group's stores.
 template <int C>
 __global__ __launch_bounds__(256, 3) void swin_ln_linear_kernel(const bf16* x, const float* ln_w, const float* ln_b, const bf16* w,
-                                                                const float* bias, bf16* y, long long M, int N, float eps) {
+                                                                const float* bias, bf16* y, long long M_max, int N, float eps,
+                                                                const int* rows_live) {
     constexpr int KC = C / 16, FS = 40;
+    const long long M = rows_live ? min(M_max, (long long)*rows_live) : M_max;
     __shared__ __attribute__((aligned(16))) bf16 stage[4 * 32 * FS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     bf16* sS = stage + wave * 32 * FS;
@@ -494,15 +500,25 @@ __global__ __launch_bounds__(256, 3) void swin_ln_linear_kernel(const bf16* x, c
 // y[rows,C] = LayerNorm(x rows; w, b, eps) in `dtype`; w,b fp32.  merge != 0: x is an NHWC map
 // [n,H,W,C/4] and row (img,i,j) is the patch-merging concat of its 2x2 neighbourhood
 // (swin_transformer.py:34-44, order x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]); rows = n*(H/2)*(W/2).
+// rows_live (every *_live entry; may be NULL): a DEVICE word with the rows in use (<= the row count argument) -- the frozen
+// image encoder on a batch whose present images were moved to the front (mtmp_image_slots): buffers and grids keep the
+// size of the whole batch (a captured hipGraph replays for any number of present images), rows past it are neither read nor
+// written.
+extern "C" int mtmp_layernorm_rows_live(int dtype, const void* x, const float* w, const float* b, void* y, long long rows,
+                                        int C, float eps, int merge, int H, int W, const int32_t* rows_live, void* stream);
 extern "C" int mtmp_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* y, long long rows,
                                    int C, float eps, int merge, int H, int W, void* stream) {
+    return mtmp_layernorm_rows_live(dtype, x, w, b, y, rows, C, eps, merge, H, W, nullptr, stream);
+}
+extern "C" int mtmp_layernorm_rows_live(int dtype, const void* x, const float* w, const float* b, void* y, long long rows,
+                                        int C, float eps, int merge, int H, int W, const int32_t* rows_live, void* stream) {
     MTMP_CHECK_ARG(x && w && b && y && rows > 0, "mtmp_layernorm_rows: bad pointer / rows");
     MTMP_CHECK_ARG(C > 0 && C % 8 == 0 && C <= 1536 && (!merge || (C % 32 == 0 && H % 2 == 0 && W % 2 == 0)),
                    "mtmp_layernorm_rows: bad shape C=%d merge=%d H=%d W=%d", C, merge, H, W);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (dtype == 0) rc = launch_ln_rows<float>(x, w, b, y, rows, C, eps, merge, H, W, st);
-    else if (dtype == 1) rc = launch_ln_rows<bf16>(x, w, b, y, rows, C, eps, merge, H, W, st);
+    if (dtype == 0) rc = launch_ln_rows<float>(x, w, b, y, rows, C, eps, merge, H, W, rows_live, st);
+    else if (dtype == 1) rc = launch_ln_rows<bf16>(x, w, b, y, rows, C, eps, merge, H, W, rows_live, st);
     else { mtmp_set_error("mtmp_layernorm_rows: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     if (rc) return rc;
     MTMP_CHECK_LAUNCH("mtmp_layernorm_rows");
@@ -511,8 +527,15 @@ extern "C" int mtmp_layernorm_rows(int dtype, const void* x, const float* w, con
 
 // out[n,H,W,C] = shifted-window attention of qkv[n,H,W,3C] (q|k|v, head h = 32 columns); window 7,
 // head_dim 32 (C = 32*heads), H % 7 == W % 7 == 0; table [4][heads][64][64] in `dtype` (see header).
+extern "C" int mtmp_swin_window_attn_live(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W,
+                                          int C, int heads, int shift, float scale, const int32_t* rows_live, void* stream);
 extern "C" int mtmp_swin_window_attn(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W,
                                      int C, int heads, int shift, float scale, void* stream) {
+    return mtmp_swin_window_attn_live(dtype, qkv, table, out, n_img, H, W, C, heads, shift, scale, nullptr, stream);
+}
+// (rows_live counts token rows: live images = *rows_live / (H W))
+extern "C" int mtmp_swin_window_attn_live(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W,
+                                          int C, int heads, int shift, float scale, const int32_t* rows_live, void* stream) {
     MTMP_CHECK_ARG(qkv && table && out, "mtmp_swin_window_attn: null pointer");
     MTMP_CHECK_ARG(n_img > 0 && H > 0 && W > 0 && H % WS == 0 && W % WS == 0 && heads > 0 && C == heads * DH && shift >= 0 &&
                        shift < WS, "mtmp_swin_window_attn: bad shape n=%d H=%d W=%d C=%d heads=%d shift=%d", n_img, H, W, C, heads, shift);
@@ -521,10 +544,10 @@ extern "C" int mtmp_swin_window_attn(int dtype, const void* qkv, const void* tab
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         hipLaunchKernelGGL(swin_wattn_kernel<float>, dim3(nb), dim3(256), 4 * DH * LDV * sizeof(float), st, (const float*)qkv,
-                           (const float*)table, (float*)out, n_img, H, W, C, heads, shift, scale);
+                           (const float*)table, (float*)out, n_img, H, W, C, heads, shift, scale, rows_live);
     else if (dtype == 1)
         hipLaunchKernelGGL(swin_wattn_kernel<bf16>, dim3(nb), dim3(256), 4 * DH * LDV * sizeof(bf16), st, (const bf16*)qkv,
-                           (const bf16*)table, (bf16*)out, n_img, H, W, C, heads, shift, scale);
+                           (const bf16*)table, (bf16*)out, n_img, H, W, C, heads, shift, scale, rows_live);
     else { mtmp_set_error("mtmp_swin_window_attn: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH("mtmp_swin_window_attn");
     return MTMP_OK;
@@ -534,15 +557,23 @@ extern "C" int mtmp_swin_window_attn(int dtype, const void* qkv, const void* tab
 // Swin block (swin_transformer.py:428-449; torchvision MLP keys mlp.0 / mlp.3) in one launch.  bf16 only (dtype 1),
 // C = 96 or 192 (stages 1-2; wider stages use mtmp_layernorm_rows + mtmp_gemm_nt); w1 [4C,C], w2 [C,4C] bf16;
 // ln_w, ln_b, b1, b2 fp32; row_scale (per-image StochasticDepth factor) may be NULL; y must not alias x.
+extern "C" int mtmp_swin_mlp_live(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                                  const void* w2, const float* b2, const float* row_scale, int rows_per_scale, void* y,
+                                  long long M, int C, float eps, const int32_t* rows_live, void* stream);
 extern "C" int mtmp_swin_mlp(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
                              const void* w2, const float* b2, const float* row_scale, int rows_per_scale, void* y,
                              long long M, int C, float eps, void* stream) {
+    return mtmp_swin_mlp_live(dtype, x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, C, eps, nullptr, stream);
+}
+extern "C" int mtmp_swin_mlp_live(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1,
+                                  const void* w2, const float* b2, const float* row_scale, int rows_per_scale, void* y,
+                                  long long M, int C, float eps, const int32_t* rows_live, void* stream) {
     MTMP_CHECK_ARG(x && ln_w && ln_b && w1 && b1 && w2 && b2 && y && x != y, "mtmp_swin_mlp: null / aliased pointer");
     MTMP_CHECK_ARG(dtype == 1 && (C == 96 || C == 192) && M > 0 && (!row_scale || rows_per_scale > 0),
                    "mtmp_swin_mlp: bf16 with C = 96 or 192 only (dtype=%d C=%d M=%lld)", dtype, C, M);
     hipStream_t st = (hipStream_t)stream;
-    const int rc = C == 96 ? launch_swin_mlp<96, 64>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, st)
-                           : launch_swin_mlp<192, 32>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, st);
+    const int rc = C == 96 ? launch_swin_mlp<96, 64>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, rows_live, st)
+                           : launch_swin_mlp<192, 32>(x, ln_w, ln_b, w1, b1, w2, b2, row_scale, rows_per_scale, y, M, eps, rows_live, st);
     if (rc) return rc;
     MTMP_CHECK_LAUNCH("mtmp_swin_mlp");
     return MTMP_OK;
@@ -551,8 +582,16 @@ extern "C" int mtmp_swin_mlp(int dtype, const void* x, const float* ln_w, const 
 // y[M,N] = LayerNorm(x[M,C]; ln_w, ln_b, eps) W[N,C]^T + bias: norm1 + the qkv projection of a Swin block
 // (swin_transformer.py:428-449, :115-225) in one launch.  bf16 only (dtype 1), C = 96 or 192, N % 32 == 0; W bf16,
 // ln_w / ln_b / bias fp32 (bias may be NULL).
+extern "C" int mtmp_swin_ln_linear_live(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w,
+                                        const float* bias, void* y, long long M, int C, int N, float eps, const int32_t* rows_live,
+                                        void* stream);
 extern "C" int mtmp_swin_ln_linear(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w,
                                    const float* bias, void* y, long long M, int C, int N, float eps, void* stream) {
+    return mtmp_swin_ln_linear_live(dtype, x, ln_w, ln_b, w, bias, y, M, C, N, eps, nullptr, stream);
+}
+extern "C" int mtmp_swin_ln_linear_live(int dtype, const void* x, const float* ln_w, const float* ln_b, const void* w,
+                                        const float* bias, void* y, long long M, int C, int N, float eps, const int32_t* rows_live,
+                                        void* stream) {
     MTMP_CHECK_ARG(x && ln_w && ln_b && w && y, "mtmp_swin_ln_linear: null pointer");
     MTMP_CHECK_ARG(dtype == 1 && (C == 96 || C == 192) && M > 0 && N > 0 && N % 32 == 0,
                    "mtmp_swin_ln_linear: bf16 with C = 96 or 192 and N %% 32 == 0 only (dtype=%d C=%d N=%d M=%lld)", dtype, C, N, M);
@@ -560,10 +599,10 @@ extern "C" int mtmp_swin_ln_linear(int dtype, const void* x, const float* ln_w, 
     const dim3 grid((unsigned)((M + 127) / 128));
     if (C == 96)
         hipLaunchKernelGGL(swin_ln_linear_kernel<96>, grid, dim3(256), 0, st, (const bf16*)x, ln_w, ln_b, (const bf16*)w, bias,
-                           (bf16*)y, M, N, eps);
+                           (bf16*)y, M, N, eps, rows_live);
     else
         hipLaunchKernelGGL(swin_ln_linear_kernel<192>, grid, dim3(256), 0, st, (const bf16*)x, ln_w, ln_b, (const bf16*)w, bias,
-                           (bf16*)y, M, N, eps);
+                           (bf16*)y, M, N, eps, rows_live);
     MTMP_CHECK_LAUNCH("mtmp_swin_ln_linear");
     return MTMP_OK;
 }

@@ -247,9 +247,9 @@ def gemm_nt(a2d, w, bias=None, res2d=None, act=None, drop_p=0.0, seed=0, gate=No
     M, K = a2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=a2d.dtype, device=a2d.device)
-    call("mtmp_gemm_nt", _dt(a2d), _p(a2d), _p(w), _p(bias), _p(res2d), _p(y), M, N, K, a2d.stride(0), N,
+    call("mtmp_gemm_nt_live", _dt(a2d), _p(a2d), _p(w), _p(bias), _p(res2d), _p(y), M, N, K, a2d.stride(0), N,
          0 if res2d is None else res2d.stride(0), ACT[act], float(drop_p), int(seed) & 0xFFFFFFFF, _p(_seed_word), _p(gate),
-         float(gate_scale), _p(row_scale), int(rows_per_scale), _stream())
+         float(gate_scale), _p(row_scale), int(rows_per_scale), _live(), _stream())
     return y
 
 
@@ -264,13 +264,13 @@ def layernorm_rows(x, w, b, eps=1e-5, merge_hw=None, out=None):
         if out is not None and (out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous()):
             raise ValueError("layernorm_rows: out must be contiguous with x's shape and dtype")
         y = torch.empty_like(x) if out is None else out
-        call("mtmp_layernorm_rows", _dt(x), _p(x), _p(w), _p(b), _p(y), x.numel() // C, C, float(eps), 0, 0, 0, _stream())
+        call("mtmp_layernorm_rows_live", _dt(x), _p(x), _p(w), _p(b), _p(y), x.numel() // C, C, float(eps), 0, 0, 0, _live(), _stream())
         return y
     H, W = merge_hw
     n, Cs = x.shape[0], x.shape[-1]
     y = torch.empty(n, H // 2, W // 2, 4 * Cs, dtype=x.dtype, device=x.device)
-    call("mtmp_layernorm_rows", _dt(x), _p(x), _p(w), _p(b), _p(y), n * (H // 2) * (W // 2), 4 * Cs, float(eps), 1, H, W,
-         _stream())
+    call("mtmp_layernorm_rows_live", _dt(x), _p(x), _p(w), _p(b), _p(y), n * (H // 2) * (W // 2), 4 * Cs, float(eps), 1, H, W,
+         _live(), _stream())
     return y
 
 
@@ -284,8 +284,8 @@ def swin_mlp(x2d, ln_w, ln_b, eps, w1, b1, w2, b2, row_scale=None, rows_per_scal
     x2d = _c(x2d)
     M, C = x2d.shape
     y = torch.empty_like(x2d)
-    call("mtmp_swin_mlp", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w1)), _p(b1), _p(_c(w2)), _p(b2), _p(row_scale),
-         int(rows_per_scale), _p(y), M, C, float(eps), _stream())
+    call("mtmp_swin_mlp_live", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w1)), _p(b1), _p(_c(w2)), _p(b2), _p(row_scale),
+         int(rows_per_scale), _p(y), M, C, float(eps), _live(), _stream())
     return y
 
 
@@ -302,7 +302,8 @@ def swin_ln_linear(x2d, ln_w, ln_b, eps, w, bias):
     M, C = x2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
-    call("mtmp_swin_ln_linear", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), _stream())
+    call("mtmp_swin_ln_linear_live", _dt(x2d), _p(x2d), _p(ln_w), _p(ln_b), _p(_c(w)), _p(bias), _p(y), M, C, N, float(eps), _live(),
+         _stream())
     return y
 
 
@@ -312,8 +313,8 @@ def swin_window_attn(qkv, table, heads, shift):
     n, H, W, C3 = qkv.shape
     C = C3 // 3
     out = torch.empty(n, H, W, C, dtype=qkv.dtype, device=qkv.device)
-    call("mtmp_swin_window_attn", _dt(qkv), _p(qkv), _p(table), _p(out), n, H, W, C, heads, int(shift),
-         float((C // heads) ** -0.5), _stream())
+    call("mtmp_swin_window_attn_live", _dt(qkv), _p(qkv), _p(table), _p(out), n, H, W, C, heads, int(shift),
+         float((C // heads) ** -0.5), _live(), _stream())
     return out
 
 
@@ -404,6 +405,39 @@ def _ptrs(ts, byte_offset=0):
 
 def _ints(vs):
     return (ctypes.c_int * len(vs))(*vs)
+
+
+# ---- rows in use of the frozen image encoder's launches (samples without an image are not computed) -------------------------
+# image_slots(present) moves the present images to the front of the encoder's batch and tabulates, per encoder stage, how many
+# token rows are in use; inside `with rows_live(slots, k):` every row kernel the encoder calls (gemm_nt, layernorm_rows,
+# swin_* below) hands word k of that table to the library as its `rows_live` argument: buffers and grids keep the size of the
+# whole batch (hipGraph replay), rows past the live ones are neither read nor written.
+_LIVE = None
+
+
+@contextlib.contextmanager
+def rows_live(table, index):
+    global _LIVE
+    prev, _LIVE = _LIVE, (None if table is None else (table, int(index)))
+    try:
+        yield
+    finally:
+        _LIVE = prev
+
+
+def _live():
+    return None if _LIVE is None else _LIVE[0].data_ptr() + 4 * _LIVE[1]
+
+
+def image_slots(present, hw0: int):
+    """present: bool / uint8 [B] (device) -> int32[2 B + 16] (csrc/elementwise.hip image_slots_kernel): slot -> image (present
+    first), image -> slot (B for a sample without image), number present, rows in use per (part, stage)."""
+    _gpu(present)
+    B = present.shape[0]
+    pr = present.to(torch.uint8).contiguous()
+    out = torch.empty(2 * B + 16, dtype=torch.int32, device=present.device)
+    call("mtmp_image_slots", _p(pr), _p(out), B, int(hw0), _stream())
+    return out
 
 
 # ---- packed token streams (the ragged vital-sign stream without its pad rows) ------------------------------------------
@@ -610,13 +644,14 @@ def dropout_bwd(g, seed, p):
     return out
 
 
-def swin_stem(img, w, b, ln_w, ln_b, dtype):
+def swin_stem(img, w, b, ln_w, ln_b, dtype, order=None):
     """img [n,1,H,W] fp32 -> [n,H/4,W/4,96] (Conv 4x4/4 + LayerNorm), no gradient (frozen encoder)."""
     _gpu(img, w)
     n, _, H, W = img.shape
     img = _c(img.float())
     out = torch.empty(n, H // 4, W // 4, 96, dtype=dtype, device=img.device)
-    call("mtmp_swin_stem_fwd", _dt(out), _p(img), _p(_c(w)), _p(b), _p(ln_w), _p(ln_b), _p(out), n, H, W, _stream())
+    call("mtmp_swin_stem_fwd_live", _dt(out), _p(img), _p(_c(w)), _p(b), _p(ln_w), _p(ln_b), _p(out), n, H, W, _p(order), _live(),
+         _stream())
     return out
 
 
@@ -1056,7 +1091,7 @@ def grouped_ok(z) -> bool:
     return GROUPED_LAUNCHES and z.dtype == torch.bfloat16
 
 
-def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None):
+def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None, after_attn=None):
     """layer_forward for the active streams of one fusion layer with ONE launch per step (lists, one entry per stream).
     packs: per stream None or the row_starts() tensor of a PACKED stream (its [B, N, 256] buffers then hold the samples' valid
     rows back to back: every kernel below works on pack[B] rows instead of B * N)."""
@@ -1069,6 +1104,8 @@ def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None):
                                                packs)
     qkv = [q.view(B, N, 3 * D) for q, N in zip(qkv, Ns)]
     o, r1, lse = attn_fwd_grouped(qkv, kv_lens, list(zs), knorm, packs)
+    if after_attn is not None:
+        after_attn()
     r1_2 = [r.view(B * N, D) for r, N in zip(r1, Ns)]
     h, xn2, st2, hsign = ln_gemm_signs_grouped(r1_2, [P[8] for P in Ps], [P[9] for P in Ps], [f[2] for f in fuseds],
                                                [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds], packs)
@@ -1170,6 +1207,9 @@ def _exchange_w(dev):
 #   "none"  -- one launch group per stream (vital signs on the caller's stream, image / text on the two side streams)
 # Measured in one box (bench.py, ms/step): see DESIGN.md section 7.
 GROUP_MODE = "small"
+# forward: the image + text group of a layer starts behind the vital-sign stream's attention launch instead of at the head of the
+# layer (its four small launches then run beside the vital-sign stream's FFN kernels, and the attention forward has the chip)
+SIDE_AFTER_ATTN = False
 
 
 def launch_groups(ms, streams, z, solo=False):
@@ -1265,6 +1305,10 @@ class FusionStackFn(torch.autograd.Function):
             if len(groups) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
+            late_fork = SIDE_AFTER_ATTN and len(groups) == 2 and groups[0][1] is None and grouped_ok(z[0]) and li > 0
+
+            def fork_side():
+                ev.record(cur)             # (re-recorded: the side group's wait below sees this later point of the stream)
             for gms, gs in groups:
                 if gs is not None:
                     gs.wait_event(ev)
@@ -1275,7 +1319,8 @@ class FusionStackFn(torch.autograd.Function):
                             [z[m] for m in gms], [cfg["kv"][m] for m in gms],
                             [params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER] for m in gms],
                             [cfg["fused"][li][m] for m in gms], cfg["drop_p"], [cfg["seeds"][li][m] for m in gms],
-                            [pack_v if m == 0 else None for m in gms])
+                            [pack_v if m == 0 else None for m in gms],
+                            after_attn=fork_side if (late_fork and gs is None) else None)
                         for i, m in enumerate(gms):
                             outs[m], row[m] = go[i], gsaved[i]
                     else:

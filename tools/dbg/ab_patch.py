@@ -23,4 +23,6 @@ buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     bench.main()
 d = json.loads([l for l in buf.getvalue().splitlines() if l.startswith("{")][-1])
-print("ms_per_step", round(d["ms_per_step"], 3), "median host", round(d.get("ms_per_step_median_host", 0.0), 3))
+rf = d.get("roofline") or {}
+print("ms_per_step", round(d["ms_per_step"], 3), "median host", round(d.get("ms_per_step_median_host", 0.0), 3),
+      "attn_fwd in-step us", round(1e3 * (rf.get("avg_launch_ms") or 0.0), 1), "frac", round(rf.get("frac") or 0.0, 3))
