@@ -365,7 +365,8 @@ int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const lo
  * encoder's batch and tabulates the rows in use per encoder stage; the *_live forms of the encoder's kernels take one word of that
  * table as `rows_live` (DEVICE pointer, may be NULL = all rows): buffers and grids keep the size of the whole batch, so a captured
  * hipGraph replays for any number of present images; rows past the live ones are neither read nor written.
- *   present: uint8[B] device.  out: int32[2 B + 16] device:
+ *   pattern: int64[B] device, the step's missing_num ids; sample b has an image iff 0 <= pattern[b] < present_below (2 for the
+ *   tri-modal ids: 0 all three, 1 vslt + image).  out: int32[2 B + 16] device:
  *     out[i], i < B            slot i of the encoder's batch works on image out[i] (present images first, in batch order)
  *     out[B + b]               the slot of sample b's image, or B (a slot the caller keeps zero) when it has none
  *     out[2 B]                 number of present images
@@ -373,7 +374,7 @@ int mtmp_stream_lengths(const long long* len_v, const long long* len_i, const lo
  *                              batch, p = 1 / 2: its first / second half of B / 2 slots (the encoder's two-stream tail)
  * mtmp_swin_stem_fwd_live: `order` (= out, may be NULL) maps slot -> image.  mtmp_swin_window_attn_live: rows_live counts token
  * rows (live images = *rows_live / (H W)). */
-int mtmp_image_slots(const unsigned char* present, int32_t* out, int B, int hw0, void* stream);
+int mtmp_image_slots(const long long* pattern, int present_below, int32_t* out, int B, int hw0, void* stream);
 int mtmp_swin_stem_fwd_live(int dtype, const float* img, const float* w, const float* bias, const float* ln_w, const float* ln_b,
                             void* out, int n_img, int H, int W, const int32_t* order, const int32_t* rows_live, void* stream);
 int mtmp_layernorm_rows_live(int dtype, const void* x, const float* w, const float* b, void* y, long long rows, int C, float eps,

@@ -51,7 +51,7 @@ SIGNATURES = {
     "mtmp_copy_batch": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_stream_lengths": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
     "mtmp_row_starts": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "mtmp_image_slots": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mtmp_image_slots": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "mtmp_transpose_batch": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mtmp_layernorm_rows": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p]),
     "mtmp_layernorm_rows_live": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -275,7 +275,8 @@ class TRI_MBT_VSLTCLS(nn.Module):
         def encode(**kw):
             slots = None
             if skip:
-                slots = ops.image_slots(missing.to(img.device) < 2, (img.shape[-2] // 4) * (img.shape[-1] // 4))
+                # missing_num 0: all three modalities, 1: vital signs + image (builder/trainer missing_to_num)
+                slots = ops.image_slots(missing.to(img.device), 2, (img.shape[-2] // 4) * (img.shape[-1] // 4))
             return self.img_encoder(img, slots=slots, **kw)
         if side is not None:
             # stages 1-2 on a third stream, stages 3-4 as two half batches on the two side streams (result valid on side[0])

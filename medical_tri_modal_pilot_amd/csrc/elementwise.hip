@@ -892,19 +892,19 @@ extern "C" int mtmp_row_starts(const int32_t* kv_len, int32_t* out, int B, int n
 }
 
 // Slots of the frozen image encoder for a batch in which some samples have no image (their encoder output is read by nothing:
-// the bottleneck exchange gives the image stream weight 0 for them, mbt_encoder.py:764-779 with missing_num 2 / 3).  present:
-// uint8[B]; out: int32[2 B + 1 + 15]:
+// the bottleneck exchange gives the image stream weight 0 for them, mbt_encoder.py:764-779 with missing_num 2 / 3).  pattern:
+// int64[B] missing_num ids, sample b HAS an image iff pattern[b] < present_below; out: int32[2 B + 1 + 15]:
 //   out[i], i < B          slot i works on image out[i] of the batch (present images first, in batch order)
 //   out[B + b]             the slot of sample b's image, or B (a slot the caller keeps zero) when it has none
 //   out[2 B]               present images
 //   out[2 B + 1 + 5 p + s] rows in use at encoder stage s = 0..3 (hw0 >> 2 s rows per image; s = 4: one row per image) for
 //                          p = 0: the whole batch, p = 1 / 2: its first / second half of B / 2 slots (the two-stream tail)
-__global__ __launch_bounds__(256) void image_slots_kernel(const unsigned char* present, int* out, int B, int hw0) {
+__global__ __launch_bounds__(256) void image_slots_kernel(const long long* pattern, int present_below, int* out, int B, int hw0) {
     __shared__ int s[256];
     int carry = 0;
     for (int b0 = 0; b0 < B; b0 += 256) {
         const int b = b0 + (int)threadIdx.x;
-        const int v = b < B && present[b] ? 1 : 0;
+        const int v = b < B && pattern[b] >= 0 && pattern[b] < present_below ? 1 : 0;
         s[threadIdx.x] = v;
         __syncthreads();
         for (int off = 1; off < 256; off <<= 1) {
@@ -931,10 +931,10 @@ __global__ __launch_bounds__(256) void image_slots_kernel(const unsigned char* p
     }
     if (threadIdx.x == 0) out[2 * B] = live;
 }
-extern "C" int mtmp_image_slots(const unsigned char* present, int32_t* out, int B, int hw0, void* stream) {
-    MTMP_CHECK_ARG(present && out && B > 0 && hw0 > 0 && hw0 % 64 == 0 && (long long)B * hw0 < (1ll << 31),
+extern "C" int mtmp_image_slots(const long long* pattern, int present_below, int32_t* out, int B, int hw0, void* stream) {
+    MTMP_CHECK_ARG(pattern && out && B > 0 && hw0 > 0 && hw0 % 64 == 0 && (long long)B * hw0 < (1ll << 31),
                    "mtmp_image_slots: bad argument (B=%d hw0=%d)", B, hw0);
-    hipLaunchKernelGGL(image_slots_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, present, out, B, hw0);
+    hipLaunchKernelGGL(image_slots_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pattern, present_below, out, B, hw0);
     MTMP_CHECK_LAUNCH("mtmp_image_slots");
     return MTMP_OK;
 }

@@ -429,14 +429,16 @@ def _live():
     return None if _LIVE is None else _LIVE[0].data_ptr() + 4 * _LIVE[1]
 
 
-def image_slots(present, hw0: int):
-    """present: bool / uint8 [B] (device) -> int32[2 B + 16] (csrc/elementwise.hip image_slots_kernel): slot -> image (present
-    first), image -> slot (B for a sample without image), number present, rows in use per (part, stage)."""
-    _gpu(present)
-    B = present.shape[0]
-    pr = present.to(torch.uint8).contiguous()
-    out = torch.empty(2 * B + 16, dtype=torch.int32, device=present.device)
-    call("mtmp_image_slots", _p(pr), _p(out), B, int(hw0), _stream())
+def image_slots(pattern, present_below: int, hw0: int):
+    """pattern: int64[B] missing_num ids (device); sample b has an image iff 0 <= pattern[b] < present_below -> int32[2 B + 16]
+    (csrc/elementwise.hip image_slots_kernel): slot -> image (present first), image -> slot (B for a sample without image),
+    number present, rows in use per (part, stage)."""
+    _gpu(pattern)
+    if pattern.dtype != torch.int64 or not pattern.is_contiguous():
+        pattern = pattern.to(torch.int64).contiguous()
+    B = pattern.shape[0]
+    out = torch.empty(2 * B + 16, dtype=torch.int32, device=pattern.device)
+    call("mtmp_image_slots", _p(pattern), int(present_below), _p(out), B, int(hw0), _stream())
     return out
 
 

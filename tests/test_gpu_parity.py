@@ -1912,7 +1912,7 @@ def test_image_slots(ops):
     for B, hw0 in ((1, 3136), (64, 3136), (300, 64)):
         g = torch.Generator().manual_seed(B)
         pres = torch.rand(B, generator=g) < 0.6
-        out = ops.image_slots(pres.to(DEV), hw0).cpu().tolist()
+        out = ops.image_slots(torch.where(pres, 1, 3).to(DEV), 2, hw0).cpu().tolist()
         live = [b for b in range(B) if pres[b]]
         dead = [b for b in range(B) if not pres[b]]
         assert out[:B] == live + dead
@@ -1946,11 +1946,11 @@ def test_swin_encodes_present_images_only(ops, split):
         torch.cuda.synchronize()
         return f
     full = run(None)
-    part = run(ops.image_slots(pres, 56 * 56))
+    part = run(ops.image_slots(torch.where(pres, 0, 2), 2, 56 * 56))
     assert part.shape == full.shape
     assert torch.equal(part[pres], full[pres])
     assert float(part[~pres].float().abs().max()) == 0.0
-    none = run(ops.image_slots(torch.zeros(B, dtype=torch.bool, device=DEV), 56 * 56))
+    none = run(ops.image_slots(torch.full((B,), 3, dtype=torch.int64, device=DEV), 2, 56 * 56))
     assert float(none.float().abs().max()) == 0.0
     REPORT[f"swin_present_only[split={int(split)}]"] = {"rel_err": 0.0, "tol": 0.0}
 
