@@ -126,7 +126,7 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hip-graph", type=int, default=1, choices=[0, 1])
-    ap.add_argument("--graph-stages", type=int, default=0, help="0 = auto (3 with more than one rank, else 1)")
+    ap.add_argument("--graph-stages", type=int, default=0, help="0 = auto (one graph; with more than one rank two, cut behind the first fusion layer)")
     ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS),
                     help="full = BASELINE configs[1] (the headline number); ragged = configs[3] shape; "
                          "cfg5 = configs[4] (K = 4 images, B 128, TIE-len 2000, 12 layers)")

@@ -131,7 +131,8 @@ _BUILD_FLAGS = [
                                           "(default: it raises -- the eager step is host-bound)")),
     (("--graph-stages",), dict(type=int, default=0,
                                help="number of hipGraphs the captured step is cut into at fusion-layer boundaries "
-                                    "(0 = auto: 3 under --ddp 1 so that the gradient all-reduce overlaps backward, else 1)")),
+                                    "(k > 0: k even groups of layers; 0 = auto: one graph, under --ddp 1 two, cut behind the first fusion layer, so "
+                                    "that the all-reduce of the later layers' gradients overlaps the rest of the backward)")),
     (("--pack-rows",), dict(type=int, default=1, choices=[0, 1],
                             help="1: the vital-sign stream runs through the fusion layers PACKED -- its samples' valid rows "
                                  "back to back, no pad rows -- whenever the bf16 kernels and the model allow it (results do "

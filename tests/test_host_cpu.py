@@ -385,11 +385,12 @@ red = GradReducer(flat, bucket_bytes=1024)
 red.staged = True
 opt = types.SimpleNamespace(flat=flat, zero_grad=flat.zero_grad)
 crit = torch.nn.BCEWithLogitsLoss()
-args = types.SimpleNamespace(graph_stages=0, vslt_type="TIE")
+args = types.SimpleNamespace(graph_stages=3, vslt_type="TIE")
 enc = net.fusion_transformer
+assert T._stage_bounds(types.SimpleNamespace(graph_stages=0, vslt_type="TIE"), enc, True) == [0, 1, L]   # DDP default: one cut behind layer 0
 bounds = T._stage_bounds(args, enc, True)
 assert bounds == [0, 2, 4, 6], bounds
-assert len(T._stage_bounds(args, enc, False)) == 2                 # single rank: one graph
+assert len(T._stage_bounds(types.SimpleNamespace(graph_stages=0, vslt_type="TIE"), enc, False)) == 2   # single rank: one graph
 enc.graph_segments = bounds[1:-1]
 g = torch.Generator().manual_seed(3)
 xs = [torch.randn(4, 7, 5, generator=g) for _ in range(world)]
