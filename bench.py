@@ -69,7 +69,7 @@ WORKLOADS = {
 }
 
 
-def make_args(wl, dtype: str, dropout: float, hip_graph: int, graph_stages: int, ddp: bool):
+def make_args(wl, dtype: str, dropout: float, hip_graph: int, graph_stages: int, ddp: bool, pack_rows: int = 1, skip_img: int = 1):
     from medical_tri_modal_pilot_amd.control.config import parse_args
     B, T, L, multi, K = WORKLOADS[wl][:5]
     return parse_args(["--input-types", "vslt_img_txt", "--model", "tri_mbt_vsltcls", "--modality-inclusion",
@@ -78,7 +78,7 @@ def make_args(wl, dtype: str, dropout: float, hip_graph: int, graph_stages: int,
                        "--model-types", "detection", "--imgtxt-time", "1", "--mbt-only-vslt", "1", "--multiimages", str(multi),
                        "--n-images", str(max(K, 1)), "--dropout", str(dropout), "--compute-dtype", dtype,
                        "--hip-graph", str(hip_graph), "--graph-stages", str(graph_stages), "--ddp", str(int(ddp)),
-                       "--synthetic", "1"])
+                       "--pack-rows", str(pack_rows), "--skip-missing-images", str(skip_img), "--synthetic", "1"])
 
 
 def cpu_baseline(wl, shapes, budget_s: float = 150.0):
@@ -132,6 +132,10 @@ def parse():
                          "cfg5 = configs[4] (K = 4 images, B 128, TIE-len 2000, 12 layers)")
     ap.add_argument("--packed", type=int, default=0, choices=[0, 1],
                     help="feed the vital-sign events as the ragged PackedTieBatch of builder/data (SURVEY 8 f-1)")
+    ap.add_argument("--pack-rows", type=int, default=1, choices=[0, 1],
+                    help="0: the reference's padded [B, T] layout in the fusion layers (what the ragged workload is compared with)")
+    ap.add_argument("--skip-missing-images", type=int, default=1, choices=[0, 1],
+                    help="0: a zero image goes through the frozen encoder for samples without one, as in the reference")
     ap.add_argument("--probe-launches", type=int, default=30,
                     help="back-to-back launches per kernel of the idle-device probe after the timed region (0 = no probe)")
     ap.add_argument("--instep-steps", type=int, default=12,
@@ -199,7 +203,7 @@ def main():
     from medical_tri_modal_pilot_amd.train import _Logger, build_training
 
     B_PER_GPU, TIE_LEN, LAYERS, multi, n_img, ragged, miss_mode, wl_text = WORKLOADS[a.workload]
-    args = make_args(a.workload, a.dtype, a.dropout, a.hip_graph, a.graph_stages, ddp)
+    args = make_args(a.workload, a.dtype, a.dropout, a.hip_graph, a.graph_stages, ddp, a.pack_rows, a.skip_missing_images)
     torch.manual_seed(412)
     model, opt, crit = build_training(args, dev, ddp)
     model.train()
@@ -399,7 +403,9 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
             "rccl_ranks": dist.get_world_size() if ddp else 1,
             "config": {"workload": wl_text + f", dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1"
-                                   + (" -- events fed as PackedTieBatch" if a.packed else ""),
+                                   + (" -- events fed as PackedTieBatch" if a.packed else "")
+                                   + ("" if a.pack_rows else " -- padded fusion stack (--pack-rows 0)")
+                                   + ("" if a.skip_missing_images else " -- zero images encoded (--skip-missing-images 0)"),
                        "global_batch": world * B_PER_GPU, "parallelism": f"dp{world}", "final_loss": loss},
             "roofline": rf,
         }

@@ -11,6 +11,12 @@ if [ "$2" != "quick" ]; then
   tail -1 $O/${T}_bench.json | cut -c1-300
   python bench.py --no-cpu-baseline --force-ddp > $O/${T}_bench_ddp1.json 2> $O/${T}_bench_ddp1.err || { tail -5 $O/${T}_bench_ddp1.err; exit 1; }
   tail -1 $O/${T}_bench_ddp1.json | cut -c1-200
+  for w in ragged cfg5; do
+    python bench.py --no-cpu-baseline --workload $w --steps 20 --warmup 6 > $O/${T}_bench_$w.json 2> $O/${T}_bench_$w.err || { tail -5 $O/${T}_bench_$w.err; exit 1; }
+    tail -1 $O/${T}_bench_$w.json | cut -c1-200
+  done
+  python bench.py --no-cpu-baseline --workload ragged --steps 20 --warmup 6 --probe-launches 0 --instep-steps 0 --pack-rows 0 --skip-missing-images 0 > $O/${T}_bench_ragged_padded.json 2> /dev/null
+  tail -1 $O/${T}_bench_ragged_padded.json | cut -c1-200
   python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 fi
 cd /tmp && export TMPDIR=/tmp
