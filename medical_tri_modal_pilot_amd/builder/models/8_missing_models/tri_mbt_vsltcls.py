@@ -329,7 +329,10 @@ class TRI_MBT_VSLTCLS(nn.Module):
             varying_lengths=[input_lengths, img_len, txt_lengths + 2], fusion_idx=None, missing=missing)
         if side is not None:
             cur.wait_stream(self._swin_stream)            # joins the encoder's stream to the caller's (its work ended long ago)
-        # ---- head (:248-255), fp32
+        return self._head(outputs, demo_embedding if not fused_head else None, age, gen, missing, fused_head)
+
+    def _head(self, outputs, demo_embedding, age, gen, missing, fused_head):
+        """The classifier on the encoder's result (:248-255), fp32 -- a hook: sibling models read other rows."""
         cls = self.fusion_transformer.last_cls             # outputs[0][:, 0, :] as a dedicated autograd output
         cls = (outputs[0][:, 0, :] if cls is None else cls).float()
         ops.mark("stack.e")

@@ -283,6 +283,8 @@ def gen_siblings():
         m[0], m[1] = 0, 1                                # both branches of the per-sample mix are exercised
         return m
     _sibling_step("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg", fold_img, False)
+    # TRI_MBT_V1 (tri_mbt_v1.py:17-283): all three CLS rows, LayerNorm head, per-sample mean over the present modalities
+    _sibling_step("tri_mbt_v1", "vslt_img_txt", "tri_v1", lambda m: m, True)
 
 
 # ------------------------------------------------------------------------ g6
