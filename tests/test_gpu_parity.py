@@ -1966,3 +1966,34 @@ def test_training_steps_do_not_depend_on_features_of_missing_images(ops):
         assert torch.equal(res[1, gr][1], res[0, gr][1])
     assert res[1, 1][2].captures == 1 and res[1, 1][2].replays == 3
     REPORT["skip_missing_images.steps"] = {"rel_err": 0.0, "tol": 0.0}
+
+
+def test_packed_stream_under_staged_graphs_and_packed_events(ops):
+    """The packed vital-sign stream (bf16) in the other step forms: (i) the step cut into two / three chained graphs as under
+    DDP -- the packed buffers and the row map cross the cut; bit-identical to the one-graph step; (ii) eval-mode forward
+    (flow_type "test", no autograd graph): same logits packed and padded."""
+    lens = [[96, 50, 7, 1], [96, 96, 96, 96], [3, 96, 20, 64], [96, 1, 1, 2]]
+    l1, p1, _ = _loop(1, 0.0, "bf16", 4, lens, L=4, graph_stages=1)
+    assert _loop.last_packed
+    for stages in (2, 3):
+        ls, ps, gs = _loop(1, 0.0, "bf16", 4, lens, L=4, graph_stages=stages)
+        assert _loop.last_packed and [len(e["graphs"]) for e in gs.entries.values()] == [stages]
+        assert ls == l1, (stages, ls, l1)
+        assert torch.equal(ps, p1)
+    REPORT["packed_staged_graphs_vs_single[bf16]"] = {"rel_err": 0.0, "tol": 0.0}
+    # (ii) eval forward, packed against padded
+    outs = {}
+    for pack in (0, 1):
+        torch.manual_seed(7)
+        args, model = _product_model(2, 0, "bf16", pack_rows=pack)
+        model.eval()
+        bt = filler.make_batch(901, 4, 96, ragged=True, missing_mode="mixed")
+        bt["input_lengths"] = torch.tensor([96, 50, 7, 1])
+        dv = lambda t: t.to(DEV)
+        with torch.no_grad():
+            out, _, _ = model(dv(bt["x"]), None, None, None, None, dv(bt["age"]), dv(bt["gen"]), dv(bt["input_lengths"]),
+                              dv(bt["txt"]), dv(bt["txt_lengths"]), dv(bt["img"]), dv(bt["missing_num"]), None,
+                              dv(bt["img_time"].half().float()), dv(bt["txt_time"].half().float()), "test", None, None)
+        assert (model.fusion_transformer.last_pack is not None) == bool(pack)
+        outs[pack] = out.float()
+    check("packed_eval_logits[bf16]", outs[1], outs[0], 1e-3)
