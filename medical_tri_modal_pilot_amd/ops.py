@@ -1093,7 +1093,7 @@ def grouped_ok(z) -> bool:
     return GROUPED_LAUNCHES and z.dtype == torch.bfloat16
 
 
-def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None, after_attn=None):
+def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None):
     """layer_forward for the active streams of one fusion layer with ONE launch per step (lists, one entry per stream).
     packs: per stream None or the row_starts() tensor of a PACKED stream (its [B, N, 256] buffers then hold the samples' valid
     rows back to back: every kernel below works on pack[B] rows instead of B * N)."""
@@ -1106,8 +1106,6 @@ def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None, af
                                                packs)
     qkv = [q.view(B, N, 3 * D) for q, N in zip(qkv, Ns)]
     o, r1, lse = attn_fwd_grouped(qkv, kv_lens, list(zs), knorm, packs)
-    if after_attn is not None:
-        after_attn()
     r1_2 = [r.view(B * N, D) for r, N in zip(r1, Ns)]
     h, xn2, st2, hsign = ln_gemm_signs_grouped(r1_2, [P[8] for P in Ps], [P[9] for P in Ps], [f[2] for f in fuseds],
                                                [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds], packs)
@@ -1209,9 +1207,6 @@ def _exchange_w(dev):
 #   "none"  -- one launch group per stream (vital signs on the caller's stream, image / text on the two side streams)
 # Measured in one box (bench.py, ms/step): see DESIGN.md section 7.
 GROUP_MODE = "small"
-# forward: the image + text group of a layer starts behind the vital-sign stream's attention launch instead of at the head of the
-# layer (its four small launches then run beside the vital-sign stream's FFN kernels, and the attention forward has the chip)
-SIDE_AFTER_ATTN = False
 
 
 def launch_groups(ms, streams, z, solo=False):
@@ -1307,10 +1302,6 @@ class FusionStackFn(torch.autograd.Function):
             if len(groups) > 1:
                 ev = torch.cuda.Event()
                 ev.record(cur)
-            late_fork = SIDE_AFTER_ATTN and len(groups) == 2 and groups[0][1] is None and grouped_ok(z[0]) and li > 0
-
-            def fork_side():
-                ev.record(cur)             # (re-recorded: the side group's wait below sees this later point of the stream)
             for gms, gs in groups:
                 if gs is not None:
                     gs.wait_event(ev)
@@ -1321,8 +1312,7 @@ class FusionStackFn(torch.autograd.Function):
                             [z[m] for m in gms], [cfg["kv"][m] for m in gms],
                             [params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER] for m in gms],
                             [cfg["fused"][li][m] for m in gms], cfg["drop_p"], [cfg["seeds"][li][m] for m in gms],
-                            [pack_v if m == 0 else None for m in gms],
-                            after_attn=fork_side if (late_fork and gs is None) else None)
+                            [pack_v if m == 0 else None for m in gms])
                         for i, m in enumerate(gms):
                             outs[m], row[m] = go[i], gsaved[i]
                     else:
