@@ -729,7 +729,14 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf
 template <typename T, bool RELU, int TM, bool DROP>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (TM == 64 ? 3 : 4) : 1)) void gemm_nt_kernel(Grouped<GemmArgs<T>> grp) {
     using G = NtGeom<TM>;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    int wg = xcd_remap(blockIdx.x, gridDim.x);
+    if (grp.first[1] >= (int)gridDim.x && grp.seg[0].m_live) {
+        // one packed stream alone in the grid: the XCD chunks are cut over the tiles of the LIVE rows -- cut over the whole grid,
+        // the live tiles (the front of the work list) would all land on the first XCDs (half the rows in use: half the chip idle)
+        const int live = ((live_rows(grp.seg[0].M, grp.seg[0].m_live) + TM - 1) / TM) * ((grp.seg[0].N + BN - 1) / BN);
+        if ((int)blockIdx.x >= live) return;
+        wg = xcd_remap(blockIdx.x, live);
+    }
     const int seg = grp_find(grp, wg);
     const GemmArgs<T>& p = grp.seg[seg];
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
