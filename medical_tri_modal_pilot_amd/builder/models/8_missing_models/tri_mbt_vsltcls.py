@@ -239,6 +239,12 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # head + ie_demo as six HIP launches (ops.HeadFn) when the demographic embedding feeds nothing but the head
         fused_head = (self.head_fusable and age.is_cuda and B <= ops.HEAD_MAX_B and self.args.vslt_type != "QIE"
                       and "rmse" not in self.args.auxiliary_loss_type and (B > 1 or not self.training))
+        if (not fused_head and self.head_fusable and age.is_cuda and self.training and not getattr(self, "_warned_torch_head", False)
+                and self.args.vslt_type != "QIE" and "rmse" not in self.args.auxiliary_loss_type):
+            import warnings
+            self._warned_torch_head = True
+            warnings.warn(f"TRI_MBT_VSLTCLS: batch of {B} is outside the fused head kernels' range (2 <= B <= {ops.HEAD_MAX_B} in "
+                          "training): the classifier head runs as torch ops (same results, ~60 more small launches per step)")
         if not fused_head:
             demographic = torch.stack([age, gen], dim=1)
             demo_embedding = self.ie_demo(demographic)                                        # [B,256] fp32
