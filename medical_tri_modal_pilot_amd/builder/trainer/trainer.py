@@ -222,7 +222,9 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         train_x = train_x.permute(1, 0, 2, 3)
         data = train_x[0].half().float().to(device, non_blocking=True)
     else:
-        max_len = int(torch.max(input_lengths))                               # ragged trim, trainer.py:41-42
+        # ragged trim, trainer.py:41-42 (at least one row: a batch of all-empty windows keeps one pad event behind kv_len --
+        # pad rows feed nothing -- instead of zero-length launches)
+        max_len = max(1, int(torch.max(input_lengths)))
         if _use_graph(args, flow_type, device, optimizer, scaler):
             max_len = min(train_x.shape[1], -(-max_len // GRAPH_LEN_BUCKET) * GRAPH_LEN_BUCKET)
         data = fp16_round(train_x[:, :max_len, :], "data")                    # 2_train.py:164

@@ -1839,7 +1839,8 @@ def _unpack_rows(t, kv, pack):
     return out
 
 
-@pytest.mark.parametrize("N,lens", [(200, [200, 5, 64, 129, 1, 77]), (1005, [1005, 6, 700, 333]), (300, [300] * 3)])
+@pytest.mark.parametrize("N,lens", [(200, [200, 5, 64, 129, 1, 77]), (1005, [1005, 6, 700, 333]), (300, [300] * 3), (70, [1]),
+                                    (133, [5, 133, 64, 65, 1, 128, 129, 2, 97]), (64, [1] * 11)])
 def test_packed_layer_equals_padded_layer(ops, N, lens):
     """One encoder layer of the grouped bf16 kernels on a PACKED stream (valid rows back to back, every row behind them NaN) against
     the same layer on the padded [B, N] layout: outputs and input gradients on the valid rows, parameter gradients.  The row-panel
@@ -1997,3 +1998,55 @@ def test_packed_stream_under_staged_graphs_and_packed_events(ops):
         assert (model.fusion_transformer.last_pack is not None) == bool(pack)
         outs[pack] = out.float()
     check("packed_eval_logits[bf16]", outs[1], outs[0], 1e-3)
+
+
+def test_packed_steps_with_empty_windows_and_four_images(ops):
+    """Edge cases of the packed vital-sign stream through get_trainer (bf16, eager + graph): samples with NO event at all (their
+    stream is bottleneck prefix + CLS, five rows), a batch of all-empty windows, and --multiimages 1 with K = 4 (the image
+    stream carries its own key lengths): losses as with --pack-rows 0."""
+    lens = [[0, 50, 0, 1], [0, 0, 0, 0], [96, 0, 20, 64]]
+    for over in (dict(), dict(multiimages=1, n_images=4)):
+        res = {}
+        for pack in (0, 1):
+            for graph in (0, 1):
+                if over:
+                    args_over = dict(over)
+                    ls, ps, _ = _loop_multi(graph, lens, pack, **args_over)
+                else:
+                    ls, ps, _ = _loop(graph, 0.0, "bf16", 3, lens, pack_rows=pack)
+                    assert _loop.last_packed == bool(pack)
+                res[pack, graph] = (ls, ps)
+        for graph in (0, 1):
+            worst = max(abs(a - b) for a, b in zip(res[1, graph][0], res[0, graph][0]))
+            REPORT[f"packed_edge_cases[{'K4' if over else 'empty'},graph={graph}].loss"] = {"rel_err": worst, "tol": 2e-3}
+            assert all(math.isfinite(v) for v in res[1, graph][0]) and worst < 2e-3, (res[1, graph][0], res[0, graph][0])
+            assert float((res[1, graph][1] - res[0, graph][1]).abs().max()) < 8e-4
+        assert res[1, 0][0] == res[1, 1][0]
+
+
+def _loop_multi(hip_graph, lens_per_step, pack, **over):
+    """_loop for --multiimages 1 (the synthetic batch then carries K images per sample)"""
+    from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
+    from medical_tri_modal_pilot_amd.builder.utils.cosine_annealing_with_warmup_v2 import CosineAnnealingWarmupRestarts
+    from medical_tri_modal_pilot_amd.optim import FusedAdamW
+    torch.manual_seed(7)
+    K = over.get("n_images", 3)
+    args, model = _product_model(2, 1, "bf16", hip_graph=hip_graph, dropout=0.0, pack_rows=pack, n_images=K)
+    model.train()
+    model.img_encoder.eval()
+    opt = FusedAdamW(model.hot_parameters(), lr=1e-4, weight_decay=args.weight_decay)
+    sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=100, cycle_mult=1, max_lr=1e-3, min_lr=1e-6, warmup_steps=10, gamma=1.0)
+    crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
+    losses = []
+    for it, lens in enumerate(lens_per_step):
+        bt = filler.make_batch(900 + it, 4, 96, ragged=True, missing_mode="mixed" if it % 2 else "none", multiimages=1, n_images=K)
+        bt["input_lengths"] = torch.tensor(lens)
+        static = torch.stack([bt["gen"], bt["age"]], 1)
+        _, loss = get_trainer(args=args, iteration=it + 1, x=bt["x"], static=static, y=bt["y"], output_lengths=None, model=model,
+                              logger=_Logger(), device=torch.device(DEV), scheduler=sched, optimizer=opt, criterion=crit,
+                              x_txt=bt["txt"], x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None,
+                              missing=bt["missing"], input_lengths=bt["input_lengths"], txt_lengths=bt["txt_lengths"],
+                              flow_type="train", reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
+        losses.append(loss)
+    assert (model.fusion_transformer.last_pack is not None) == bool(pack)
+    return losses, opt.flat.data.detach().clone(), getattr(model, "_mtmp_graph_step", None)
