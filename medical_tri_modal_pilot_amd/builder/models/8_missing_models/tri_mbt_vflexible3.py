@@ -1,0 +1,7 @@
+"""TRI_MBT_VFLEXIBLE3 -- TRI_MBT_VFLEXIBLE with softmax temperature 3.334
+(builder/models/8_missing_models/tri_mbt_vflexible3.py:279)."""
+from .tri_mbt_vflexible import TRI_MBT_VFLEXIBLE
+
+
+class TRI_MBT_VFLEXIBLE3(TRI_MBT_VFLEXIBLE):
+    flex_temperature = 3.334

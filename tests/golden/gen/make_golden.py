@@ -285,6 +285,12 @@ def gen_siblings():
     _sibling_step("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg", fold_img, False)
     # TRI_MBT_V1 (tri_mbt_v1.py:17-283): all three CLS rows, LayerNorm head, per-sample mean over the present modalities
     _sibling_step("tri_mbt_v1", "vslt_img_txt", "tri_v1", lambda m: m, True)
+    # TRI_MBT_VFLEXIBLE / 2 / 3 (tri_mbt_vflexible*.py): V1 with learned softmax weights over the present modalities (temperature
+    # 1 / 10 / 3.334).  Their __init__ builds mask tensors with .cuda(): patched to identity for the CPU run.  flexibleavg starts
+    # at zeros in the reference; the filler gives it distinct values so that the softmax is not uniform.
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    for name, tag in (("tri_mbt_vflexible", "tri_vflex"), ("tri_mbt_vflexible2", "tri_vflex2"), ("tri_mbt_vflexible3", "tri_vflex3")):
+        _sibling_step(name, "vslt_img_txt", tag, lambda m: m, False)
 
 
 # ------------------------------------------------------------------------ g6
