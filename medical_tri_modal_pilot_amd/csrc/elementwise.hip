@@ -856,8 +856,8 @@ __global__ __launch_bounds__(256) void row_starts_kernel(const int* kv_len, int*
     __shared__ int s[256];
     for (int b = threadIdx.x; b < B; b += 256) {
         const int v = min(max(kv_len[b], 0), n_max);
-        int rank = 0;
-        for (int c = 0; c < B; ++c) {
+        int rank = B > 2048 ? b : 0;                                  // (ranking is O(B^2) in one workgroup: batch order beyond that)
+        for (int c = 0; c < (B > 2048 ? 0 : B); ++c) {
             const int u = min(max(kv_len[c], 0), n_max);
             rank += (u > v || (u == v && c < b)) ? 1 : 0;
         }
