@@ -2,8 +2,7 @@
 (builder/models/8_missing_models/bi_vslttxt_mbt_v1.py:17-183): vital-sign / lab events (TIE / UMSE
 embedding) and clinical text (Linear on BioBERT embeddings + time / modality embedding) fused by
 BimodalTransformerEncoder_MBT, CLS vectors mixed per sample by ``missing`` (0: mean of both, 1: vital signs alone), the
-same classifier head.  Of the 25 sibling files of 8_missing_models this is the one whose ``forward`` returns (every
-other one ends in ``exit(1)``).  Same constructor, forward signature, return triple and state_dict keys as the reference;
+same classifier head.  Same constructor, forward signature, return triple and state_dict keys as the reference;
 ``--input-types vslt_txt`` (the trainer then folds the four modality patterns onto {0, 1}, trainer.py:99-101).
 
 Differences from the reference file, all forced: ``output`` keeps the reference's ``.squeeze()`` ([B]); only
@@ -89,6 +88,10 @@ class BI_VSLTTXT_MBT_V1(nn.Module):
         outputs, _ = self.fusion_transformer(
             enc_outputs=[vslt_embedding, txt_embedding], fixed_lengths=[vslt_embedding.size(1), txt_embedding.size(1)],
             varying_lengths=[input_lengths, txt_lengths + 2], fusion_idx=None, missing=missing)
+        return self._head(outputs, age, gen, missing, B)
+
+    def _head(self, outputs, age, gen, missing, B):
+        """The classifier on the two CLS rows -- a hook: sibling models mix them differently."""
         # per-sample CLS mix (:171-174): mean of both streams' CLS rows, or the vital-sign CLS alone
         c0, c1 = outputs[0][:, 0, :].float(), outputs[1][:, 0, :].float()
         cls = torch.where((missing == 0).unsqueeze(1), torch.stack([c0, c1]).mean(0), c0)

@@ -292,6 +292,16 @@ def gen_siblings():
     for name, tag in (("tri_mbt_vflexible", "tri_vflex"), ("tri_mbt_vflexible2", "tri_vflex2"), ("tri_mbt_vflexible3", "tri_vflex3")):
         _sibling_step(name, "vslt_img_txt", tag, lambda m: m, False)
 
+    def fold_txt(m):                                     # trainer.py:99-101 (input_types == "vslt_txt"): 2 -> 0, {1, 3} -> 1
+        m = m.clone()
+        m[m == 1] = 3
+        m[m == 2] = 0
+        m[m == 3] = 1
+        m[0], m[1] = 0, 1
+        return m
+    # BITXT_MBT_VFLEXIBLE1 (bitxt_mbt_vflexible1.py:17-200): the two-stream encoder with the flexible head
+    _sibling_step("bitxt_mbt_vflexible1", "vslt_txt", "bitxt_vflex1", fold_txt, False)
+
 
 # ------------------------------------------------------------------------ g6
 def build_model(args):
