@@ -102,6 +102,10 @@ class BI_VSLTIMG_MBT_V1(nn.Module):
         outputs, _ = self.fusion_transformer(
             enc_outputs=[vslt_embedding, img_embedding], fixed_lengths=[vslt_embedding.size(1), img_embedding.size(1)],
             varying_lengths=[input_lengths, img_embedding.size(1)], fusion_idx=None, missing=missing)
+        return self._head(outputs, demo_embedding, missing)
+
+    def _head(self, outputs, demo_embedding, missing):
+        """The classifier on the two CLS rows -- a hook: sibling models weight them differently."""
         # head on both CLS rows (:230-235), then the per-sample mix of the two logits (:245-247)
         cls2 = torch.stack([outputs[0][:, 0, :], outputs[1][:, 0, :]]).float()              # [2,B,256]
         class_input = torch.cat([self.layer_norms_after_concat(cls2).reshape(-1, self.model_dim),

@@ -301,6 +301,8 @@ def gen_siblings():
         return m
     # BITXT_MBT_VFLEXIBLE1 (bitxt_mbt_vflexible1.py:17-200): the two-stream encoder with the flexible head
     _sibling_step("bitxt_mbt_vflexible1", "vslt_txt", "bitxt_vflex1", fold_txt, False)
+    # BIIMG_MBT_VFLEXIBLE1 (biimg_mbt_vflexible1.py:17-262): the same with the frozen CXR encoder as the second stream
+    _sibling_step("biimg_mbt_vflexible1", "vslt_img", "biimg_vflex1", fold_img, False)
 
 
 # ------------------------------------------------------------------------ g6
