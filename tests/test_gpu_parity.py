@@ -2054,3 +2054,23 @@ def _loop_multi(hip_graph, lens_per_step, pack, **over):
         losses.append(loss)
     assert (model.fusion_transformer.last_pack is not None) == bool(pack)
     return losses, opt.flat.data.detach().clone(), getattr(model, "_mtmp_graph_step", None)
+
+
+def test_packed_full_size_steps_match_padded(ops):
+    """The packed stream at the benchmark's size (B 64, T 1000, 6 layers, bf16, hipGraph replay, ragged lengths that change from
+    step to step under one captured graph, mixed missing modalities): the grouped LDS-DMA weight-gradient plan, eight XCD chunks,
+    503-block grids with half the blocks idle.  Losses as with --pack-rows 0 --skip-missing-images 0."""
+    g = torch.Generator().manual_seed(4)
+    lens = [torch.randint(3, 1001, (64,), generator=g).tolist() for _ in range(3)]
+    lens[1][0] = 1000
+    res = {}
+    for mode in (0, 1):
+        ls, ps, gs = _loop(1, 0.0, "bf16", 3, lens, L=6, B=64, T=1000, batch_size=64, pack_rows=mode, skip_missing_images=mode)
+        assert _loop.last_packed == bool(mode) and gs.captures == 1 and gs.replays == 2
+        res[mode] = (ls, ps)
+    worst = max(abs(a - b) for a, b in zip(res[1][0], res[0][0]))
+    REPORT["packed_full_size[bf16,B64,T1000].loss"] = {"rel_err": worst, "tol": 2e-3}
+    assert all(math.isfinite(v) for v in res[1][0]) and worst < 2e-3, (res[1][0], res[0][0])
+    dp = float((res[1][1] - res[0][1]).abs().max())
+    REPORT["packed_full_size[bf16,B64,T1000].params"] = {"rel_err": dp, "tol": 6e-4}
+    assert dp < 6e-4, dp
