@@ -275,14 +275,23 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # Samples without an image (missing_num 2 / 3: the bottleneck exchange gives their image stream weight 0, and this
         # model reads nothing else of it) are not encoded: the present images take the first slots of the encoder's batch
         # (ops.image_slots), the others come back as zero features.  The reference encodes a zero image for them.
-        skip = (bool(getattr(self.args, "skip_missing_images", 1)) and img.is_cuda and self.args.multiimages != 1
+        # With --multiimages 1 the image stream's key length is 4 + 1 + 49 * (images whose time is not the pad value 10), :226-231:
+        # the tokens of image j >= that count are masked as keys and read by nothing -- those images are not encoded either
+        # (by POSITION, as the reference masks them; an image in front of the count is encoded whatever its time says).
+        skip = (bool(getattr(self.args, "skip_missing_images", 1)) and img.is_cuda
                 and self.args.img_model_type == "swin" and torch.is_tensor(missing) and missing.dim() == 1)
 
         def encode(**kw):
             slots = None
-            if skip:
+            hw0 = (img.shape[-2] // 4) * (img.shape[-1] // 4)
+            if skip and self.args.multiimages == 1:
+                K = self.n_images
+                n_keep = torch.count_nonzero(img_time.reshape(-1, K).to(img.device) - 10, dim=1)            # [B]
+                absent = (torch.arange(K, device=img.device).unsqueeze(0) >= n_keep.unsqueeze(1)).reshape(-1)
+                slots = ops.image_slots(absent.to(torch.int64), 1, hw0)
+            elif skip:
                 # missing_num 0: all three modalities, 1: vital signs + image (builder/trainer missing_to_num)
-                slots = ops.image_slots(missing.to(img.device), 2, (img.shape[-2] // 4) * (img.shape[-1] // 4))
+                slots = ops.image_slots(missing.to(img.device), 2, hw0)
             return self.img_encoder(img, slots=slots, **kw)
         if side is not None:
             # stages 1-2 on a third stream, stages 3-4 as two half batches on the two side streams (result valid on side[0])

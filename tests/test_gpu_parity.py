@@ -2028,6 +2028,17 @@ def test_packed_steps_with_empty_windows_and_four_images(ops):
         assert res[1, 0][0] == res[1, 1][0]
 
 
+def test_multi_image_steps_do_not_depend_on_images_behind_the_key_length(ops):
+    """--multiimages 1, K = 4 with absent images: the images at positions >= the stream's image count are masked as keys and
+    not encoded (--skip-missing-images 1); losses and parameters bit-identical to encoding them."""
+    lens = [[96, 50, 7, 1], [96, 96, 96, 96], [3, 96, 20, 64]]
+    res = {(sk, gr): _loop_multi(gr, lens, 1, n_images=4, skip_missing_images=sk)[:2] for sk in (0, 1) for gr in (0, 1)}
+    for gr in (0, 1):
+        assert res[1, gr][0] == res[0, gr][0], (res[1, gr][0], res[0, gr][0])
+        assert torch.equal(res[1, gr][1], res[0, gr][1])
+    REPORT["skip_missing_images.multi_image_steps"] = {"rel_err": 0.0, "tol": 0.0}
+
+
 def _loop_multi(hip_graph, lens_per_step, pack, **over):
     """_loop for --multiimages 1 (the synthetic batch then carries K images per sample)"""
     from medical_tri_modal_pilot_amd.builder.trainer import get_trainer
@@ -2035,7 +2046,8 @@ def _loop_multi(hip_graph, lens_per_step, pack, **over):
     from medical_tri_modal_pilot_amd.optim import FusedAdamW
     torch.manual_seed(7)
     K = over.get("n_images", 3)
-    args, model = _product_model(2, 1, "bf16", hip_graph=hip_graph, dropout=0.0, pack_rows=pack, n_images=K)
+    args, model = _product_model(2, 1, "bf16", hip_graph=hip_graph, dropout=0.0, pack_rows=pack, n_images=K,
+                                 skip_missing_images=over.get("skip_missing_images", 1))
     model.train()
     model.img_encoder.eval()
     opt = FusedAdamW(model.hot_parameters(), lr=1e-4, weight_decay=args.weight_decay)
