@@ -1,5 +1,7 @@
+"""Per-step losses of the packed and the padded fusion stack at the benchmark's size (see test_packed_full_size_steps_match_padded)."""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tests/golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import torch, test_gpu_parity as T
 g = torch.Generator().manual_seed(4)
 lens = [torch.randint(3, 1001, (64,), generator=g).tolist() for _ in range(3)]
