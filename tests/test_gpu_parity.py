@@ -2086,3 +2086,23 @@ def test_packed_full_size_steps_match_padded(ops):
     dp = float((res[1][1] - res[0][1]).abs().max())
     REPORT["packed_full_size[bf16,B64,T1000].params"] = {"rel_err": dp, "tol": 6e-4}
     assert dp < 6e-4, dp
+
+
+@pytest.mark.parametrize("over", [dict(mbt_only_vslt=0), dict(residual_bottlenecks=1), dict(mbt_fusion_startIdx=1)],
+                         ids=["vsltonly0", "resbottle", "fusion_start1"])
+def test_packed_stream_with_other_encoder_flags(ops, over):
+    """--pack-rows 1 against 0 (bf16, eager + graph, ragged lengths) with the encoder's other switches: all three streams in the
+    last layer (--mbt-only-vslt 0), residual bottlenecks, and uni-modal layers in front of the fusion layers
+    (--mbt-fusion-startIdx 1: the stream inputs are not fused there, so the stream stays padded -- the flag must be harmless)."""
+    lens = [[96, 50, 7, 1], [3, 96, 20, 64], [96, 1, 1, 2]]
+    res = {}
+    for pack in (0, 1):
+        for graph in (0, 1):
+            res[pack, graph] = _loop(graph, 0.0, "bf16", 3, lens, pack_rows=pack, **over)[:2]
+            assert _loop.last_packed == (bool(pack) and "mbt_fusion_startIdx" not in over)
+    tag = next(iter(over))
+    for graph in (0, 1):
+        worst = max(abs(a - b) for a, b in zip(res[1, graph][0], res[0, graph][0]))
+        REPORT[f"packed_flags[{tag},graph={graph}].loss"] = {"rel_err": worst, "tol": 2e-3}
+        assert all(math.isfinite(v) for v in res[1, graph][0]) and worst < 2e-3, (res[1, graph][0], res[0, graph][0])
+    assert res[1, 0][0] == res[1, 1][0]
