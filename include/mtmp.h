@@ -63,6 +63,20 @@ int mtmp_attn_bwd_grouped(int dtype, int n, const void* const* q, const void* co
                           const int32_t* const* row_start, void* const* dq, void* const* dk, void* const* dv,
                           float* const* delta_ws, const int* N, const int* ld_qkv, const int* ld_o, const int* ld_do,
                           const int* ld_dqkv, int B, int H, float scale, void* stream);
+/* Attention of ONE query row per sample -- the CLS token of the last fusion layer of the vital-sign stream: tri_mbt_vsltcls.py:248
+ * reads nothing of the encoder's result but outputs[0][:, 0, :], so in the LAST layer only that row's attention output, FFN and
+ * residuals feed the loss (its keys / values still come from all rows).  q / k / v [rows, ld_qkv], res [rows, ld_res] (the layer
+ * input: residual of encoder.py:27); kv_len / row_start as in mtmp_attn_fwd_grouped (both may be NULL: padded [B, N], all keys
+ * valid); cls_tok = the query's token index inside a sample.  _fwd: o_cls, r1_cls [B, H * 64] (the attention output and output +
+ * residual, both in `dtype`), lse float[B, H].  _bwd: d_o [B, H * 64] = gradient w.r.t. o_cls -> dq, dk, dv written for EVERY row
+ * of every sample (dense [rows, ld_dqkv]; dq is zero outside row cls_tok, rows past kv_len are zero): what mtmp_gemm_tn /
+ * mtmp_gemm_lnbwd read next.  Replaces attention.py:24-84 (+ autograd) for that one row. */
+int mtmp_attn_cls_fwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const void* res, int ld_res, void* o_cls,
+                      void* r1_cls, float* lse, const int32_t* kv_len, const int32_t* row_start, int B, int N, int H, int cls_tok,
+                      float scale, void* stream);
+int mtmp_attn_cls_bwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const void* o_cls, const void* d_o,
+                      const float* lse, const int32_t* kv_len, const int32_t* row_start, void* dq, void* dk, void* dv, int ld_dqkv,
+                      int B, int N, int H, int cls_tok, float scale, void* stream);
 /* out[ceil(rows / 32)][H] = max over each 32-row block of ||k[row, 64h : 64h + 64]||_2 (k: [rows, ld]). */
 long long mtmp_key_norms_floats(long long rows, int H);
 int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream);

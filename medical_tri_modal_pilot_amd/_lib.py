@@ -18,6 +18,8 @@ SIGNATURES = {
     "mtmp_abi_version": (c_int, []),
     "mtmp_last_error": (c_char_p, []),
     "mtmp_attn_fwd": (c_int, [c_int] + [c_void_p] * 9 + [c_int] * 5 + [c_float, c_void_p]),
+    "mtmp_attn_cls_fwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int, c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 4 + [c_float, c_void_p]),
+    "mtmp_attn_cls_bwd": (c_int, [c_int] + [c_void_p] * 3 + [c_int] + [c_void_p] * 8 + [c_int] * 5 + [c_float, c_void_p]),
     "mtmp_attn_fwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 13 + [c_int, c_int, c_float, c_void_p]),
     "mtmp_attn_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 17 + [c_int, c_int, c_float, c_void_p]),
     "mtmp_key_norms_floats": (c_longlong, [c_longlong, c_int]),

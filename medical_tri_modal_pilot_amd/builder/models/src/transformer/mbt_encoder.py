@@ -159,6 +159,11 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         first_only = (bool(getattr(self, "first_stream_output_only", False)) and not self.resbottle and fused_in
                       and self.vsltonly != 1)
         skip_last = first_only or (self.vsltonly == 1 and fused_in and not self.resbottle)     # (vsltonly: ops.FusionStackFn skips them too)
+        # ... and when the reader takes nothing but stream 0's CLS row (first_stream_output_only) and the last layer runs that
+        # stream alone, the last layer computes that one query row only (ops.cls_layer_forward: K / V of all rows, attention, FFN
+        # and residuals of the CLS row -- the other rows of the last layer's output feed nothing)
+        cls_only = (bool(getattr(self, "first_stream_output_only", False)) and fused_in and (first_only or self.vsltonly == 1)
+                    and bool(getattr(self, "cls_only_last_layer", True)) and not return_attns)
         dead = lambda li, m: skip_last and li == len(fl) - 1 and m > 0
         all_fused = iter(type(fl[0][0]).fused_weights_of(
             [layer for li, layers in enumerate(fl) for m, layer in enumerate(layers) if not dead(li, m)], dt))
@@ -189,15 +194,15 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             cfg = dict(n_layers=len(seg), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
                        prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True, first_only=first_only and final,
                        missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev),
-                       inputs_on_side=side_in is not None and si == 0, pack_v=pack_v)
+                       inputs_on_side=side_in is not None and si == 0, pack_v=pack_v, cls_only=cls_only and final)
             out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(zs[0], zs[1], zs[2], self.bottlenecks, *params, cfg)
             zs = (out_v, out_i, out_t)
             if not final:
                 self.segment_boundaries.append(zs)
         nb = self.bottlenecks_n
         self.last_cls = cls_v               # = outs[0][:, 0, :] as its own autograd output (cheap backward)
-        # (a packed stream 0 has no [B, N] view: its reader takes ``last_cls``)
-        out_v = None if pack_v is not None else out_v[:, nb:]
+        # (a packed stream 0 has no [B, N] view, and with cls_only only the CLS row of the last layer exists: the reader takes ``last_cls``)
+        out_v = None if (pack_v is not None or cls_only) else out_v[:, nb:]
         if self.vsltonly == 1:
             return [out_v], 0
         return [out_v, out_i[:, nb:], out_t[:, nb:]], 0

@@ -1101,6 +1101,253 @@ extern "C" int mtmp_attn_bwd(int dtype, const void* q, const void* k, const void
                                  &ld_do, &ld_dqkv, B, H, scale, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Attention of ONE query per sample -- the CLS token of the LAST fusion layer of the vital-sign stream.  tri_mbt_vsltcls.py:248
+// reads nothing of the encoder's result but outputs[0][:, 0, :]: in the last layer only the CLS row's attention output, FFN and
+// residuals feed the loss (every other query row of that layer is dead code; its keys and values are not -- K / V come from
+// all rows).  Forward: s_k = scale q_cls.k_k over the kv_len[b] valid keys, p = softmax(s), o = sum p_k v_k, r1 = o + residual
+// (o rounded to T first, like the dense kernel's epilogue).  Backward: dO arrives for the CLS query only, so dQ is one row and
+// dK / dV are rank one per (sample, head): dk_k = scale dS_k q, dv_k = p_k dO, dq = scale sum dS_k k_k with dS = p (dP - delta).
+// One workgroup per (sample, head); plain fp32 FMAs (a few hundred thousand MACs per workgroup: no MFMA needed); the scores
+// live in LDS.  Same packed / padded addressing as the dense kernels (AttnArgs::row_start).
+namespace {
+template <typename T> struct AttnClsArgs {
+    const T* q; const T* k; const T* v; int ld_qkv;
+    const T* res; int ld_res;              // forward: the layer input z, row-aligned with q (residual of encoder.py:27)
+    T* o_cls; T* r1_cls; float* lse;       // [B, H * 64], [B, H * 64], [B, H] (log2 units of the scaled scores)
+    const T* d_o;                          // backward: gradient w.r.t. o_cls, [B, H * 64]
+    T* dq; T* dk; T* dv; int ld_dqkv;      // backward: DENSE gradient rows (every row of the sample is written)
+    const int* kv_len; const int* row_start;
+    int B, N, H, cls_tok;
+    float scale;
+};
+
+// 8 consecutive elements of a row as floats (one 16-byte load for bf16, two for fp32)
+template <typename T> MTMP_DEV void load8f(const T* ptr, float (&o)[8]) {
+    const f32x4 a = load4<T>(ptr), b = load4<T>(ptr + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+MTMP_DEV float block_reduce(float v, float* red, bool take_max) {      // 256 threads; red: 4 floats of LDS scratch
+    v = take_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return take_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One workgroup (256 threads) per (sample, head).  Scores: a thread per key (the whole 128-byte key row against q held in
+// registers).  P V: thread = (8-dim group dg = tid & 7, key lane kl = tid >> 3): 32 key lanes walk the keys with 16-byte loads,
+// their partial sums meet in LDS.
+template <typename T> __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(AttnClsArgs<T> p) {
+    extern __shared__ float cls_lds[];
+    float* s = cls_lds;                                     // [N] scores -> probabilities
+    float* red = s + p.N;                                   // [4]
+    float* part = red + 4;                                  // [32][64] partial outputs
+    const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H, tid = threadIdx.x;
+    const int kvl = max(1, min(p.kv_len ? p.kv_len[b] : p.N, p.N));
+    const size_t row0 = p.row_start ? (size_t)p.row_start[b] : (size_t)b * p.N;
+    const T* Kb = p.k + row0 * p.ld_qkv + hd * DH;
+    const T* Vb = p.v + row0 * p.ld_qkv + hd * DH;
+    const T* qrow = p.q + (row0 + p.cls_tok) * p.ld_qkv + hd * DH;
+    const float c2 = p.scale * LOG2E;
+    float q[DH];
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) {
+        float t[8];
+        load8f<T>(qrow + 8 * c, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[8 * c + j] = t[j] * c2;
+    }
+    float mx = -INFINITY;
+    for (int k = tid; k < kvl; k += 256) {
+        const T* kr = Kb + (size_t)k * p.ld_qkv;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            float t[8];
+            load8f<T>(kr + 8 * c, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = fmaf(q[8 * c + j], t[j], a);
+        }
+        s[k] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = block_reduce(mx, red, true);
+    float l = 0.f;
+    for (int k = tid; k < kvl; k += 256) {
+        const float e = fast_exp2(s[k] - mx);
+        s[k] = e;
+        l += e;
+    }
+    l = block_reduce(l, red, false);                        // (its barriers also publish the probabilities)
+    const int dg = tid & 7, kl = tid >> 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = kl; k < kvl; k += 32) {
+        float t[8];
+        load8f<T>(Vb + (size_t)k * p.ld_qkv + 8 * dg, t);
+        const float pk = s[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(pk, t[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[kl * DH + 8 * dg + j] = acc[j];
+    __syncthreads();
+    if (tid < DH) {
+        float o = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) o += part[i * DH + tid];
+        const T ot = from_f32<T>(o / l);
+        const size_t oi = ((size_t)b * p.H + hd) * DH + tid;
+        p.o_cls[oi] = ot;
+        p.r1_cls[oi] = from_f32<T>(to_f32(ot) + to_f32(p.res[(row0 + p.cls_tok) * p.ld_res + hd * DH + tid]));
+        if (tid == 0) p.lse[b * p.H + hd] = mx + log2f(l);
+    }
+}
+
+template <typename T> MTMP_DEV void store8(T* ptr, const float (&v)[8]) {
+    store4<T>(ptr, v[0], v[1], v[2], v[3]);
+    store4<T>(ptr + 4, v[4], v[5], v[6], v[7]);
+}
+
+template <typename T> __global__ __launch_bounds__(256) void attn_cls_bwd_kernel(AttnClsArgs<T> p) {
+    extern __shared__ float cls_lds[];
+    float* sP = cls_lds;                                    // [N] p_k
+    float* sD = sP + p.N;                                   // [N] dS_k
+    float* red = sD + p.N;                                  // [4]
+    float* part = red + 4;                                  // [32][64] partial dq
+    const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H, tid = threadIdx.x;
+    const int kvl = max(1, min(p.kv_len ? p.kv_len[b] : p.N, p.N));
+    const int nrows = p.row_start ? kvl : p.N;              // rows of this sample in the dense gradient buffers
+    const size_t row0 = p.row_start ? (size_t)p.row_start[b] : (size_t)b * p.N;
+    const T* Kb = p.k + row0 * p.ld_qkv + hd * DH;
+    const T* Vb = p.v + row0 * p.ld_qkv + hd * DH;
+    const T* qrow = p.q + (row0 + p.cls_tok) * p.ld_qkv + hd * DH;
+    const size_t oi = ((size_t)b * p.H + hd) * DH;
+    const float c2 = p.scale * LOG2E, lse = p.lse[b * p.H + hd];
+    float q[DH], g[DH];                                     // q (scaled to log2 units) and dO: whole rows in every thread
+    float dl = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) {
+        float t[8], d[8], o[8];
+        load8f<T>(qrow + 8 * c, t);
+        load8f<T>(p.d_o + oi + 8 * c, d);
+        load8f<T>(p.o_cls + oi + 8 * c, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { q[8 * c + j] = t[j] * c2; g[8 * c + j] = d[j]; dl = fmaf(d[j], o[j], dl); }
+    }
+    for (int k = tid; k < kvl; k += 256) {                  // a thread per key: p_k and dS_k = p_k (dO.v_k - dO.o)
+        const T* kr = Kb + (size_t)k * p.ld_qkv;
+        const T* vr = Vb + (size_t)k * p.ld_qkv;
+        float a = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+            float t[8], u[8];
+            load8f<T>(kr + 8 * c, t);
+            load8f<T>(vr + 8 * c, u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a = fmaf(q[8 * c + j], t[j], a); dp = fmaf(g[8 * c + j], u[j], dp); }
+        }
+        const float pk = fast_exp2(a - lse);
+        sP[k] = pk;
+        sD[k] = pk * (dp - dl);
+    }
+    __syncthreads();
+    // thread = (8-dim group dg, key lane kl): the gradient rows leave as 16-byte pieces; dq's partial sums meet in LDS
+    const int dg = tid & 7, kl = tid >> 3;
+    float qd[8], gd[8], zero[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    load8f<T>(qrow + 8 * dg, qd);                            // (re-read: indexing the register copies by dg would put them in scratch)
+    load8f<T>(p.d_o + oi + 8 * dg, gd);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qd[j] *= p.scale;
+    T* dQb = p.dq + row0 * p.ld_dqkv + hd * DH + 8 * dg;
+    T* dKb = p.dk + row0 * p.ld_dqkv + hd * DH + 8 * dg;
+    T* dVb = p.dv + row0 * p.ld_dqkv + hd * DH + 8 * dg;
+    for (int k = kl; k < nrows; k += 32) {
+        const size_t ro = (size_t)k * p.ld_dqkv;
+        if (k < kvl) {
+            const float ds = sD[k], pk = sP[k];
+            float t[8], dk[8], dv[8];
+            load8f<T>(Kb + (size_t)k * p.ld_qkv + 8 * dg, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[j] = fmaf(ds, t[j], acc[j]); dk[j] = ds * qd[j]; dv[j] = pk * gd[j]; }
+            store8<T>(dKb + ro, dk);
+            store8<T>(dVb + ro, dv);
+        } else {
+            store8<T>(dKb + ro, zero);
+            store8<T>(dVb + ro, zero);
+        }
+        if (k != p.cls_tok) store8<T>(dQb + ro, zero);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[kl * DH + 8 * dg + j] = acc[j];
+    __syncthreads();
+    if (tid < DH) {
+        float o = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) o += part[i * DH + tid];
+        p.dq[(row0 + p.cls_tok) * p.ld_dqkv + hd * DH + tid] = from_f32<T>(o * p.scale);
+    }
+}
+
+bool attn_cls_ok(int B, int N, int H, int cls_tok, int ld) {
+    return B > 0 && N > 0 && N <= 8192 && H > 0 && H <= 4 && cls_tok >= 0 && cls_tok < N && ld >= H * DH && ld % 4 == 0;
+}
+}  // namespace
+
+// o_cls, r1_cls [B, H * 64] (dtype), lse float[B, H]: attention output of query row `cls_tok` of every sample, and that output plus
+// the residual row res[.., cls_tok] (encoder.py:27).  q / k / v [rows, ld_qkv], res [rows, ld_res]; kv_len (may be NULL), row_start
+// (may be NULL: padded [B, N] layout) as in mtmp_attn_fwd_grouped.  Replaces attention.py:24-84 for the one query row that
+// tri_mbt_vsltcls.py:248 reads of the last layer.
+extern "C" int mtmp_attn_cls_fwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const void* res, int ld_res,
+                                 void* o_cls, void* r1_cls, float* lse, const int32_t* kv_len, const int32_t* row_start, int B, int N,
+                                 int H, int cls_tok, float scale, void* stream) {
+    MTMP_CHECK_ARG(q && k && v && res && o_cls && r1_cls && lse, "mtmp_attn_cls_fwd: null pointer");
+    MTMP_CHECK_ARG(attn_cls_ok(B, N, H, cls_tok, ld_qkv) && ld_res >= H * DH && (!row_start || kv_len),
+                   "mtmp_attn_cls_fwd: bad argument (B=%d N=%d H=%d cls=%d ld=%d)", B, N, H, cls_tok, ld_qkv);
+    const size_t sm = ((size_t)N + 4 + 32 * DH) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        AttnClsArgs<float> a{(const float*)q, (const float*)k, (const float*)v, ld_qkv, (const float*)res, ld_res, (float*)o_cls,
+                             (float*)r1_cls, lse, nullptr, nullptr, nullptr, nullptr, 0, kv_len, row_start, B, N, H, cls_tok, scale};
+        if (int e = set_smem(attn_cls_fwd_kernel<float>, sm)) return e;
+        hipLaunchKernelGGL(attn_cls_fwd_kernel<float>, dim3(B * H), dim3(256), sm, st, a);
+    } else if (dtype == 1) {
+        AttnClsArgs<bf16> a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ld_qkv, (const bf16*)res, ld_res, (bf16*)o_cls,
+                            (bf16*)r1_cls, lse, nullptr, nullptr, nullptr, nullptr, 0, kv_len, row_start, B, N, H, cls_tok, scale};
+        if (int e = set_smem(attn_cls_fwd_kernel<bf16>, sm)) return e;
+        hipLaunchKernelGGL(attn_cls_fwd_kernel<bf16>, dim3(B * H), dim3(256), sm, st, a);
+    } else { mtmp_set_error("mtmp_attn_cls_fwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_attn_cls_fwd");
+    return MTMP_OK;
+}
+
+// Backward of the above: d_o [B, H * 64] (gradient w.r.t. o_cls) -> dq, dk, dv written for EVERY row of every sample (dq is zero
+// except in row cls_tok; rows past kv_len are zero): the dense [rows, ld_dqkv] buffers the layer's remaining backward
+// (mtmp_gemm_tn, mtmp_gemm_lnbwd) reads.
+extern "C" int mtmp_attn_cls_bwd(int dtype, const void* q, const void* k, const void* v, int ld_qkv, const void* o_cls, const void* d_o,
+                                 const float* lse, const int32_t* kv_len, const int32_t* row_start, void* dq, void* dk, void* dv,
+                                 int ld_dqkv, int B, int N, int H, int cls_tok, float scale, void* stream) {
+    MTMP_CHECK_ARG(q && k && v && o_cls && d_o && lse && dq && dk && dv, "mtmp_attn_cls_bwd: null pointer");
+    MTMP_CHECK_ARG(attn_cls_ok(B, N, H, cls_tok, ld_qkv) && ld_dqkv >= H * DH && (!row_start || kv_len),
+                   "mtmp_attn_cls_bwd: bad argument (B=%d N=%d H=%d cls=%d ld=%d)", B, N, H, cls_tok, ld_qkv);
+    const size_t sm = ((size_t)2 * N + 4 + 32 * DH) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        AttnClsArgs<float> a{(const float*)q, (const float*)k, (const float*)v, ld_qkv, nullptr, 0, (float*)o_cls, nullptr,
+                             (float*)lse, (const float*)d_o, (float*)dq, (float*)dk, (float*)dv, ld_dqkv, kv_len, row_start, B, N, H,
+                             cls_tok, scale};
+        if (int e = set_smem(attn_cls_bwd_kernel<float>, sm)) return e;
+        hipLaunchKernelGGL(attn_cls_bwd_kernel<float>, dim3(B * H), dim3(256), sm, st, a);
+    } else if (dtype == 1) {
+        AttnClsArgs<bf16> a{(const bf16*)q, (const bf16*)k, (const bf16*)v, ld_qkv, nullptr, 0, (bf16*)o_cls, nullptr, (float*)lse,
+                            (const bf16*)d_o, (bf16*)dq, (bf16*)dk, (bf16*)dv, ld_dqkv, kv_len, row_start, B, N, H, cls_tok, scale};
+        if (int e = set_smem(attn_cls_bwd_kernel<bf16>, sm)) return e;
+        hipLaunchKernelGGL(attn_cls_bwd_kernel<bf16>, dim3(B * H), dim3(256), sm, st, a);
+    } else { mtmp_set_error("mtmp_attn_cls_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_attn_cls_bwd");
+    return MTMP_OK;
+}
+
 extern "C" long long mtmp_key_norms_floats(long long rows, int H) { return ((rows + 31) / 32) * H; }
 
 extern "C" int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream) {

@@ -1082,6 +1082,97 @@ def layer_backward(saved, d_out, sink=None, late=None):
     return dz.view(B, N, D), grads
 
 
+# ----------------------------------------------------------------------------- the last layer of a CLS-only reader
+# tri_mbt_vsltcls.py:248 reads nothing of the encoder's result but the vital-sign stream's CLS row.  In the LAST fusion layer
+# (which runs that stream alone: mbt_encoder.py first_stream_output_only / vsltonly) every other query row is therefore dead
+# code -- its attention output, its FFN, and in the backward its dH / dW2 / dW1 products and the N x N score gradients.  What
+# stays dense is what the CLS row needs of the other rows: LayerNorm + K / V projection of all rows (forward), and in the
+# backward dK / dV (rank one per sample and head: only the CLS query looks at them), the QKV weight gradient and dX of that
+# projection.  The reference computes the whole layer; nothing it computes beyond this reaches the loss or a gradient.
+def attn_cls_fwd(qkv, z, kv_len, pack, cls_tok):
+    """qkv [B,N,768], z [B,N,256] (residual source) -> (o_cls [B,256], r1_cls [B,256] = o + z[:, cls_tok], lse float[B,4])"""
+    _gpu(qkv, z)
+    B, N, _ = qkv.shape
+    es = qkv.element_size()
+    o = torch.empty(B, D_MODEL, dtype=qkv.dtype, device=qkv.device)
+    r1 = torch.empty_like(o)
+    lse = torch.empty(B, N_HEAD, dtype=torch.float32, device=qkv.device)
+    call("mtmp_attn_cls_fwd", _dt(qkv), _p(qkv), _p(qkv, D_MODEL * es), _p(qkv, 2 * D_MODEL * es), qkv.stride(1), _p(z), z.stride(1),
+         _p(o), _p(r1), _p(lse), _p(kv_len), _p(pack), B, N, N_HEAD, int(cls_tok), D_HEAD ** -0.5, _stream())
+    return o, r1, lse
+
+
+def attn_cls_bwd(qkv, o_cls, d_o, lse, kv_len, pack, cls_tok):
+    """-> dqkv [B,N,768], every row written (dq zero outside the CLS rows)."""
+    _gpu(qkv, o_cls, d_o)
+    B, N, _ = qkv.shape
+    es = qkv.element_size()
+    dqkv = torch.empty_like(qkv)
+    call("mtmp_attn_cls_bwd", _dt(qkv), _p(qkv), _p(qkv, D_MODEL * es), _p(qkv, 2 * D_MODEL * es), qkv.stride(1), _p(o_cls), _p(_c(d_o)),
+         _p(lse), _p(kv_len), _p(pack), _p(dqkv), _p(dqkv, D_MODEL * es), _p(dqkv, 2 * D_MODEL * es), dqkv.stride(1), B, N, N_HEAD,
+         int(cls_tok), D_HEAD ** -0.5, _stream())
+    return dqkv
+
+
+def cls_layer_forward(z, kv_len, P, fused, drop_p, seeds, pack, cls_tok):
+    """The last layer for a reader of the CLS row only: z [B,N,256] (padded, or packed with `pack`) -> (out_cls [B,256], saved)."""
+    B, N, D = z.shape
+    g1, b1, g2, b2, c1, c2 = P[0], P[1], P[8], P[9], P[11], P[13]
+    wqkv, bqkv, w1c, w2c, w2t, wqkvt, w1t = fused
+    z2 = z.view(B * N, D)
+    if pack is not None:                               # (bf16: the grouped form knows the live row count)
+        qkv, xn1, st1 = (t[0] for t in ln_gemm_qkv_grouped([z2], [g1], [b1], [wqkv], [bqkv], [pack])[:3])
+    else:
+        qkv, xn1, st1 = ln_gemm(z2, g1, b1, wqkv, bqkv, 3 * D)
+    qkv = qkv.view(B, N, 3 * D)
+    o_cls, r1, lse = attn_cls_fwd(qkv, z, kv_len, pack, cls_tok)
+    h, xn2, st2, hsign = ln_gemm(r1, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
+    out = gemm_nt(h, w2c, c2, res2d=r1, drop_p=drop_p, seed=seeds[1])
+    rows = (pack[:B].long() if pack is not None else torch.arange(B, device=z.device) * N) + cls_tok
+    return out, (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o_cls, lse, r1, xn2, st2, h, drop_p, seeds, hsign, pack, rows, cls_tok)
+
+
+def cls_layer_backward(saved, d_cls, sink=None, late=None):
+    """d_cls [B,256] (gradient of cls_layer_forward's output) -> (dz [B,N,256], 14 parameter gradients | None), as layer_backward."""
+    z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o_cls, lse, r1, xn2, st2, h, p, seeds, hsign, pack, rows, cls_tok = saved
+    B, N, D = z.shape
+    M = B * N
+    d_out = _c(d_cls).to(z.dtype)
+    direct = sink is not None and sink.usable()
+    red = [] if DEFER_REDUCTIONS else None
+    # ---- FFN of the B CLS rows
+    if hsign is not None and p > 0 and FOLD_DROPOUT_BWD:
+        dh, dy2 = gemm_nt_signs(d_out, w2t, hsign, 1.0 / (1.0 - p), drop_p=p, seed=seeds[1])
+    else:
+        dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
+        dh = gemm_nt_signs(dy2, w2t, hsign, 1.0 / (1.0 - p)) if hsign is not None else gemm_nt(dy2, w2t, gate=h, gate_scale=1.0 / (1.0 - p))
+    dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None, defer=red)
+    dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None, defer=red)
+    dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1, st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None, defer=red)
+    # ---- attention of the CLS query: dense dK / dV (and a dQ that is zero outside the CLS rows), then the projection's backward
+    dqkv = attn_cls_bwd(qkv, o_cls, dr1, lse, kv_len, pack, cls_tok).view(M, 3 * D)
+    z2 = z.view(M, D)
+    if pack is not None:
+        dwqkv, dbqkv = gemm_tn_grouped([dqkv], [xn1], [(sink.wqkv, sink.bqkv) if direct else None], [red], [pack])[0]
+        dz, dg1, db1 = gemm_lnbwd_grouped([dqkv], [wqkvt], [z2], [st1], [g1], [None], [sink.gb1 if direct else None], [red], [pack])[0]
+    else:
+        dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None, defer=red)
+        dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z2, st1, g1, d_res2d=None, gb_out=sink.gb1 if direct else None, defer=red)
+    dz.index_add_(0, rows, dr1)                        # r1 = z + o: the CLS rows' residual gradient
+    if late is not None and red:
+        late.append((red, sink if direct else None))
+    else:
+        if red:
+            reduce_batch(red)
+        if direct:
+            sink.flat.mark_ready(sink.idx)
+    if direct:
+        return dz.view(B, N, D), None
+    grads = (dg1, db1, dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
+             dg2, db2, dw1, dc1, dw2, dc2)
+    return dz.view(B, N, D), grads
+
+
 # One launch per layer step over the active streams (bf16): csrc/common.cuh, Grouped.  The three streams of a fusion layer are
 # 1005 / 54 / 133 tokens long; as three launches on three HIP streams the short ones held whole-CU workgroup slots beside the
 # long one's kernels (round 2: every vital-sign-stream kernel 15-40 % slower in the step than alone, ~1.2 ms per step, ~200
@@ -1285,6 +1376,7 @@ class FusionStackFn(torch.autograd.Function):
         streams = cfg.get("side_streams")
         cur = torch.cuda.current_stream()
         saved, active = [], []
+        cls_out = None
         # the vital-sign stream PACKED (cfg["pack_v"] = row_starts(kv[0], Ns[0]), made by the encoder together with a packed
         # stream input): bf16 grouped kernels only, and only for a caller that reads nothing of stream 0 but its CLS row
         pack_v = cfg.get("pack_v")
@@ -1298,6 +1390,16 @@ class FusionStackFn(torch.autograd.Function):
             row = [None, None, None]
             # launch groups of this layer: (streams, HIP stream).  Layer 0 keeps one group per stream while the image / text
             # inputs are still being made on the side streams (the vital-sign stream's first layer runs beside the image encoder)
+            if last and cfg.get("cls_only"):       # the reader takes the CLS row only: ops.cls_layer_forward
+                P = params[(li * n_s) * PARAMS_PER_LAYER:(li * n_s + 1) * PARAMS_PER_LAYER]
+                mark(f"f{li}.g0.s")
+                cls_out, row[0] = cls_layer_forward(z[0], cfg["kv"][0], P, cfg["fused"][li][0], cfg["drop_p"], cfg["seeds"][li][0],
+                                                    pack_v, NB)
+                mark(f"f{li}.g0.e")
+                saved.append(row)
+                active.append(ms)
+                z = [None, None, None]
+                break
             groups = launch_groups(ms, streams, z[0], solo=(li == 0 and bool(cfg.get("inputs_on_side"))))
             if len(groups) > 1:
                 ev = torch.cuda.Event()
@@ -1341,6 +1443,11 @@ class FusionStackFn(torch.autograd.Function):
         ctx.saved, ctx.active, ctx.cfg, ctx.wsel = saved, active, cfg, wsel
         ctx.shapes = (B, Ns, [p.shape for p in params])
         ctx.set_materialize_grads(False)
+        ctx.cls_only = cls_out is not None
+        if cls_out is not None:            # nothing but the CLS row exists of the last layer's output: one-row placeholders
+            outs_full = [torch.zeros(B, NB + 1, D_MODEL, dtype=dt, device=dev) for _ in range(3)]
+            ctx.mark_non_differentiable(*outs_full)
+            return outs_full[0], outs_full[1], outs_full[2], cls_out
         outs_full = [z[m] if z[m] is not None else torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) for m in range(3)]
         ctx.mark_non_differentiable(*[o for m, o in enumerate(outs_full) if z[m] is None])
         if pack_v is not None:             # row pack_v[b] + NB of the packed buffer
@@ -1373,10 +1480,12 @@ class FusionStackFn(torch.autograd.Function):
         # gradient w.r.t. the last executed layer's outputs
         dz = [None, None, None]
         for m, g in enumerate((d_v, d_i, d_t)):
-            if m in active[-1]:
+            if m in active[-1] and not ctx.cls_only:
                 dz[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) if g is None else _c(g).to(dt).clone()
         pack_v = cfg.get("pack_v")
-        if d_cls is not None and pack_v is not None:
+        if ctx.cls_only:
+            pass                           # d_cls goes straight into ops.cls_layer_backward below
+        elif d_cls is not None and pack_v is not None:
             dz[0].view(-1, D_MODEL).index_add_(0, ctx.cls_rows, d_cls.to(dt))
         elif d_cls is not None:
             dz[0][:, NB, :] += d_cls.to(dt)
@@ -1404,6 +1513,22 @@ class FusionStackFn(torch.autograd.Function):
                 bottleneck_exchange_bwd(dz, cfg["missing"], cfg["resbottle"], d_prev_bott, d_out_prev, pack_v)
                 d_prev_bott = d_out_prev
             nxt = [None, None, None]
+            if ctx.cls_only and li == n_run - 1:
+                mark(f"b{li}.g0.s")
+                d1 = d_cls if d_cls is not None else torch.zeros(B, D_MODEL, dtype=dt, device=dev)
+                nxt[0], gg0 = cls_layer_backward(saved[li][0], d1, cfg["sinks"][li][0] if cfg.get("sinks") else None,
+                                                 late=late[0] if LATE_REDUCTIONS else None)
+                if gg0 is not None:
+                    base = (li * n_s) * PARAMS_PER_LAYER
+                    for k in range(PARAMS_PER_LAYER):
+                        pgrads[base + k] = gg0[k].view(pshapes[base + k])
+                mark(f"b{li}.g0.e")
+                saved[li] = None
+                if li > 0:
+                    for m in range(1, n_s):
+                        nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
+                dz = nxt
+                continue
             groups = launch_groups(ms, streams, saved[li][ms[0]][0])
             if len(groups) > 1:
                 ev = torch.cuda.Event()

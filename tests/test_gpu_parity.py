@@ -2106,3 +2106,47 @@ def test_packed_stream_with_other_encoder_flags(ops, over):
         REPORT[f"packed_flags[{tag},graph={graph}].loss"] = {"rel_err": worst, "tol": 2e-3}
         assert all(math.isfinite(v) for v in res[1, graph][0]) and worst < 2e-3, (res[1, graph][0], res[0, graph][0])
     assert res[1, 0][0] == res[1, 1][0]
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("packed", [False, True])
+def test_attn_cls_row_vs_dense_attention(ops, dt, packed):
+    """mtmp_attn_cls_fwd / _bwd (the CLS query of the last layer alone) against the oracle's dense attention: output and
+    output + residual of row cls_tok, and -- for a gradient that is zero outside that row -- the dense dq / dk / dv of
+    O.attention_core's autograd; padded and packed layouts, ragged key lengths incl. a sample whose only rows are the prefix."""
+    torch.manual_seed(5)
+    B, N, cls_tok = 6, 333, 4
+    lens = [333, 5, 64, 129, 300, 65]
+    kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    qkv32 = torch.randn(B, N, 768, device=DEV) * 0.7
+    z32 = torch.randn(B, N, 256, device=DEV)
+    d32 = torch.randn(B, 256, device=DEV)
+    qkv, z, d_o = qkv32.to(dt), z32.to(dt), d32.to(dt)
+    # oracle: dense attention (keys masked behind kv), row cls_tok
+    qr = qkv.float().clone().requires_grad_(True)
+    q, k, v = (t.reshape(B, N, 4, 64).permute(0, 2, 1, 3) for t in qr.split(256, dim=2))
+    mask = (torch.arange(N, device=DEV)[None, :] >= kv[:, None])[:, None, None, :]
+    sc = (q @ k.transpose(-1, -2)) / 8.0
+    sc = sc.masked_fill(mask, -65504.0)
+    o_ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, 256)[:, cls_tok]
+    (o_ref * d_o.float()).sum().backward()
+    g_ref = qr.grad.clone()
+    valid = (torch.arange(N, device=DEV)[None, :] < kv[:, None])[..., None]
+    pack = ops.row_starts(kv, N) if packed else None
+    if packed:
+        qkv_in, z_in = _pack_rows(qkv, lens, pack.cpu()), _pack_rows(z, lens, pack.cpu())
+    else:
+        qkv_in, z_in = qkv, z
+    o, r1, lse = ops.attn_cls_fwd(qkv_in.contiguous(), z_in.contiguous(), kv, pack, cls_tok)
+    tol = 1e-4 if dt == torch.float32 else 1e-2
+    tag = f"attn_cls[{str(dt).replace('torch.', '')},packed={int(packed)}]"
+    check(tag + ".o", o.float(), o_ref, tol)
+    check(tag + ".r1", r1.float(), o_ref.to(dt).float() + z.float()[:, cls_tok], tol)
+    dqkv = ops.attn_cls_bwd(qkv_in.contiguous(), o, d_o, lse, kv, pack, cls_tok)
+    if packed:
+        dqkv = _unpack_rows(dqkv, lens, pack.cpu())
+    assert torch.isfinite(dqkv.float()[valid.expand(-1, -1, 768)]).all()
+    assert float((dqkv.float() * (~valid)).abs().max()) == 0.0            # rows behind kv_len: zeros
+    check(tag + ".dqkv", dqkv.float() * valid, g_ref * valid, 2e-4 if dt == torch.float32 else 2e-2)
+    nz = dqkv[:, :, :256].float().abs().sum(-1) > 0
+    assert not nz[:, :cls_tok].any() and not nz[:, cls_tok + 1:].any()    # dq lives in the CLS row only
