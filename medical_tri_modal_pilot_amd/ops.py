@@ -1114,6 +1114,17 @@ def attn_cls_bwd(qkv, o_cls, d_o, lse, kv_len, pack, cls_tok):
     return dqkv
 
 
+_cls_rows_cache = {}
+
+
+def _cls_rows(B, N, cls_tok, dev):
+    """int64[B]: row b * N + cls_tok of a padded [B, N] stream (made once per shape: nothing to launch inside a step)"""
+    key = (B, N, cls_tok, dev.type, dev.index)
+    if key not in _cls_rows_cache:
+        _cls_rows_cache[key] = (torch.arange(B, dtype=torch.int64) * N + cls_tok).to(dev)
+    return _cls_rows_cache[key]
+
+
 def cls_layer_forward(z, kv_len, P, fused, drop_p, seeds, pack, cls_tok):
     """The last layer for a reader of the CLS row only: z [B,N,256] (padded, or packed with `pack`) -> (out_cls [B,256], saved)."""
     B, N, D = z.shape
@@ -1128,7 +1139,7 @@ def cls_layer_forward(z, kv_len, P, fused, drop_p, seeds, pack, cls_tok):
     o_cls, r1, lse = attn_cls_fwd(qkv, z, kv_len, pack, cls_tok)
     h, xn2, st2, hsign = ln_gemm(r1, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
     out = gemm_nt(h, w2c, c2, res2d=r1, drop_p=drop_p, seed=seeds[1])
-    rows = (pack[:B].long() if pack is not None else torch.arange(B, device=z.device) * N) + cls_tok
+    rows = pack[:B].long() + cls_tok if pack is not None else _cls_rows(B, N, cls_tok, z.device)
     return out, (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o_cls, lse, r1, xn2, st2, h, drop_p, seeds, hsign, pack, rows, cls_tok)
 
 
