@@ -1195,10 +1195,13 @@ def grouped_ok(z) -> bool:
     return GROUPED_LAUNCHES and z.dtype == torch.bfloat16
 
 
-def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None):
+def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None, ffn_rows=None):
     """layer_forward for the active streams of one fusion layer with ONE launch per step (lists, one entry per stream).
     packs: per stream None or the row_starts() tensor of a PACKED stream (its [B, N, 256] buffers then hold the samples' valid
-    rows back to back: every kernel below works on pack[B] rows instead of B * N)."""
+    rows back to back: every kernel below works on pack[B] rows instead of B * N).
+    ffn_rows = R: only rows 0..R-1 of every sample of the OUTPUT are read by anyone (the image / text streams in the last layer
+    they run in: the bottleneck exchange takes rows 0..3 and nothing else follows) -- the FFN half runs on those B * R rows, the
+    other output rows are left unwritten; the attention half stays dense (the R rows attend to all keys).  Padded streams only."""
     n = len(zs)
     B, D = zs[0].shape[0], D_MODEL
     Ns = [z.shape[1] for z in zs]
@@ -1208,12 +1211,23 @@ def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None):
                                                packs)
     qkv = [q.view(B, N, 3 * D) for q, N in zip(qkv, Ns)]
     o, r1, lse = attn_fwd_grouped(qkv, kv_lens, list(zs), knorm, packs)
-    r1_2 = [r.view(B * N, D) for r, N in zip(r1, Ns)]
+    R = ffn_rows
+    if R is not None:
+        if any(pk is not None for pk in packs) or any(N < R for N in Ns):
+            raise ValueError("ffn_rows: padded streams of at least that many rows")
+        r1_2 = [r[:, :R].reshape(B * R, D) for r in r1]            # the rows somebody reads, gathered (B * R x 256 each)
+    else:
+        r1_2 = [r.view(B * N, D) for r, N in zip(r1, Ns)]
     h, xn2, st2, hsign = ln_gemm_signs_grouped(r1_2, [P[8] for P in Ps], [P[9] for P in Ps], [f[2] for f in fuseds],
                                                [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds], packs)
     out = gemm_nt_grouped(h, [f[3] for f in fuseds], [P[13] for P in Ps], r1_2, drop_p, [sd[1] for sd in seeds], packs)
+    if R is not None:
+        full = [torch.empty(B, N, D, dtype=zs[0].dtype, device=zs[0].device) for N in Ns]
+        for f_, o_ in zip(full, out):
+            f_[:, :R] = o_.view(B, R, D)
+        out = full
     saved = [(zs[i], kv_lens[i], Ps[i][0], Ps[i][8], fuseds[i][5], fuseds[i][6], fuseds[i][4], xn1[i], st1[i], qkv[i], o[i], lse[i],
-              r1[i], xn2[i], st2[i], h[i], drop_p, seeds[i], hsign[i], packs[i]) for i in range(n)]
+              r1_2[i] if R is not None else r1[i], xn2[i], st2[i], h[i], drop_p, seeds[i], hsign[i], packs[i], R) for i in range(n)]
     return [out[i].view(B, Ns[i], D) for i in range(n)], saved
 
 
@@ -1235,12 +1249,20 @@ def layer_backward_grouped(saveds, d_outs, sinks, late):
     kv = col(1)
     seeds = col(17)
     packs = [sv[19] if len(sv) > 19 else None for sv in saveds]
+    R = saveds[0][20] if len(saveds[0]) > 20 else None
+    if R is not None:                     # the FFN half ran on rows 0..R-1 of every sample: so does its backward
+        d_out = [d.view(B, N, D)[:, :R].reshape(B * R, D) for d, N in zip(d_out, Ns)]
     dh, dy2 = gemm_nt_signs_drop_grouped(d_out, w2t, hsign, 1.0 / (1.0 - p), p, [sd[1] for sd in seeds], packs)
     gw2 = gemm_tn_grouped(dy2, h, [(sinks[i].w2, sinks[i].c2) if direct[i] else None for i in range(n)], reds, packs)
     gw1 = gemm_tn_grouped(dh, xn2, [(sinks[i].w1, sinks[i].c1) if direct[i] else None for i in range(n)], reds, packs)
-    r1_2 = [r.view(M, D) for r, M in zip(r1, Ms)]
+    r1_2 = [r.view(-1, D) for r in r1]
     l2 = gemm_lnbwd_grouped(dh, w1t, r1_2, st2, g2, d_out, [sinks[i].gb2 if direct[i] else None for i in range(n)], reds, packs)
     dr1 = [t[0] for t in l2]
+    if R is not None:                     # r1's gradient is zero outside those rows (nothing read the other output rows)
+        dense = [torch.zeros(B, N, D, dtype=d.dtype, device=d.device) for d, N in zip(dr1, Ns)]
+        for f_, d in zip(dense, dr1):
+            f_[:, :R] = d.view(B, R, D)
+        dr1 = [f_.view(-1, D) for f_ in dense]
     dqkv = attn_bwd_grouped(qkv, o, [d.view(B, N, D) for d, N in zip(dr1, Ns)], lse, kv, packs)
     dqkv = [d.view(M, 3 * D) for d, M in zip(dqkv, Ms)]
     gwq = gemm_tn_grouped(dqkv, xn1, [(sinks[i].wqkv, sinks[i].bqkv) if direct[i] else None for i in range(n)], reds, packs)
@@ -1309,6 +1331,7 @@ def _exchange_w(dev):
 #   "none"  -- one launch group per stream (vital signs on the caller's stream, image / text on the two side streams)
 # Measured in one box (bench.py, ms/step): see DESIGN.md section 7.
 GROUP_MODE = "small"
+FFN_ROWS_BEFORE_LAST = True
 
 
 def launch_groups(ms, streams, z, solo=False):
@@ -1401,6 +1424,10 @@ class FusionStackFn(torch.autograd.Function):
             row = [None, None, None]
             # launch groups of this layer: (streams, HIP stream).  Layer 0 keeps one group per stream while the image / text
             # inputs are still being made on the side streams (the vital-sign stream's first layer runs beside the image encoder)
+            # the layer in front of a last layer that runs stream 0 alone, read by a CLS-only reader: the image / text outputs of
+            # THIS layer feed the bottleneck exchange (rows 0..3) and nothing else
+            exchange_only = (final and bool(cfg.get("cls_only")) and li == L - 2 and not cfg["resbottle"]
+                             and (cfg["vsltonly"] == 1 or bool(cfg.get("first_only"))) and FFN_ROWS_BEFORE_LAST)
             if last and cfg.get("cls_only"):       # the reader takes the CLS row only: ops.cls_layer_forward
                 P = params[(li * n_s) * PARAMS_PER_LAYER:(li * n_s + 1) * PARAMS_PER_LAYER]
                 mark(f"f{li}.g0.s")
@@ -1425,7 +1452,8 @@ class FusionStackFn(torch.autograd.Function):
                             [z[m] for m in gms], [cfg["kv"][m] for m in gms],
                             [params[(li * n_s + m) * PARAMS_PER_LAYER:(li * n_s + m + 1) * PARAMS_PER_LAYER] for m in gms],
                             [cfg["fused"][li][m] for m in gms], cfg["drop_p"], [cfg["seeds"][li][m] for m in gms],
-                            [pack_v if m == 0 else None for m in gms])
+                            [pack_v if m == 0 else None for m in gms],
+                            ffn_rows=NB if (exchange_only and 0 not in gms) else None)
                         for i, m in enumerate(gms):
                             outs[m], row[m] = go[i], gsaved[i]
                     else:
