@@ -166,6 +166,21 @@ class TRI_MBT_VSLTCLS(nn.Module):
                                   self.ie_time[1].bias, feat_tab, dt)
         return emb[:n_it], emb[n_it:]
 
+    joint_embeddings = True    # (switch for A/B runs and tests)
+
+    def _joint_embeddings(self, x, img_time, txt_time, dt):
+        """(vslt [B,T,256], it, tt) from ONE autograd node (ops.TieTimeEmbed) when the event embedding and the two time
+        embeddings share ie_time / ie_feat and run as HIP kernels; None: the caller takes the two separate nodes."""
+        if (not self.joint_embeddings or self.args.vslt_type != "TIE" or isinstance(x, PackedTie) or not img_time.is_cuda
+                or not x.is_cuda):
+            return None
+        n_it = img_time.numel()
+        ev = self._time_events(n_it, txt_time.numel(), img_time.device)
+        ev[:, 0] = torch.cat([img_time, txt_time])
+        return ops.TieTimeEmbed.apply(x, ev, n_it, self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight,
+                                      self.ie_vslt[1].bias, self.ie_time[0].weight, self.ie_time[0].bias, self.ie_time[1].weight,
+                                      self.ie_time[1].bias, self.ie_feat.weight, dt)
+
     # NOTE: like the reference, model.train() (2_train.py:128) puts the Swin encoder back into train mode
     # although the constructor called .eval() (:104), so its row-mode StochasticDepth is active while
     # training.  Parity tests call model.img_encoder.eval() explicitly, as the golden generator did.
@@ -313,16 +328,22 @@ class TRI_MBT_VSLTCLS(nn.Module):
         with on_side(0):
             img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
         # ---- vital-sign / lab stream
+        img_time = img_time.reshape(-1).float()
+        txt_time = txt_time.float()
+        it = tt = None
         if self.args.vslt_type == "carryforward":
             vslt_embedding = self.vslt_enc(x).to(dt)
         else:
-            vslt_embedding = self._vslt_embedding(x, dt)
+            joint = self._joint_embeddings(x, img_time, txt_time, dt) if self.args.imgtxt_time == 1 else None
+            if joint is not None:
+                vslt_embedding, it, tt = joint
+            else:
+                vslt_embedding = self._vslt_embedding(x, dt)
             if self.args.vslt_type == "QIE":
                 vslt_embedding = vslt_embedding + demo_embedding.unsqueeze(1).to(dt)
-        img_time = img_time.reshape(-1).float()
-        txt_time = txt_time.float()
         if self.args.imgtxt_time == 1:                                                        # (:216-224)
-            it, tt = self._time_embeddings(img_time, txt_time, demo_embedding if not fused_head else None, dt)
+            if it is None:
+                it, tt = self._time_embeddings(img_time, txt_time, demo_embedding if not fused_head else None, dt)
             if side is not None:
                 for s_ in side:
                     s_.wait_stream(cur)              # the time embeddings were made on the main stream

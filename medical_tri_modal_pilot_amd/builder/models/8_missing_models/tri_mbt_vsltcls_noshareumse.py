@@ -56,6 +56,9 @@ class TRI_MBT_VSLTCLS_NOSHAREUMSE(TRI_MBT_VSLTCLS):
             return torch.nn.functional.linear(h, seq[2].weight).to(dt)
         return ops.LinearFn.apply(h, seq[2].weight, None, dt)
 
+    def _joint_embeddings(self, x, img_time, txt_time, dt):
+        return None                       # three time chains of their own: nothing is shared
+
     def _vslt_embedding(self, x, dt):
         if isinstance(x, PackedTie):
             raise NotImplementedError("TRI_MBT_VSLTCLS_NOSHAREUMSE takes the padded event tensor (no packed batches)")

@@ -757,6 +757,58 @@ class TimeEmbed(torch.autograd.Function):
         return None, grads[4].view(ctx.wshape), grads[5], grads[6], grads[7], grads[8:28], None
 
 
+class TieTimeEmbed(torch.autograd.Function):
+    """TieEmbed of the event tensor and TimeEmbed of the image / text times as ONE autograd node: apply(events [B,T,3],
+    time_events [n,3], n_img, 9 parameters, dtype) -> (vslt [B,T,256], it [n_img,256], tt [n - n_img,256]).  The two nodes
+    share ie_time and ie_feat: apart they cost the tail of the step -- where nothing else runs -- five gradient sums, five more
+    accumulations into the flat buffer and the slicing of the time embedding's gradient (~14 launches of ~4.5 us); here the two
+    backward kernels' results are added once and all nine gradients go into the flat buffer with one multi-tensor copy."""
+
+    @staticmethod
+    def forward(ctx, events, tev, n_img, wv, bv, gv, hv, wt, bt, gt, ht, ftab, dtype):
+        _gpu(events, tev, ftab)
+        B, T, _ = events.shape
+        ev = _c(events.float()).view(B * T, 3)
+        te = _c(tev.float())
+        prm = torch.stack([wv.reshape(-1), bv, gv, hv, wt.reshape(-1), bt, gt, ht]).float().contiguous()
+        ft = _c(ftab.float())
+        out = torch.empty(B, T, D_MODEL, dtype=dtype, device=events.device)
+        emb = torch.empty(te.shape[0], D_MODEL, dtype=dtype, device=events.device)
+        call("mtmp_tie_embed_fwd", _dt(out), _p(ev), _p(prm), _p(ft), _p(out), B * T, _stream())
+        call("mtmp_time_embed_fwd", _dt(emb), _p(te), _p(prm), _p(ft), _p(emb), te.shape[0], _stream())   # (reads the time chain only)
+        ctx.save_for_backward(ev, te, prm)
+        ctx.wshape, ctx.n_img, ctx.dtype = (wv.shape, wt.shape), n_img, dtype
+        ctx.prm = [wv, bv, gv, hv, wt, bt, gt, ht, ftab]
+        ctx.set_materialize_grads(False)
+        return out, emb[:n_img], emb[n_img:]
+
+    @staticmethod
+    def backward(ctx, d_out, d_it, d_tt):
+        ev, te, prm = ctx.saved_tensors
+        dev, lib = ev.device, _lib.lib()
+        g = None
+        if d_it is not None or d_tt is not None:
+            n, n_img = te.shape[0], ctx.n_img
+            z = lambda k: torch.zeros(k, D_MODEL, dtype=ctx.dtype, device=dev)
+            d_time = torch.cat([z(n_img) if d_it is None else d_it.to(ctx.dtype), z(n - n_img) if d_tt is None else d_tt.to(ctx.dtype)])
+            g_t = torch.empty(28, D_MODEL, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.mtmp_tie_bwd_ws_floats(n), dtype=torch.float32, device=dev)
+            call("mtmp_time_embed_bwd", _dt(d_time), _p(te), _p(prm), _p(d_time), _p(g_t), _p(ws), n, _stream())
+            g = g_t
+        if d_out is not None:
+            d_out = _c(d_out)
+            g_v = torch.empty(28, D_MODEL, dtype=torch.float32, device=dev)
+            ws = torch.empty(lib.mtmp_tie_bwd_ws_floats(ev.shape[0]), dtype=torch.float32, device=dev)
+            call("mtmp_tie_embed_bwd", _dt(d_out), _p(ev), _p(prm), _p(d_out), _p(g_v), _p(ws), ev.shape[0], _stream())
+            if g is not None:
+                g_v[4:].add_(g[4:])              # the shared time chain and table (the time kernel's value-chain rows are zero)
+            g = g_v
+        if g is None:
+            return (None,) * 13
+        v = sink_param_grads(ctx.prm, [g[0].view(ctx.wshape[0]), g[1], g[2], g[3], g[4].view(ctx.wshape[1]), g[5], g[6], g[7], g[8:28]])
+        return (None, None, None, *v, None)
+
+
 class TieEmbedPacked(torch.autograd.Function):
     """The same embedding on the ragged batch layout of builder/data: events [E,3] fp32 back to
     back, cu_seqlens [B+1] int32; returns the padded stream layout [B, t_pad, 256] with zero rows past each
