@@ -293,8 +293,11 @@ class TRI_MBT_VSLTCLS(nn.Module):
         # With --multiimages 1 the image stream's key length is 4 + 1 + 49 * (images whose time is not the pad value 10), :226-231:
         # the tokens of image j >= that count are masked as keys and read by nothing -- those images are not encoded either
         # (by POSITION, as the reference masks them; an image in front of the count is encoded whatever its time says).
+        # (maps that are multiples of the 7x7 window at every stage: 224 / 448 pixels a side; other sizes take the reference's
+        #  zero-padded windows and encode every image)
         skip = (bool(getattr(self.args, "skip_missing_images", 1)) and img.is_cuda
-                and self.args.img_model_type == "swin" and torch.is_tensor(missing) and missing.dim() == 1)
+                and self.args.img_model_type == "swin" and torch.is_tensor(missing) and missing.dim() == 1
+                and img.shape[-2] % 224 == 0 and img.shape[-1] % 224 == 0)
 
         def encode(**kw):
             slots = None

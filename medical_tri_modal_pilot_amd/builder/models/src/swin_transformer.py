@@ -12,9 +12,12 @@ Every block runs on libmtmp_hip.so kernels over ONE un-shifted NHWC map:
     W-MSA / SW-MSA  mtmp_swin_window_attn   shift + window partition + bias/mask + softmax + PV +
                                             reverse as address arithmetic (no roll/permute copies)
 The additive table (relative-position bias + shift mask) is constant per block: built once on
-the host and cached.  Feature maps whose side is not a multiple of 7 (e.g. --image-size 512) need
-the reference's zero-padding of windows, which the window kernel does not implement: that case
-raises NotImplementedError.
+the host and cached.  Feature maps whose side is not a multiple of 7 (--image-size 512: 128 / 64 /
+32 / 16 tokens a side) take the reference's zero-padded windows (:150-152): a padded token is a zero
+vector behind norm1, so its q / k / v are the projection's bias -- the qkv map is laid into a
+bias-filled map of the padded size (two torch copies per block), the window kernel runs on that map
+and the result is cropped.  Odd-sized maps are zero-padded in front of a patch merging (:34-44).
+The present-images-only form (`slots`) needs maps that are multiples of the window at every stage.
 """
 import contextlib
 from typing import List
@@ -146,15 +149,24 @@ class ShiftedWindowAttention(nn.Module):
         """xn [n,H,W,C] (already normalised, or raw with `norm` = the block's norm1 to be fused into the qkv
         projection) -> attention output [n,H,W,C] BEFORE the output projection."""
         n, H, W, C = xn.shape
-        if H % WS or W % WS:
-            raise NotImplementedError("feature maps must be multiples of the 7x7 window (use --image-size 224)")
-        shift = 0 if WS >= H else self.shift_size[0]
+        Hp, Wp = -(-H // WS) * WS, -(-W // WS) * WS           # zero-padded to whole windows (:150-152)
+        if (WS >= Hp) != (WS >= Wp):
+            raise NotImplementedError("maps with one side of a single window and the other of several (per-axis shift)")
+        shift = 0 if WS >= Hp else self.shift_size[0]
         if norm is not None:          # xn is the un-normalised map: norm1 + qkv in one launch (mtmp_swin_ln_linear)
             qkv = ops.swin_ln_linear(xn.view(-1, C), norm.weight, norm.bias, norm.eps, _w(self.qkv.weight, xn.dtype),
                                      self.qkv.bias).view(n, H, W, 3 * C)
         else:
             qkv = ops.gemm_nt(xn.view(-1, C), _w(self.qkv.weight, xn.dtype), self.qkv.bias).view(n, H, W, 3 * C)
-        return ops.swin_window_attn(qkv, self.additive_table(shift, xn.dtype, xn.device), self.num_heads, shift)
+        tab = self.additive_table(shift, xn.dtype, xn.device)
+        if (Hp, Wp) == (H, W):
+            return ops.swin_window_attn(qkv, tab, self.num_heads, shift)
+        if ops.live_rows_active():
+            raise NotImplementedError("present-images-only encoding needs maps that are multiples of the 7x7 window")
+        # the pad tokens are zero vectors BEHIND norm1 (the reference pads the normalised map): q / k / v = the bias
+        padded = self.qkv.bias.detach().to(qkv.dtype).expand(n, Hp, Wp, 3 * C).contiguous()
+        padded[:, :H, :W] = qkv
+        return ops.swin_window_attn(padded, tab, self.num_heads, shift)[:, :H, :W].contiguous()
 
 
 class SwinTransformerBlock(nn.Module):
@@ -209,8 +221,11 @@ class PatchMerging(nn.Module):
 
     def forward(self, x):
         n, H, W, C = x.shape
-        if H % 2 or W % 2:
-            raise NotImplementedError("patch merging of odd-sized maps (zero padding) is not on the MI355X path")
+        if H % 2 or W % 2:            # _patch_merging_pad (:34-44): a zero row / column behind the map
+            if ops.live_rows_active():
+                raise NotImplementedError("present-images-only encoding needs even-sized maps in front of every patch merging")
+            x = torch.nn.functional.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+            H, W = H + H % 2, W + W % 2
         y = ops.layernorm_rows(x, self.norm.weight, self.norm.bias, self.norm.eps, merge_hw=(H, W))
         return ops.gemm_nt(y.view(-1, 4 * C), _w(self.reduction.weight, x.dtype)).view(n, H // 2, W // 2, 2 * C)
 

@@ -429,6 +429,11 @@ def _live():
     return None if _LIVE is None else _LIVE[0].data_ptr() + 4 * _LIVE[1]
 
 
+def live_rows_active() -> bool:
+    """inside a rows_live() context (the Swin-side launches then take their row count from the slot table)"""
+    return _LIVE is not None
+
+
 def image_slots(pattern, present_below: int, hw0: int):
     """pattern: int64[B] missing_num ids (device); sample b has an image iff 0 <= pattern[b] < present_below -> int32[2 B + 16]
     (csrc/elementwise.hip image_slots_kernel): slot -> image (present first), image -> slot (B for a sample without image),

@@ -326,6 +326,24 @@ def gen_swin(model):
     save("swin", seed=np.array(21), feat=y, stem=stem[:, ::8, ::8, :], stage1=s1[:, ::8, ::8, :])
 
 
+def gen_swin_sizes():
+    """The real encoder on maps that are NOT multiples of the 7x7 window (zero-padded windows, swin_transformer.py:150-152) and
+    on odd-sized maps in front of a patch merging (_patch_merging_pad, :60-85 / :34-44): --image-size 512 (128 -> 64 -> 32 -> 16
+    tokens a side: padded to 133 / 70 / 35 / 21) and a 200 x 200 input (50 -> 25 -> 13 -> 7: two odd merges)."""
+    args = ref_args(multiimages=0, batch_size=4, transformer_num_layers=2)
+    model = build_model(args)
+    model.img_encoder.eval()
+    out = {}
+    for size, seed in ((512, 31), (200, 32)):
+        g = torch.Generator().manual_seed(seed)
+        img = torch.rand(1 if size == 512 else 2, 1, size, size, generator=g)
+        with torch.no_grad():
+            out[f"feat{size}"] = model.img_encoder(img)
+            out[f"stage1_{size}"] = model.img_encoder.features[1](model.img_encoder.features[0](img))[:, ::8, ::8, :]
+        out[f"seed{size}"] = np.array(seed)
+    save("swin_sizes", **out)
+
+
 # --------------------------------------------------------------------- g5/g7
 class _Logger:
     class _Ev:
@@ -477,6 +495,8 @@ if __name__ == "__main__":
         gen_siblings()
     if "misc" in which:
         gen_misc()
+    if "swin_sizes" in which:
+        gen_swin_sizes()
     if "model" in which:
         gen_model_step(0, "model_step")
         gen_model_step(1, "model_step_multi")

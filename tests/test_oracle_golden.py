@@ -256,6 +256,19 @@ def test_swin_forward(golden_dir):
     np.testing.assert_allclose(y.numpy(), G["feat"], rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("size", [512, 200])
+def test_swin_forward_padded_windows_and_odd_merges(golden_dir, size):
+    """--image-size 512 (maps of 128 / 64 / 32 / 16 tokens a side: every stage zero-pads its windows, swin_transformer.py:150-152)
+    and a 200 x 200 input (50 -> 25 -> 13 -> 7: two odd-sized patch merges, :34-44): the oracle against the real class."""
+    G = _g(golden_dir, "swin_sizes")
+    sd = _model_sd(2)
+    g = torch.Generator().manual_seed(int(G[f"seed{size}"]))
+    img = torch.rand(1 if size == 512 else 2, 1, size, size, generator=g)
+    with torch.no_grad():
+        y = O.swin_forward(sd, "img_encoder", img)
+    np.testing.assert_allclose(y.numpy(), G[f"feat{size}"], rtol=2e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("multi,tag", [(0, "model_step"), (1, "model_step_multi")])
 def test_full_training_step(golden_dir, multi, tag):
     G = _g(golden_dir, tag)
