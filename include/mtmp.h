@@ -400,6 +400,18 @@ int mtmp_swin_mlp_live(int dtype, const void* x, const float* ln_w, const float*
                        float eps, const int32_t* rows_live, void* stream);
 int mtmp_swin_window_attn_live(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W, int C, int heads,
                                int shift, float scale, const int32_t* rows_live, void* stream);
+
+/* Attention half of a Swin block in ONE launch (ABI 4): out = x + row_scale[image] * (proj(window_attention(qkv(norm1(x)))) + b_proj).
+ * Replaces builder/models/src/swin_transformer.py:428-449 (norm1, attn, stochastic_depth, residual) with :115-225
+ * (shifted_window_attention) for maps that are multiples of the 7x7 window.  bf16 only (dtype MTMP_BF16); x, out [n_img, H, W, C]
+ * (out != x), C = 96 or 192, heads = C / 32; wqkv [3C][C], wproj [C][C] bf16; ln_w, ln_b [C], bqkv [3C], bproj [C] fp32; table
+ * [4 window types][heads][64][64] bf16 as mtmp_swin_window_attn's, but with the KEY columns of every group of 16 keys in
+ * accumulator-register order: position 8 h + j (h = 0, 1; j = 0..7) of group g holds key 16 g + (j & 3) + 8 (j >> 2) + 4 h.
+ * row_scale: fp32[n_img] (row-mode StochasticDepth) or NULL; rows_live: NULL or the device word of mtmp_image_slots. */
+int mtmp_swin_attn_block(int dtype, const void* x, const float* ln_w, const float* ln_b, float eps, const void* wqkv,
+                         const float* bqkv, const void* table, const void* wproj, const float* bproj, const float* row_scale,
+                         void* out, int n_img, int H, int W, int C, int heads, int shift, float scale, const int32_t* rows_live,
+                         void* stream);
 int mtmp_gemm_nt_live(int dtype, const void* a, const void* w, const float* bias, const void* res, void* y, int M, int N, int K,
                       int lda, int ldy, int ldr, int act, float drop_p, unsigned seed, const unsigned* seed_dev, const void* gate,
                       float gate_scale, const float* row_scale, int rows_per_scale, const int32_t* rows_live, void* stream);

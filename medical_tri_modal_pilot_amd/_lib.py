@@ -87,6 +87,7 @@ SIGNATURES = {
     "mtmp_swin_ln_linear_live": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_void_p, c_void_p]),
     "mtmp_swin_mlp": (c_int, [c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_longlong, c_int, c_float, c_void_p]),
     "mtmp_swin_mlp_live": (c_int, [c_int] + [c_void_p] * 8 + [c_int, c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p]),
+    "mtmp_swin_attn_block": (c_int, [c_int] + [c_void_p] * 3 + [c_float] + [c_void_p] * 7 + [c_int] * 6 + [c_float, c_void_p, c_void_p]),
     "mtmp_swin_stem_fwd": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p]),
     "mtmp_swin_stem_fwd_live": (c_int, [c_int] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p, c_void_p, c_void_p]),
     "mtmp_adamw_step": (c_int, [c_void_p] * 5 + [c_longlong] + [c_float] * 5 + [c_int, c_float, c_void_p]),

@@ -33,6 +33,7 @@ PAD_LOGIT = -30000.0
 # Both on in the product; tools/dbg A/B scripts flip these module attributes (no environment switches in the package).
 _SPLIT_TAIL = True     # stages 3-4 as two half batches on two streams
 _FUSED_MLP = True      # mtmp_swin_ln_linear / mtmp_swin_mlp (C = 96 / 192)
+_FUSED_ATTN = True     # mtmp_swin_attn_block: norm1 -> qkv -> window attention -> proj -> residual in one launch
 
 
 def _w(p: torch.Tensor, dtype) -> torch.Tensor:
@@ -129,11 +130,12 @@ class ShiftedWindowAttention(nn.Module):
         self.register_buffer("relative_position_index", _relative_position_index(window_size[0]))
         self._tab_key, self._tab = None, None
 
-    def additive_table(self, shift: int, dtype, device) -> torch.Tensor:
+    def additive_table(self, shift: int, dtype, device, acc_order: bool = False) -> torch.Tensor:
         """[4][heads][64][64]: relative-position bias (swin_transformer.py:47-55) + the shift mask of the four
-        window types (interior, last column, last row, corner; :190-203), PAD_LOGIT on the 15 pad keys."""
+        window types (interior, last column, last row, corner; :190-203), PAD_LOGIT on the 15 pad keys.
+        acc_order: the key columns of every 16-key group in MFMA accumulator-register order (mtmp_swin_attn_block)."""
         t = self.relative_position_bias_table
-        key = (shift, dtype, t._version, t.data_ptr())
+        key = (shift, dtype, t._version, t.data_ptr(), acc_order)
         if key != self._tab_key:
             L, h = WS * WS, self.num_heads
             bias = t.detach()[self.relative_position_index.long()].view(L, L, h).permute(2, 0, 1).float()
@@ -142,6 +144,9 @@ class ShiftedWindowAttention(nn.Module):
             tab[:, :, :L, :L] = bias
             if shift > 0:
                 tab[:, :, :L, :L] += _shift_mask(2 * WS, 2 * WS, WS, shift, shift).to(device).unsqueeze(1)
+            if acc_order:          # position 8 h + j of group g <- key 16 g + (j & 3) + 8 (j >> 2) + 4 h
+                src = [16 * g + (j & 3) + 8 * (j >> 2) + 4 * h for g in range(4) for h in range(2) for j in range(8)]
+                tab = tab[..., torch.tensor(src, device=device)]
             self._tab, self._tab_key = tab.to(dtype).contiguous(), key
         return self._tab
 
@@ -194,12 +199,19 @@ class SwinTransformerBlock(nn.Module):
         dt, hw = x.dtype, H * W
         x2 = x.view(-1, C)
         s_attn, s_mlp = self.draw_scales(n, x.device) if scales is None else scales
-        if dt == torch.bfloat16 and C in ops.SWIN_LN_LINEAR_WIDTHS and _FUSED_MLP:
-            a = self.attn(x, norm=self.norm1)
+        at = self.attn
+        if dt == torch.bfloat16 and C in ops.SWIN_ATTN_BLOCK_WIDTHS and _FUSED_ATTN and H % WS == 0 and W % WS == 0:
+            # stages 1-2: the whole attention half in one launch; the 3C-wide qkv map never exists
+            shift = 0 if WS >= H else at.shift_size[0]
+            x2 = ops.swin_attn_block(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, _w(at.qkv.weight, dt), at.qkv.bias,
+                                     at.additive_table(shift, dt, x.device, acc_order=True), at.num_heads, shift,
+                                     _w(at.proj.weight, dt), at.proj.bias, s_attn).view(-1, C)
         else:
-            a = self.attn(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
-        x2 = ops.gemm_nt(a.view(-1, C), _w(self.attn.proj.weight, dt), self.attn.proj.bias, res2d=x2,
-                         row_scale=s_attn, rows_per_scale=hw)
+            if dt == torch.bfloat16 and C in ops.SWIN_LN_LINEAR_WIDTHS and _FUSED_MLP:
+                a = at(x, norm=self.norm1)
+            else:
+                a = at(ops.layernorm_rows(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+            x2 = ops.gemm_nt(a.view(-1, C), _w(at.proj.weight, dt), at.proj.bias, res2d=x2, row_scale=s_attn, rows_per_scale=hw)
         if dt == torch.bfloat16 and C in ops.SWIN_MLP_WIDTHS and _FUSED_MLP:
             # stages 1-2: norm2 -> fc1 -> GELU -> fc2 -> row scale -> residual in one launch; the 4C-wide hidden
             # activation (154 MB per stage-1 block of 64 images) stays in registers

@@ -495,6 +495,214 @@ __global__ __launch_bounds__(256, 3) void swin_ln_linear_kernel(const bf16* x, c
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
+// ------------------------------------------------------------------------------------------
+// Attention half of a Swin block (swin_transformer.py:428-449: x + stochastic_depth(attn(norm1(x))), :115-225) in ONE kernel
+// for the narrow stages (bf16, C = 96 / 192, maps that are multiples of the window): norm1, the qkv projection, the window
+// attention, the output projection, the per-image StochasticDepth factor and the residual.  The four-launch chain
+// (mtmp_swin_ln_linear, mtmp_swin_window_attn, mtmp_gemm_nt) moves the 3C-wide qkv map and the attention output through
+// HBM (308 MB per stage-1 block of 64 images against 77 MB of tokens read and written); here a token is read once and
+// written once.  One workgroup per window, one wave per head (head_dim 32):
+//   * the window's 49 tokens (padded to 64: two 32-token blocks) are normalised once (nn.LayerNorm, a lane pair per token)
+//     into LDS, bf16 -- the B operand of every head's projections;
+//   * Q^T, K^T = W_{q,k}[head] xn^T come out of the MFMA with the head dims on the accumulator ROWS and tokens on the lanes,
+//     V = xn W_v[head]^T with tokens on the rows and head dims on the lanes: accumulator registers 8s..8s+7 of each ARE the
+//     k-step-s operand fragments of S^T = K Q^T and O^T = V^T P^T (common.cuh, "acc -> Frag": both operands of a product
+//     come from accumulators with the same row order, so the contraction index pairs up) -- q, k, v never leave registers;
+//   * the additive table (relative-position bias + shift mask, PAD_LOGIT on the 15 pad keys) is stored by the host with its
+//     key columns in accumulator-register order, so a lane reads its 16 keys of a block as two 16-byte loads;
+//   * the heads' outputs meet in the same LDS tile ([64 tokens][C], bf16 as the unfused chain rounds them), then wave w
+//     computes output channels [32 w, 32 w + 32) of the projection and writes x + scale * (proj + bias) to the token's pixel.
+template <int C>
+__global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x, const float* ln_w, const float* ln_b, float eps,
+                                                                   const bf16* wqkv, const float* bqkv, const bf16* table,
+                                                                   const bf16* wproj, const float* bproj, const float* row_scale,
+                                                                   bf16* out, int n_img_max, int H, int W, int shift, float scale,
+                                                                   const int* rows_live) {
+    constexpr int HEADS = C / DH, KC = C / 16, LDO = C + 8;
+    __shared__ __attribute__((aligned(16))) bf16 sX[LP * LDO];    // normalised tokens, later the heads' outputs
+    const int n_img = rows_live ? min(n_img_max, *rows_live / (H * W)) : n_img_max;
+    const int nWh = H / WS, nWw = W / WS;
+    const int img = blockIdx.x / (nWh * nWw), win = blockIdx.x - img * (nWh * nWw);
+    if (img >= n_img) return;                                     // (whole workgroup: no barrier is skipped by part of it)
+    const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6, r = lane & 31, half = lane >> 5;
+    const int wi = win / nWw, wj = win - wi * nWw;
+    const int type = shift > 0 ? ((wi == nWh - 1 ? 2 : 0) + (wj == nWw - 1 ? 1 : 0)) : 0;
+    auto pix = [&](int t) -> long long {                          // token of this window -> its pixel on the UN-shifted map
+        const int ty = t / WS, tx = t - ty * WS;
+        int yy = wi * WS + ty + shift, xx = wj * WS + tx + shift;
+        if (yy >= H) yy -= H;
+        if (xx >= W) xx -= W;
+        return ((long long)img * H + yy) * W + xx;
+    };
+    // ---- norm1 of the window's tokens (waves 0 and 1: 32 tokens each, a lane pair per token) -> LDS, bf16
+    if (head < 2) {
+        const int tq = 32 * head + r;
+        Frag<bf16> xf[KC];
+        const bf16* xrow = x + pix(tq < L ? tq : 0) * C + 8 * half;
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            xf[c] = frag_load<bf16>(xrow + 16 * c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s1 += to_f32(xf[c].v[j]);
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.0f / C);
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = to_f32(xf[c].v[j]) - mean; s2 += d * d; }
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = rsqrtf(s2 * (1.0f / C) + eps);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = 16 * c + 8 * half;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_w + k), g1 = *reinterpret_cast<const f32x4*>(ln_w + k + 4);
+            const f32x4 o0 = *reinterpret_cast<const f32x4*>(ln_b + k), o1 = *reinterpret_cast<const f32x4*>(ln_b + k + 4);
+            Frag<bf16> y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                y.v[i] = from_f32<bf16>(fmaf((to_f32(xf[c].v[i]) - mean) * rstd, g0[i], o0[i]));
+                y.v[i + 4] = from_f32<bf16>(fmaf((to_f32(xf[c].v[i + 4]) - mean) * rstd, g1[i], o1[i]));
+            }
+            frag_store<bf16>(sX + tq * LDO + k, frag_keep(y, tq < L));          // (pad tokens: zero rows)
+        }
+    }
+    __syncthreads();
+    // ---- this head's projections, from the bias: K^T [head dim][token] and V [token][head dim] first, then Q^T -- each
+    //      becomes operand fragments as soon as it is complete (fewer live accumulators)
+    const bf16* wl = wqkv + (size_t)(head * DH + r) * C + 8 * half;
+    const bf16* xl = sX + r * LDO + 8 * half;
+    Frag<bf16> kf[2][2], vf[2][2], qf[2][2];
+    {
+        f32x16 ka[2], va[2];
+        const float bv = bqkv[2 * C + head * DH + r];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 bk = *reinterpret_cast<const f32x4*>(bqkv + C + head * DH + 8 * i4 + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ka[0][4 * i4 + i] = ka[1][4 * i4 + i] = bk[i];
+                va[0][4 * i4 + i] = va[1][4 * i4 + i] = bv;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const Frag<bf16> wk = frag_load<bf16>(wl + (size_t)C * C + 16 * c), wv = frag_load<bf16>(wl + (size_t)2 * C * C + 16 * c);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const Frag<bf16> xb = frag_load<bf16>(xl + 32 * tb * LDO + 16 * c);
+                mma<bf16>(ka[tb], wk, xb);
+                mma<bf16>(va[tb], xb, wv);
+            }
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) { kf[tb][s_] = frag_from_acc<bf16>(ka[tb], s_); vf[tb][s_] = frag_from_acc<bf16>(va[tb], s_); }
+    }
+    {
+        f32x16 qa[2];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(bqkv + head * DH + 8 * i4 + 4 * half);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qa[0][4 * i4 + i] = qa[1][4 * i4 + i] = bq[i];
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const Frag<bf16> wq = frag_load<bf16>(wl + 16 * c);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) mma<bf16>(qa[tb], wq, frag_load<bf16>(xl + 32 * tb * LDO + 16 * c));
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) qf[tb][s_] = frag_from_acc<bf16>(qa[tb], s_);
+    }
+    __syncthreads();                                              // every wave is done with the normalised tokens
+    // ---- per query block: S^T = K Q^T (rows = keys, cols = queries on lanes), * scale + bias / mask table, softmax over
+    //      the rows, O^T = V^T P^T (rows = head dims), normalised, to LDS as [token][channel]
+    const bf16* tab = table + ((size_t)type * HEADS + head) * LP * LP;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = mma0<bf16>(kf[kb][0], qf[qb][0]);
+            mma<bf16>(st[kb], kf[kb][1], qf[qb][1]);
+        }
+        const bf16* trow = tab + (32 * qb + r) * LP + 8 * half;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const Frag<bf16> t0 = frag_load<bf16>(trow + 32 * kb), t1 = frag_load<bf16>(trow + 32 * kb + 16);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                st[kb][t] = fmaf(st[kb][t], scale, to_f32(t0.v[t]));
+                st[kb][t + 8] = fmaf(st[kb][t + 8], scale, to_f32(t1.v[t]));
+                mx = fmaxf(mx, fmaxf(st[kb][t], st[kb][t + 8]));
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float pv = fast_exp2((st[kb][t] - mx) * LOG2E);
+                st[kb][t] = pv;
+                l += pv;
+            }
+        l += __shfl_xor(l, 32, 64);
+        const float linv = 1.0f / l;
+        f32x16 o = {0};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) mma<bf16>(o, vf[kb][s_], frag_from_acc<bf16>(st[kb], s_));
+        bf16* po = sX + (32 * qb + r) * LDO + head * DH + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) store4<bf16>(po + 8 * g, o[4 * g] * linv, o[4 * g + 1] * linv, o[4 * g + 2] * linv, o[4 * g + 3] * linv);
+    }
+    __syncthreads();
+    // ---- output projection: wave w owns channels [32 w, 32 w + 32); acc^T [channel][token]
+    f32x16 pa[2];
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+        const f32x4 bp = *reinterpret_cast<const f32x4*>(bproj + head * DH + 8 * i4 + 4 * half);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[0][4 * i4 + i] = pa[1][4 * i4 + i] = bp[i];
+    }
+    const bf16* wpl = wproj + (size_t)(head * DH + r) * C + 8 * half;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const Frag<bf16> wp = frag_load<bf16>(wpl + 16 * c);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) mma<bf16>(pa[tb], wp, frag_load<bf16>(xl + 32 * tb * LDO + 16 * c));
+    }
+    const float sc = row_scale ? row_scale[img] : 1.0f;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tq = 32 * tb + r;
+        if (tq < L) {
+            const long long px = pix(tq);
+            const bf16* xr = x + px * C + head * DH + 4 * half;
+            bf16* yo = out + px * C + head * DH + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 res = load4<bf16>(xr + 8 * g);
+                // (rounded where mtmp_gemm_nt's epilogue rounds: the projection, its scaled value, then the sum)
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = round_as<bf16>(round_as<bf16>(pa[tb][4 * g + i]) * sc) + res[i];
+                store4<bf16>(yo + 8 * g, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // y[rows,C] = LayerNorm(x rows; w, b, eps) in `dtype`; w,b fp32.  merge != 0: x is an NHWC map
@@ -604,5 +812,36 @@ extern "C" int mtmp_swin_ln_linear_live(int dtype, const void* x, const float* l
         hipLaunchKernelGGL(swin_ln_linear_kernel<192>, grid, dim3(256), 0, st, (const bf16*)x, ln_w, ln_b, (const bf16*)w, bias,
                            (bf16*)y, M, N, eps, rows_live);
     MTMP_CHECK_LAUNCH("mtmp_swin_ln_linear");
+    return MTMP_OK;
+}
+
+// out = x + row_scale[image] * (proj(window_attention(qkv(norm1(x)))) + b_proj): the attention half of a Swin block
+// (swin_transformer.py:428-449 with :115-225) in one launch.  bf16 only (dtype 1); x, out [n_img, H, W, C] (out != x), C = 96
+// or 192 (heads = C / 32), H and W multiples of 7; wqkv [3C][C], wproj [C][C] bf16; ln_w, ln_b, bqkv [3C], bproj [C] fp32;
+// table [4][heads][64][64] bf16 as mtmp_swin_window_attn's but with the KEY columns of every 16-key group in accumulator-register
+// order (position 8 h + j of group g holds key 16 g + (j & 3) + 8 (j >> 2) + 4 h); row_scale: fp32[n_img] or NULL;
+// rows_live: NULL or the device word of mtmp_image_slots (rows of the [n_img H W] map in use).
+extern "C" int mtmp_swin_attn_block(int dtype, const void* x, const float* ln_w, const float* ln_b, float eps, const void* wqkv,
+                                    const float* bqkv, const void* table, const void* wproj, const float* bproj,
+                                    const float* row_scale, void* out, int n_img, int H, int W, int C, int heads, int shift,
+                                    float scale, const int32_t* rows_live, void* stream) {
+    MTMP_CHECK_ARG(x && ln_w && ln_b && wqkv && bqkv && table && wproj && bproj && out && out != x,
+                   "mtmp_swin_attn_block: null pointer / in place");
+    MTMP_CHECK_ARG(dtype == 1 && (C == 96 || C == 192) && heads * DH == C && n_img > 0 && H > 0 && W > 0 && H % WS == 0 &&
+                       W % WS == 0 && shift >= 0 && shift < WS,
+                   "mtmp_swin_attn_block: bf16 with C = 96 or 192, heads = C / 32, maps that are multiples of 7 only "
+                   "(dtype=%d C=%d heads=%d n=%d H=%d W=%d shift=%d)", dtype, C, heads, n_img, H, W, shift);
+    const long long nwg = (long long)n_img * (H / WS) * (W / WS);
+    MTMP_CHECK_ARG(nwg < (1ll << 31), "mtmp_swin_attn_block: too many windows");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 96)
+        hipLaunchKernelGGL(swin_attn_block_kernel<96>, dim3((unsigned)nwg), dim3(192), 0, st, (const bf16*)x, ln_w, ln_b, eps,
+                           (const bf16*)wqkv, bqkv, (const bf16*)table, (const bf16*)wproj, bproj, row_scale, (bf16*)out, n_img, H,
+                           W, shift, scale, rows_live);
+    else
+        hipLaunchKernelGGL(swin_attn_block_kernel<192>, dim3((unsigned)nwg), dim3(384), 0, st, (const bf16*)x, ln_w, ln_b, eps,
+                           (const bf16*)wqkv, bqkv, (const bf16*)table, (const bf16*)wproj, bproj, row_scale, (bf16*)out, n_img, H,
+                           W, shift, scale, rows_live);
+    MTMP_CHECK_LAUNCH("mtmp_swin_attn_block");
     return MTMP_OK;
 }

@@ -318,6 +318,22 @@ def swin_window_attn(qkv, table, heads, shift):
     return out
 
 
+SWIN_ATTN_BLOCK_WIDTHS = (96, 192)
+
+
+def swin_attn_block(x, ln_w, ln_b, eps, wqkv, bqkv, table, heads, shift, wproj, bproj, row_scale=None):
+    """x [n,H,W,C] bf16 -> x + row_scale[image] * (proj(window_attention(qkv(LayerNorm(x)))) + bproj) in one launch
+    (mtmp_swin_attn_block; C in SWIN_ATTN_BLOCK_WIDTHS, H and W multiples of 7; table in accumulator-register key order:
+    ShiftedWindowAttention.additive_table(..., acc_order=True))."""
+    _gpu(x)
+    x = _c(x)
+    n, H, W, C = x.shape
+    out = torch.empty_like(x)
+    call("mtmp_swin_attn_block", _dt(x), _p(x), _p(ln_w), _p(ln_b), float(eps), _p(_c(wqkv)), _p(bqkv), _p(table), _p(_c(wproj)),
+         _p(bproj), _p(row_scale), _p(out), n, H, W, C, heads, int(shift), float((C // heads) ** -0.5), _live(), _stream())
+    return out
+
+
 REDUCE_BATCH_MAX = 8
 LATE_REDUCTIONS = True         # FusionStackFn.backward: that launch goes out behind the NEXT bottleneck exchange
 FOLD_DROPOUT_BWD = True         # layer_backward: drop2's backward inside the dH launch (A/B: tools/dbg/ab_patch.py)

@@ -816,6 +816,47 @@ def test_train_step_at_image_size_512_vs_oracle(ops):
     assert losses[0] == losses[1], (losses[0], losses[1])
 
 
+@pytest.mark.parametrize("H,C,heads,shift", [(56, 96, 3, 0), (56, 96, 3, 3), (28, 192, 6, 3), (28, 192, 6, 0), (14, 96, 3, 3),
+                                             (7, 192, 6, 3)])
+def test_swin_attention_half_in_one_launch(ops, monkeypatch, H, C, heads, shift):
+    """mtmp_swin_attn_block (norm1 -> qkv -> window attention -> proj -> StochasticDepth factor -> residual in one launch, q / k / v
+    and the attention output never in HBM) against the chain of launches it replaces, on the same block and input: bf16 results
+    that differ by accumulation order only (the roundings sit in the same places); with a live-row word the images in front of
+    it come out the same."""
+    from medical_tri_modal_pilot_amd.builder.models.src import swin_transformer as ST
+    g = torch.Generator().manual_seed(H + C + shift)
+    blk = ST.SwinTransformerBlock(C, heads, [7, 7], [shift, shift], 0.1)
+    sd = {k: filler.fill_tensor("blk." + k, v) for k, v in blk.state_dict().items()}
+    for k in sd:
+        if k.endswith("bias"):
+            sd[k] = 0.2 * torch.randn(sd[k].shape, generator=g)
+    sd["attn.relative_position_bias_table"] = torch.randn(sd["attn.relative_position_bias_table"].shape, generator=g)
+    blk.load_state_dict(sd)
+    blk = blk.to(DEV).eval()
+    n = 3
+    x = torch.randn(n, H, H, C, generator=g).to(DEV, torch.bfloat16)
+    scales = (torch.tensor([1.25, 0.0, 1.25], device=DEV), None)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ST, "_FUSED_ATTN", fused)
+        with torch.no_grad():
+            res[fused] = blk(x, scales=scales).float()
+    t = f"swin_attn_block[H={H},C={C},shift={shift}]"
+    check(t, res[True], res[False], 1e-2)
+    assert float((res[True] - res[False]).abs().max()) <= 0.07 * float(res[False].abs().max()), t      # no element is off by much
+    assert torch.equal(res[True][1], res[False][1])              # (factor 0: the attention branch is dropped, x passes through the MLP half)
+    # live rows: two of the three images
+    at = blk.attn
+    word = torch.tensor([2 * H * H], dtype=torch.int32, device=DEV)
+    sh = 0 if 7 >= H else shift
+    args = (x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, ST._w(at.qkv.weight, x.dtype), at.qkv.bias,
+            at.additive_table(sh, x.dtype, x.device, acc_order=True), heads, sh, ST._w(at.proj.weight, x.dtype), at.proj.bias, scales[0])
+    full = ops.swin_attn_block(*args)
+    with ops.rows_live(word, 0):
+        part = ops.swin_attn_block(*args)
+    assert torch.equal(part[:2], full[:2])
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("H,C,heads,shift", [(16, 768, 24, 3), (32, 384, 12, 3), (25, 192, 6, 3), (13, 384, 12, 0), (5, 96, 3, 3),
                                              (128, 96, 3, 3)])

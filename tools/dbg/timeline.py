@@ -49,6 +49,6 @@ def report():
         print("%9.1f us  %s" % (v - t0, k), file=sys.stderr)
 
 
-sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "20", "--warmup", "8", "--probe-launches", "0"] + sys.argv[1:]
+sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "20", "--warmup", "8", "--probe-launches", "0", "--instep-steps", "0"] + sys.argv[1:]
 import runpy
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
