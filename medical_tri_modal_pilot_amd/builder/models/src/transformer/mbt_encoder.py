@@ -177,6 +177,9 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         self.segment_boundaries = []
         zs = (streams[0], streams[1], streams[2])
         cls_v = None
+        # the layer in front of a CLS-only last layer: its image / text outputs feed the bottleneck exchange and nothing else
+        # (ops.layer_forward_grouped ffn_rows) -- by GLOBAL layer index, whatever segment it falls into
+        g_ex = len(fl) - 2 if (cls_only and not self.resbottle) else -1
         for si in range(len(bounds) - 1):
             seg = fl[bounds[si]:bounds[si + 1]]
             final = si == len(bounds) - 2
@@ -194,7 +197,8 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
             cfg = dict(n_layers=len(seg), vsltonly=self.vsltonly, resbottle=bool(self.resbottle), kv=kv_fused, sinks=sinks,
                        prebuilt=fused_in or si > 0, final=final, bott_rows_unused=True, first_only=first_only and final,
                        missing=missing, drop_p=p, seeds=seeds, fused=fused, dtype=dt, side_streams=self._side_streams(dev),
-                       inputs_on_side=side_in is not None and si == 0, pack_v=pack_v, cls_only=cls_only and final)
+                       inputs_on_side=side_in is not None and si == 0, pack_v=pack_v, cls_only=cls_only and final,
+                       exchange_only_layer=g_ex - bounds[si] if bounds[si] <= g_ex < bounds[si + 1] else -1)
             out_v, out_i, out_t, cls_v = ops.FusionStackFn.apply(zs[0], zs[1], zs[2], self.bottlenecks, *params, cfg)
             zs = (out_v, out_i, out_t)
             if not final:

@@ -535,29 +535,33 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
         return ((long long)img * H + yy) * W + xx;
     };
     // ---- norm1 of the window's tokens (waves 0 and 1: 32 tokens each, a lane pair per token) -> LDS, bf16
-    if (head < 2) {
-        const int tq = 32 * head + r;
-        Frag<bf16> xf[KC];
-        const bf16* xrow = x + pix(tq < L ? tq : 0) * C + 8 * half;
+    // (wide rows: a wave normalises 16 tokens with four lanes per token, so that a lane keeps KC / 2 fragments, not KC)
+    constexpr int LPT = KC >= 12 ? 4 : 2, TPW = 64 / LPT, KL = KC * 2 / LPT;      // lanes per token, tokens per wave, fragments per lane
+    if (head < LP / TPW) {
+        const int tq = TPW * head + (LPT == 2 ? r : (lane & 15)), part = LPT == 2 ? half : (lane >> 4);
+        Frag<bf16> xf[KL];
+        const bf16* xrow = x + pix(tq < L ? tq : 0) * C + 8 * part;
         float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            xf[c] = frag_load<bf16>(xrow + 16 * c);
+        for (int c = 0; c < KL; ++c) {
+            xf[c] = frag_load<bf16>(xrow + 8 * LPT * c);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s1 += to_f32(xf[c].v[j]);
         }
         s1 += __shfl_xor(s1, 32, 64);
+        if (LPT == 4) s1 += __shfl_xor(s1, 16, 64);
         const float mean = s1 * (1.0f / C);
         float s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < KC; ++c)
+        for (int c = 0; c < KL; ++c)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = to_f32(xf[c].v[j]) - mean; s2 += d * d; }
         s2 += __shfl_xor(s2, 32, 64);
+        if (LPT == 4) s2 += __shfl_xor(s2, 16, 64);
         const float rstd = rsqrtf(s2 * (1.0f / C) + eps);
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const int k = 16 * c + 8 * half;
+        for (int c = 0; c < KL; ++c) {
+            const int k = 8 * LPT * c + 8 * part;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(ln_w + k), g1 = *reinterpret_cast<const f32x4*>(ln_w + k + 4);
             const f32x4 o0 = *reinterpret_cast<const f32x4*>(ln_b + k), o1 = *reinterpret_cast<const f32x4*>(ln_b + k + 4);
             Frag<bf16> y;
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
                 va[0][4 * i4 + i] = va[1][4 * i4 + i] = bv;
             }
         }
-#pragma unroll
+#pragma unroll(KC >= 12 ? 4 : KC)
         for (int c = 0; c < KC; ++c) {
             const Frag<bf16> wk = frag_load<bf16>(wl + (size_t)C * C + 16 * c), wv = frag_load<bf16>(wl + (size_t)2 * C * C + 16 * c);
 #pragma unroll
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
 #pragma unroll
             for (int i = 0; i < 4; ++i) qa[0][4 * i4 + i] = qa[1][4 * i4 + i] = bq[i];
         }
-#pragma unroll
+#pragma unroll(KC >= 12 ? 4 : KC)
         for (int c = 0; c < KC; ++c) {
             const Frag<bf16> wq = frag_load<bf16>(wl + 16 * c);
 #pragma unroll
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
         for (int i = 0; i < 4; ++i) pa[0][4 * i4 + i] = pa[1][4 * i4 + i] = bp[i];
     }
     const bf16* wpl = wproj + (size_t)(head * DH + r) * C + 8 * half;
-#pragma unroll
+#pragma unroll(KC >= 12 ? 4 : KC)
     for (int c = 0; c < KC; ++c) {
         const Frag<bf16> wp = frag_load<bf16>(wpl + 16 * c);
 #pragma unroll

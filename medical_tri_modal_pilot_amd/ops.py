@@ -318,6 +318,8 @@ def swin_window_attn(qkv, table, heads, shift):
     return out
 
 
+# (the 384-wide stage, 128 windows per half batch, was instantiated and measured: 7.93 vs 7.94 ms/step -- one round of
+#  workgroups bound by their own chain of weight fetches, as long as the four launches it replaces; not kept)
 SWIN_ATTN_BLOCK_WIDTHS = (96, 192)
 
 
@@ -1497,10 +1499,9 @@ class FusionStackFn(torch.autograd.Function):
             row = [None, None, None]
             # launch groups of this layer: (streams, HIP stream).  Layer 0 keeps one group per stream while the image / text
             # inputs are still being made on the side streams (the vital-sign stream's first layer runs beside the image encoder)
-            # the layer in front of a last layer that runs stream 0 alone, read by a CLS-only reader: the image / text outputs of
-            # THIS layer feed the bottleneck exchange (rows 0..3) and nothing else
-            exchange_only = (final and bool(cfg.get("cls_only")) and li == L - 2 and not cfg["resbottle"]
-                             and (cfg["vsltonly"] == 1 or bool(cfg.get("first_only"))) and FFN_ROWS_BEFORE_LAST)
+            # the layer in front of a last layer that runs stream 0 alone, read by a CLS-only reader (the encoder names it, by its
+            # index in this segment): the image / text outputs of THIS layer feed the bottleneck exchange (rows 0..3) and nothing else
+            exchange_only = li == cfg.get("exchange_only_layer", -1) and FFN_ROWS_BEFORE_LAST
             if last and cfg.get("cls_only"):       # the reader takes the CLS row only: ops.cls_layer_forward
                 P = params[(li * n_s) * PARAMS_PER_LAYER:(li * n_s + 1) * PARAMS_PER_LAYER]
                 mark(f"f{li}.g0.s")

@@ -816,9 +816,10 @@ def test_train_step_at_image_size_512_vs_oracle(ops):
     assert losses[0] == losses[1], (losses[0], losses[1])
 
 
-@pytest.mark.parametrize("H,C,heads,shift", [(56, 96, 3, 0), (56, 96, 3, 3), (28, 192, 6, 3), (28, 192, 6, 0), (14, 96, 3, 3),
-                                             (7, 192, 6, 3)])
-def test_swin_attention_half_in_one_launch(ops, monkeypatch, H, C, heads, shift):
+@pytest.mark.parametrize("n,H,C,heads,shift", [(3, 56, 96, 3, 0), (3, 56, 96, 3, 3), (3, 28, 192, 6, 3), (3, 28, 192, 6, 0),
+                                               (3, 14, 96, 3, 3), (3, 7, 192, 6, 3),
+                                               (33, 56, 96, 3, 3)])
+def test_swin_attention_half_in_one_launch(ops, monkeypatch, n, H, C, heads, shift):
     """mtmp_swin_attn_block (norm1 -> qkv -> window attention -> proj -> StochasticDepth factor -> residual in one launch, q / k / v
     and the attention output never in HBM) against the chain of launches it replaces, on the same block and input: bf16 results
     that differ by accumulation order only (the roundings sit in the same places); with a live-row word the images in front of
@@ -833,28 +834,30 @@ def test_swin_attention_half_in_one_launch(ops, monkeypatch, H, C, heads, shift)
     sd["attn.relative_position_bias_table"] = torch.randn(sd["attn.relative_position_bias_table"].shape, generator=g)
     blk.load_state_dict(sd)
     blk = blk.to(DEV).eval()
-    n = 3
     x = torch.randn(n, H, H, C, generator=g).to(DEV, torch.bfloat16)
-    scales = (torch.tensor([1.25, 0.0, 1.25], device=DEV), None)
+    sc = torch.full((n,), 1.25, device=DEV)
+    sc[1] = 0.0
+    scales = (sc, None)
     res = {}
     for fused in (False, True):
         monkeypatch.setattr(ST, "_FUSED_ATTN", fused)
         with torch.no_grad():
             res[fused] = blk(x, scales=scales).float()
-    t = f"swin_attn_block[H={H},C={C},shift={shift}]"
+    t = f"swin_attn_block[n={n},H={H},C={C},shift={shift}]"
     check(t, res[True], res[False], 1e-2)
     assert float((res[True] - res[False]).abs().max()) <= 0.07 * float(res[False].abs().max()), t      # no element is off by much
     assert torch.equal(res[True][1], res[False][1])              # (factor 0: the attention branch is dropped, x passes through the MLP half)
     # live rows: two of the three images
     at = blk.attn
-    word = torch.tensor([2 * H * H], dtype=torch.int32, device=DEV)
+    n_live = n - 1 if n > 3 else 2
+    word = torch.tensor([n_live * H * H], dtype=torch.int32, device=DEV)
     sh = 0 if 7 >= H else shift
     args = (x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, ST._w(at.qkv.weight, x.dtype), at.qkv.bias,
             at.additive_table(sh, x.dtype, x.device, acc_order=True), heads, sh, ST._w(at.proj.weight, x.dtype), at.proj.bias, scales[0])
     full = ops.swin_attn_block(*args)
     with ops.rows_live(word, 0):
         part = ops.swin_attn_block(*args)
-    assert torch.equal(part[:2], full[:2])
+    assert torch.equal(part[:n_live], full[:n_live])
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -1386,14 +1389,16 @@ def test_packed_batch_training_steps_vs_golden(ops, graph):
     assert abs(tl - float(Gd["test_loss"])) < 1e-4
 
 
-BF16_STEP_GATES = dict(loss=1.5e-3, grad_norm=0.12, grad_digest=0.12, test_loss=1.5e-3)     # ~2 x the worst measured on MI355X (see the test)
+BF16_STEP_GATES = dict(loss=3.5e-3, grad_norm=0.14, grad_digest=0.14, test_loss=1.8e-3)     # ~2 x the worst measured on MI355X (see the test)
 
 
 def test_full_training_step_bf16_tolerance(ops):
     """bf16 MFMA build against the fp32 golden of the reference: the benchmarked build runs its own kernels for the heaviest
     GEMMs (LDS-DMA row-panel / weight-gradient kernels), so its step is gated per tensor at about twice the error measured on
-    MI355X (round 3: loss |diff| 6.2e-4, test loss 7.1e-4; worst tensor -- a query-projection BIAS gradient, a sum with heavy
-    cancellation -- 6.0e-2 in L2 norm and in its sampled entries; the median tensor is far below), not at a blanket figure."""
+    MI355X (round 3: loss |diff| 6.2e-4 ... 1.7e-3 -- it moved within that range when the image encoder's attention half became
+    one kernel with another accumulation order, the encoder's features keeping their 1.2e-2 against the golden --, test loss
+    8.7e-4; worst tensor -- a query-projection BIAS gradient, a sum with heavy cancellation -- 7e-2 in L2 norm and in its sampled
+    entries; the median tensor is far below), not at a blanket figure."""
     Gd, model, grads, params1, loss1, loss2, tl, lg, _ = _run_steps("bf16", 0, "model_step", True)
     gt = BF16_STEP_GATES
     REPORT["step[bf16].loss_abs_err"] = {"rel_err": abs(loss1 - float(Gd["loss"])), "tol": gt["loss"]}
