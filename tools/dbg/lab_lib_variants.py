@@ -1,3 +1,3 @@
+# scratch: VARIANTS = {name: [(file, old, new), ...]} for tools/lab_lib.py (patched copies of csrc/, timing experiments only)
 VARIANTS = {
-    "nopers": [("swin.hip", "if (C == 96 && nwg >= 2048) {", "if (C == 96 && nwg >= (1ll << 40)) {")],
 }
