@@ -337,7 +337,11 @@ def swin_attn_block(x, ln_w, ln_b, eps, wqkv, bqkv, table, heads, shift, wproj, 
 
 
 REDUCE_BATCH_MAX = 8
-LATE_REDUCTIONS = True         # FusionStackFn.backward: that launch goes out behind the NEXT bottleneck exchange
+# FusionStackFn.backward: True = a layer's reduction launch goes out behind the NEXT bottleneck exchange (one layer late).  That
+# was worth 0.05 ms while every layer ran three dense streams; with the CLS-only last layer and the row-restricted FFN in front
+# of it the in-place order is the faster one (full 8.00 vs 8.06 ms/step, ragged 5.96 vs 6.01, --force-ddp 8.11 vs 8.20; four
+# A/B rounds in one box, tools/dbg/ab_modflag.sh).
+LATE_REDUCTIONS = False
 FOLD_DROPOUT_BWD = True         # layer_backward: drop2's backward inside the dH launch (A/B: tools/dbg/ab_patch.py)
 DEFER_REDUCTIONS = True        # layer_backward: one mtmp_reduce_batch per layer and stream instead of seven reduction launches
 
@@ -1604,7 +1608,7 @@ class FusionStackFn(torch.autograd.Function):
             dz[0][:, NB, :] += d_cls.to(dt)
         pgrads = [None] * len(pshapes)
         d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
-        # A layer's gradient reductions (one mtmp_reduce_batch launch per stream) are issued one layer LATE, on the same stream:
+        # With LATE_REDUCTIONS a layer's gradient reductions (one mtmp_reduce_batch launch per stream) are issued one layer LATE, on the same stream:
         # the bottleneck exchange in between needs the streams' dz but none of their parameter gradients, and it is the image /
         # text streams' last launches that the vital-sign stream waits for there.
         late = [[], [], []]          # keyed by the first stream of the launch group that produced them
