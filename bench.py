@@ -386,6 +386,7 @@ def main():
         # script (counters / traces cannot be read from inside it); committed under profiles/ with their method
         traffic = traffic_src = rocprof_us = rocprof_src = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        tj = {}
         if a.dtype == "bf16" and a.workload == "full" and os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
@@ -413,6 +414,8 @@ def main():
             roof("attn_bwd", "attn_bwd_dq_kernel + attn_bwd_dkdv_kernel (vslt stream; algorithmic flops = 2.5 x forward)"),
             roof("gemm_tn", "gemm_tn_dma_kernel (vslt-stream QKV weight gradient, M x 768 x 256; its reduction is deferred into "
                             "the layer's mtmp_reduce_batch launch)")]
+        for r, key in zip(out["roofline_more"], ("attn_bwd", "gemm_tn")):      # rocprofv3 averages of the committed trace, as above
+            r.update((tj.get("more") or {}).get(key) or {})
         out["roofline_more"] = [r for r in out["roofline_more"] if r["avg_launch_ms"] > 0]
         if world == 1 and not a.no_cpu_baseline:
             shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.is_floating_point()}
