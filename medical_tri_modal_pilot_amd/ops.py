@@ -1561,8 +1561,9 @@ class FusionStackFn(torch.autograd.Function):
         ctx.shapes = (B, Ns, [p.shape for p in params])
         ctx.set_materialize_grads(False)
         ctx.cls_only = cls_out is not None
-        if cls_out is not None:            # nothing but the CLS row exists of the last layer's output: one-row placeholders
-            outs_full = [torch.zeros(B, NB + 1, D_MODEL, dtype=dt, device=dev) for _ in range(3)]
+        if cls_out is not None:            # nothing but the CLS row exists of the last layer's output: placeholders (one fill, three views)
+            ph = torch.zeros(1, NB + 1, D_MODEL, dtype=dt, device=dev)
+            outs_full = [ph.expand(B, -1, -1) for _ in range(3)]
             ctx.mark_non_differentiable(*outs_full)
             return outs_full[0], outs_full[1], outs_full[2], cls_out
         outs_full = [z[m] if z[m] is not None else torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev) for m in range(3)]
