@@ -500,9 +500,9 @@ __global__ __launch_bounds__(256, 3) void swin_ln_linear_kernel(const bf16* x, c
 // for the narrow stages (bf16, C = 96 / 192, maps that are multiples of the window): norm1, the qkv projection, the window
 // attention, the output projection, the per-image StochasticDepth factor and the residual.  The four-launch chain
 // (mtmp_swin_ln_linear, mtmp_swin_window_attn, mtmp_gemm_nt) moves the 3C-wide qkv map and the attention output through
-// HBM (308 MB per stage-1 block of 64 images against 77 MB of tokens read and written); here a token is read once and
+// HBM (424 MB per stage-1 block of 64 images against 77 MB of tokens read and written); here a token is read once and
 // written once.  One workgroup per window, one wave per head (head_dim 32):
-//   * the window's 49 tokens (padded to 64: two 32-token blocks) are normalised once (nn.LayerNorm, a lane pair per token)
+//   * the window's 49 tokens (padded to 64: two 32-token blocks) are normalised once (nn.LayerNorm, two or four lanes per token)
 //     into LDS, bf16 -- the B operand of every head's projections;
 //   * Q^T, K^T = W_{q,k}[head] xn^T come out of the MFMA with the head dims on the accumulator ROWS and tokens on the lanes,
 //     V = xn W_v[head]^T with tokens on the rows and head dims on the lanes: accumulator registers 8s..8s+7 of each ARE the
