@@ -3,6 +3,7 @@ file tools/dbg/lab_lib_variants.py: VARIANTS = {name: [(file, old, new), ...]} (
 
     python tools/lab_lib.py build                 # build container: tools/dbg/_lab/<name>/libmtmp_hip.so for every variant (+ "base")
     python tools/lab_lib.py bench NAME [bench.py flags]   # GPU box: bench.py on that library (sets _lib.LIB_PATH before anything loads)
+    python tools/lab_lib.py run NAME SCRIPT [flags]       # GPU box: any script of the repo on that library
 """
 import os
 import runpy
@@ -47,8 +48,20 @@ def bench(name, argv):
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 
 
+def run(name, script, argv):
+    """any script of the repo on that library: python tools/lab_lib.py run NAME tools/dbg/swin_blk_bench.py"""
+    sys.path.insert(0, ROOT)
+    from medical_tri_modal_pilot_amd import _lib
+    _lib.LIB_PATH = os.path.join(LAB, name, "libmtmp_hip.so")
+    assert os.path.exists(_lib.LIB_PATH), _lib.LIB_PATH
+    sys.argv = [script] + argv
+    runpy.run_path(os.path.join(ROOT, script), run_name="__main__")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "run":
+        run(sys.argv[2], sys.argv[3], sys.argv[4:])
     else:
         bench(sys.argv[2], sys.argv[3:])
