@@ -509,10 +509,17 @@ def test_dropout_mask_consistency(ops):
 
 
 # ------------------------------------------------------------------ TIE / stem / AdamW
+_MODEL_SD = {}
+
+
 def _model_sd(L):
-    sd = {k: filler.fill_tensor(k, torch.zeros(s)) for k, s in reference_state_shapes(L).items()}
-    sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
-    return sd
+    """closed-form weights of the reference's state_dict at L layers (made once per L: ~30 M values through the hash filler;
+    the tensors are shared between callers, which load / clone them and never write into them)"""
+    if L not in _MODEL_SD:
+        sd = {k: filler.fill_tensor(k, torch.zeros(s)) for k, s in reference_state_shapes(L).items()}
+        sd["fusion_transformer.positional_encoding.pe"] = O.sinusoid_table(2500, 256).unsqueeze(0)
+        _MODEL_SD[L] = sd
+    return dict(_MODEL_SD[L])
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -806,10 +813,10 @@ def test_train_step_at_image_size_512_vs_oracle(ops):
                   x_txt=bt["txt"], x_img=bt["img"], imgtxt_time=(bt["img_time"], bt["txt_time"]), scaler=None,
                   missing=bt["missing"], reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
         losses[graph] = [get_trainer(iteration=it, input_lengths=bt["input_lengths"].clone(), txt_lengths=bt["txt_lengths"].clone(),
-                                     flow_type="train", **kw)[1] for it in (1, 2, 3)]
+                                     flow_type="train", **kw)[1] for it in (1, 2)]
         del model, opt
     tr = O.OracleTrainer(_model_sd(L), O.Cfg(n_layers=L), lr_init=args.lr_init, batch_size=args.batch_size, iters_per_epoch=10)
-    ref = [tr.step(bt, it) for it in (1, 2, 3)]
+    ref = [tr.step(bt, it) for it in (1, 2)]
     worst = max(abs(a - b) for a, b in zip(losses[0], ref))
     REPORT["image512_step[fp32].loss"] = {"rel_err": worst, "tol": 1e-4}
     assert worst < 1e-4, (losses[0], ref)
@@ -2054,18 +2061,17 @@ def test_layer_with_ffn_on_read_rows_only(ops, Ns, lens):
 def test_joint_embedding_node_equals_separate_nodes(ops, monkeypatch):
     """ops.TieTimeEmbed (event embedding + image / text time embeddings as one autograd node: one sum of the shared ie_time /
     ie_feat gradients, one multi-tensor copy into the flat buffer) against ops.TieEmbed + ops.TimeEmbed through autograd's own
-    accumulation: same kernels, a two-operand sum either way -> bit-identical losses and parameters, eager and replayed."""
+    accumulation: same kernels, a two-operand sum either way -> bit-identical losses and parameters (bf16 replayed, fp32 eager)."""
     import importlib
     cls = importlib.import_module("medical_tri_modal_pilot_amd.builder.models.8_missing_models.tri_mbt_vsltcls").TRI_MBT_VSLTCLS
     lens = [[96, 50, 7, 1], [96, 96, 96, 96], [3, 96, 20, 64]]
     res = {}
     for joint in (True, False):
         monkeypatch.setattr(cls, "joint_embeddings", joint)
-        for graph in (0, 1):
-            for dtype in ("bf16", "fp32"):
-                res[joint, graph, dtype] = _loop(graph, 0.0, dtype, 3, lens)[:2]
-    for graph in (0, 1):
-        for dtype in ("bf16", "fp32"):
+        for graph, dtype in ((1, "bf16"), (0, "fp32")):
+            res[joint, graph, dtype] = _loop(graph, 0.0, dtype, 3, lens)[:2]
+    for graph, dtype in ((1, "bf16"), (0, "fp32")):
+        if True:
             a, b = res[True, graph, dtype], res[False, graph, dtype]
             assert a[0] == b[0], (graph, dtype, a[0], b[0])
             assert torch.equal(a[1], b[1]), (graph, dtype, float((a[1] - b[1]).abs().max()))
