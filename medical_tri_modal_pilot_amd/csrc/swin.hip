@@ -518,7 +518,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
                                                                    const bf16* wproj, const float* bproj, const float* row_scale,
                                                                    bf16* out, int n_img_max, int H, int W, int shift, float scale,
                                                                    const int* rows_live) {
-    constexpr int HEADS = C / DH, KC = C / 16, LDO = C + 8;
+    constexpr int HEADS = C / DH, KC = C / 16, LDO = C + 8, UNR = KC >= 12 ? 4 : KC;     // (UNR: unroll of the k loops)
     __shared__ __attribute__((aligned(16))) bf16 sX[LP * LDO];    // normalised tokens, later the heads' outputs
     const int n_img = rows_live ? min(n_img_max, *rows_live / (H * W)) : n_img_max;
     const int nWh = H / WS, nWw = W / WS;
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
                 va[0][4 * i4 + i] = va[1][4 * i4 + i] = bv;
             }
         }
-#pragma unroll(KC >= 12 ? 4 : KC)
+#pragma unroll UNR
         for (int c = 0; c < KC; ++c) {
             const Frag<bf16> wk = frag_load<bf16>(wl + (size_t)C * C + 16 * c), wv = frag_load<bf16>(wl + (size_t)2 * C * C + 16 * c);
 #pragma unroll
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
 #pragma unroll
             for (int i = 0; i < 4; ++i) qa[0][4 * i4 + i] = qa[1][4 * i4 + i] = bq[i];
         }
-#pragma unroll(KC >= 12 ? 4 : KC)
+#pragma unroll UNR
         for (int c = 0; c < KC; ++c) {
             const Frag<bf16> wq = frag_load<bf16>(wl + 16 * c);
 #pragma unroll
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
         for (int i = 0; i < 4; ++i) pa[0][4 * i4 + i] = pa[1][4 * i4 + i] = bp[i];
     }
     const bf16* wpl = wproj + (size_t)(head * DH + r) * C + 8 * half;
-#pragma unroll(KC >= 12 ? 4 : KC)
+#pragma unroll UNR
     for (int c = 0; c < KC; ++c) {
         const Frag<bf16> wp = frag_load<bf16>(wpl + 16 * c);
 #pragma unroll
