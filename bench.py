@@ -62,7 +62,7 @@ WORKLOADS = {
              "(N_v=1005), 224x224 CXR, 128-tok text"),
     "ragged": (64, 1000, 6, 0, 1, True, "mixed",
                "BASELINE configs[3] shape: configs[1] with len ~ U{3..1000} and mixed missing modalities; roofline flops "
-               "still count the dense N^2"),
+               "count the batch's own lengths"),
     "cfg5": (128, 2000, 12, 1, 4, False, "none",
              "BASELINE configs[4]: multiimages with 4 images per sample (N_i=201), TIE-len 2000 (N_v=2005), 12 layers, "
              "batch 128/GPU"),
@@ -289,9 +289,19 @@ def main():
         raise SystemExit(f"non-finite loss {loss}")
 
     n_tok = TIE_LEN + 5
-    flops = {"attn_fwd": 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
-             "attn_bwd": 10.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
-             "gemm_tn": 2.0 * B_PER_GPU * n_tok * 768 * 256}
+    flops_dense = {"attn_fwd": 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
+                   "attn_bwd": 10.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
+                   "gemm_tn": 2.0 * B_PER_GPU * n_tok * 768 * 256}
+    # The roofline counts the work a launch DOES.  On a ragged batch the attention kernels read keys below kv_len only (always) and,
+    # with the packed stream (--pack-rows 1), run no pad query row either; the weight gradient then sees the live rows only.  Pricing
+    # those launches at the dense N^2 made the same kernel look 1.5x closer to peak: use the batch's own lengths.
+    kv = [min(int(n), TIE_LEN) + 5 for n in in_len_host.tolist()]
+    if a.pack_rows:
+        flops = {"attn_fwd": 4.0 * 4 * 64 * sum(k * k for k in kv), "attn_bwd": 10.0 * 4 * 64 * sum(k * k for k in kv),
+                 "gemm_tn": 2.0 * sum(kv) * 768 * 256}
+    else:           # padded layout: every query row runs, against kv_len keys; the weight gradient sees all B * N rows
+        flops = {"attn_fwd": 4.0 * 4 * 64 * n_tok * sum(kv), "attn_bwd": 10.0 * 4 * 64 * n_tok * sum(kv),
+                 "gemm_tn": flops_dense["gemm_tn"]}
     # ---- in-step duration of the roofline kernels: the step re-captured with time stamps around them (ops.kernel_marks)
     instep = {}
     if a.instep_steps > 0 and graphed and a.dtype == "bf16":
@@ -374,7 +384,9 @@ def main():
             ms = ins[0] if ins else pr                # in-step when measured, else (fp32 / eager runs) the probe
             tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             d = {"bound": "mfma", "kernel": kernel_name, "achieved": tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                 "frac": tf / PEAK_BF16_TFLOPS, "flops_per_launch": fl,
+                 "frac": tf / PEAK_BF16_TFLOPS, "flops_per_launch": fl, "dense_flops_per_launch": flops_dense[kind],
+                 "flops_counted": ("the launch's own lengths: sum over samples of kv_len^2 (packed stream) or N * kv_len (padded); equal "
+                                   "to the dense figure on the full workload"),
                  "timed_in": ("replayed steps, mtmp_timestamp in front of and behind every launch of this kernel on its stream, "
                               "minus the stamp pair's own gap" if ins else "idle-device probe (no in-step measurement in this mode)"),
                  "avg_launch_ms": ms, "launches_timed": ins[1] if ins else (a.probe_launches if pr > 0 else 0),

@@ -10,7 +10,17 @@ trainer.py:102-104).
 
 On the HIP path: ``--vslt-type TIE``, ``--img-model-type swin`` (the ViT / MONAI branches and the report decoder
 (``--auxiliary-loss-type tdecoder``, :150-164) raise).  The head over 2 B rows is small fp32 torch code.
+
+DEVIATION FROM THE REFERENCE (training only): the reference calls ``self.img_encoder(img)`` WITH gradients (:203-206), so its
+AdamW trains the 27.5 M Swin-T parameters; the HIP encoder is forward-only, so here they are frozen
+(``requires_grad_(False)``, said once in a warning at construction).  Forward outputs, the loss and the gradients of every
+other parameter match the reference (golden ``bi_vsltimg_step.npz``); the parameter trajectory does not once the encoder would
+have moved, and ``img_encoder.*`` optimizer moments of a reference checkpoint are dropped on resume (with a warning).
+BIIMG_MBT_VFLEXIBLE1, which subclasses this file, is frozen in the reference too (biimg_mbt_vflexible1.py:210-211): no deviation
+there.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -22,6 +32,8 @@ from .tri_mbt_vsltcls import _compute_dtype, flat_layout
 
 
 class BI_VSLTIMG_MBT_V1(nn.Module):
+    TRAINS_ENCODER_IN_REFERENCE = True       # the one deviation of this model (module docstring); subclasses say for themselves
+
     def __init__(self, args):
         super().__init__()
         self.args = args
@@ -58,6 +70,11 @@ class BI_VSLTIMG_MBT_V1(nn.Module):
         self.img_pretrain = args.img_pretrain
         # pretrained Swin weights come in through load_state_dict (the reference reads ImageNet / a private CXR checkpoint, :88-100)
         self.img_encoder = swin_t_m(compute_dtype=self.compute_dtype)
+        self.img_encoder.requires_grad_(False)               # forward-only HIP encoder: frozen, explicitly (module docstring)
+        if self.TRAINS_ENCODER_IN_REFERENCE:
+            warnings.warn("BI_VSLTIMG_MBT_V1 on the MI355X path keeps the Swin-T image encoder frozen; the reference trains it "
+                          "(bi_vsltimg_mbt_v1.py:203-206).  Inference and the gradients of all other parameters match; training "
+                          "is NOT reference-equivalent for img_encoder.*", stacklevel=2)
         self.linear = nn.Linear(768, 256)
         self.flatten = nn.Flatten(1, 2)
         self.fusion_transformer = BimodalTransformerEncoder_MBT(

@@ -19,6 +19,8 @@ _ABSENT = torch.tensor([[False, False], [False, True]])          # rows = missin
 
 
 class BIIMG_MBT_VFLEXIBLE1(BI_VSLTIMG_MBT_V1):
+    TRAINS_ENCODER_IN_REFERENCE = False      # frozen there too (biimg_mbt_vflexible1.py:210-211)
+
     def __init__(self, args):
         super().__init__(args)
         if int(getattr(args, "multiimages", 0)) == 1:

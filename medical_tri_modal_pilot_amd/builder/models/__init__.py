@@ -1,6 +1,11 @@
 """Model registry with the reference's contract (builder/models/__init__.py:14-51):
 ``get_model(args)`` imports ``builder.models.8_missing_models.<args.model>`` and returns the
-class named ``<args.model>.upper()``; the caller constructs it as ``Model(args)``."""
+class named ``<args.model>.upper()``; the caller constructs it as ``Model(args)``.
+
+Built models: tri_mbt_vsltcls (the benchmarked one), tri_mbt_vsltcls_noshareumse, tri_mbt_v1,
+tri_mbt_vflexible / 2 / 3, bi_vslttxt_mbt_v1, bitxt_mbt_vflexible1, biimg_mbt_vflexible1 -- reference-equivalent for
+inference AND training -- and bi_vsltimg_mbt_v1, reference-equivalent for inference only: the reference trains its Swin-T
+encoder, this path keeps it frozen (warned at construction; its module docstring)."""
 import importlib
 
 

@@ -148,6 +148,7 @@ template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
 // keeps 60 binades below its largest term.
 constexpr float FAST_BOUND = 64.0f;
 constexpr int FWD_QW = 64;                      // query rows per wave
+constexpr bool FWD_ROTATED = true;              // bounded body: unit pipeline carried across the tile barrier (body_rot)
 constexpr int FWD_QWG = 4 * FWD_QW;             // ... per workgroup
 
 template <typename T> constexpr int fwd_stage_elems() { return KT * LDT + tr_elems<T>(); }     // one K + V^T image pair
@@ -264,10 +265,20 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
 #pragma unroll
         for (int c = 1; c < 4; ++c) mma<T>(st, ka[c], qf[qb][c]);
     };
-    auto mask_tail = [&](f32x16& st, int k0) {           // ragged last tile: keys >= kv_len drop out
+    // Ragged last tile: keys >= kv_len drop out THROUGH THE MATRIX PIPE.  Keys are accumulator rows of S^T = K Q^T, so the
+    // mask is a per-register constant: the tail tile's score products start from C = -inf in the rows of the missing keys
+    // (0 elsewhere) instead of from the inline 0 -- exp2(-inf + finite) = 0 with no compare / select per score (the select
+    // form cost 135 vector instructions more than a full tile for the same 32 MFMAs).  Built once per key block of the tail.
+    auto tail_c = [&](int k0) {
+        f32x16 c;
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            if (k0 + acc_row_swz(t, half) >= kvl) st[t] = -INFINITY;
+        for (int t = 0; t < 16; ++t) c[t] = (k0 + acc_row_swz(t, half) >= kvl) ? -INFINITY : 0.f;
+        return c;
+    };
+    auto scores_c = [&](f32x16& st, const Frag<T> (&ka)[4], int qb, const f32x16& c) {
+        st = mma_c<T>(ka[0], qf[qb][0], c);
+#pragma unroll
+        for (int c4 = 1; c4 < 4; ++c4) mma<T>(st, ka[c4], qf[qb][c4]);
     };
     auto pv = [&](int qb, const Frag<T> (&pf)[2], const Frag<T> (&vt)[2][2]) {
 #pragma unroll
@@ -318,23 +329,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
             Frag<T> ka0[4], ka1[4], vt0[2][2], vt1[2][2], p00[2], p10[2], p01[2], p11[2];
             load_k(sK, 0, ka0);
             load_k(sK, 1, ka1);
-            scores(s00, ka0, 0);
-            if (TAIL) mask_tail(s00, k0);
+            f32x16 c0, c1;
+            if (TAIL) { c0 = tail_c(k0); c1 = tail_c(k0 + 32); }
+            if (TAIL) scores_c(s00, ka0, 0, c0); else scores(s00, ka0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            scores(s10, ka0, 1);                             // slot 1: S(1,0) || softmax(0,0)
-            if (TAIL) mask_tail(s10, k0);
+            if (TAIL) scores_c(s10, ka0, 1, c0); else scores(s10, ka0, 1);      // slot 1: S(1,0) || softmax(0,0)
             soft(s00, 0, p00);
             load_v(sV, 0, vt0);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
-            scores(s01, ka1, 0);                             // slot 2: S(0,1) + PV(0,0) || softmax(1,0)
-            if (TAIL) mask_tail(s01, k0 + 32);
+            if (TAIL) scores_c(s01, ka1, 0, c1); else scores(s01, ka1, 0);      // slot 2: S(0,1) + PV(0,0) || softmax(1,0)
             pv(0, p00, vt0);
             soft(s10, 1, p10);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
-            scores(s11, ka1, 1);                             // slot 3: S(1,1) + PV(1,0) || softmax(0,1)
-            if (TAIL) mask_tail(s11, k0 + 32);
+            if (TAIL) scores_c(s11, ka1, 1, c1); else scores(s11, ka1, 1);      // slot 3: S(1,1) + PV(1,0) || softmax(0,1)
             pv(1, p10, vt0);
             soft(s01, 0, p01);
             load_v(sV, 1, vt1);
@@ -346,8 +355,67 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
             __builtin_amdgcn_sched_barrier(0);
             pv(1, p11, vt1);                                 // slot 5
         };
-        for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
-        if (ntiles > nfull) body(nfull, std::true_type{});
+        // ROTATED form (round 4): the unit pipeline runs ACROSS the tile boundary.  The form above drains at every barrier -- its
+        // first slot is four score MFMAs with nothing beside them, its last four P.V MFMAs likewise (6 slots for 4 units of
+        // vector work) -- and the K fragments of the next tile are waited for with an empty matrix pipe.  Here the last unit's
+        // softmax and the last two units' P.V products of tile t run beside the first score products of tile t + 1, after
+        // that tile's barrier (they read registers only: P, and the V fragments fetched one slot before the barrier): every
+        // slot is 8 MFMAs beside one unit of softmax, 4 slots per tile.  The state crossing a barrier is s11 (raw scores of
+        // unit (1,1)), p01 and the key block's V fragments; it starts as "-inf scores, zero P" so that the first tile needs no
+        // special body (its eight idle P.V MFMAs add zeros: 1.5 % of a 16-tile sample).
+        auto body_rot = [&](int it, auto tail_tag, f32x16& s11, Frag<T> (&p01)[2], Frag<T> (&vtp)[2][2]) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+            __syncthreads();                                 // tile `it` visible; the other buffer is free for tile it + 1
+            const T* sK = sbase + (it & 1) * fwd_stage_elems<T>();
+            const T* sV = sK + KT * LDT;
+            const int k0 = it * KT;
+            f32x16 s00, s10, s01;
+            Frag<T> ka0[4], ka1[4], vt0[2][2], p00[2], p10[2], p11[2];
+            load_k(sK, 0, ka0);                              // (ahead of the staging stores in this wave's LDS queue)
+            if (it + 1 < ntiles) put(it + 1);
+            if (it + 2 < ntiles) fetch(it + 2);
+            f32x16 c0, c1;
+            if (TAIL) { c0 = tail_c(k0); c1 = tail_c(k0 + 32); }
+            pv(0, p01, vtp);                                 // slot A: PV(prev 0,1) + S(0,0) || softmax(prev 1,1)
+            if (TAIL) scores_c(s00, ka0, 0, c0); else scores(s00, ka0, 0);
+            soft(s11, 1, p11);
+            load_v(sV, 0, vt0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            pv(1, p11, vtp);                                 // slot B: PV(prev 1,1) + S(1,0) || softmax(0,0)
+            if (TAIL) scores_c(s10, ka0, 1, c0); else scores(s10, ka0, 1);
+            soft(s00, 0, p00);
+            load_k(sK, 1, ka1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            pv(0, p00, vt0);                                 // slot C: PV(0,0) + S(0,1) || softmax(1,0)
+            if (TAIL) scores_c(s01, ka1, 0, c1); else scores(s01, ka1, 0);
+            soft(s10, 1, p10);
+            load_v(sV, 1, vtp);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            pv(1, p10, vt0);                                 // slot D: PV(1,0) + S(1,1) || softmax(0,1)
+            if (TAIL) scores_c(s11, ka1, 1, c1); else scores(s11, ka1, 1);
+            soft(s01, 0, p01);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (FWD_ROTATED) {
+            f32x16 s11;
+            Frag<T> p01[2] = {frag_zero<T>(), frag_zero<T>()}, vtp[2][2] = {{frag_zero<T>(), frag_zero<T>()}, {frag_zero<T>(), frag_zero<T>()}};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s11[t] = -INFINITY;
+            for (int it = 0; it < nfull; ++it) body_rot(it, std::false_type{}, s11, p01, vtp);
+            if (ntiles > nfull) body_rot(nfull, std::true_type{}, s11, p01, vtp);
+            Frag<T> p11[2];                                  // drain: PV(last 0,1) || softmax(last 1,1), then PV(last 1,1)
+            pv(0, p01, vtp);
+            soft(s11, 1, p11);
+            __builtin_amdgcn_sched_barrier(0);
+            pv(1, p11, vtp);
+        } else {
+            for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
+            if (ntiles > nfull) body(nfull, std::true_type{});
+        }
         m[0] = m[1] = 0.f;
     } else {
         auto body = [&](int it, auto tail_tag) {
@@ -360,11 +428,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
                 Frag<T> ka[4], vt[2][2];
                 load_k(sK, kb, ka);
                 load_v(sV, kb, vt);
+                f32x16 ct;
+                if (TAIL) ct = tail_c(it * KT + 32 * kb);
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
                     f32x16 st;
-                    scores(st, ka, qb);
-                    if (TAIL) mask_tail(st, it * KT + 32 * kb);
+                    if (TAIL) scores_c(st, ka, qb, ct); else scores(st, ka, qb);
                     // v_max3 is inline asm, which the compiler's hazard recogniser does not see: an asm instruction
                     // that reads an MFMA result too early gets whatever the register holds.  `seed` is an ordinary
                     // instruction on the LAST accumulator register written, so the required wait states are inserted
@@ -670,6 +739,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
             const int row = 32 * kb + swz23(r);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { ka[c] = DT::row_frag(sK, row, c, half); va[c] = DT::row_frag(sV, row, c, half); }
+            if (TAIL) {
+                // ragged last tile: -LSE becomes -inf in the accumulator rows of the keys >= kv_len (keys are rows of S^T), so
+                // their p -- and with it dS = p * dP' -- is exactly 0 with no select per score
+                f32x16 cLt;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) cLt[t] = (k0 + 32 * kb + acc_row_swz(t, half) < kvl) ? nL : -INFINITY;
+                u.st = mma_c<T>(ka[0], qf[0], cLt);
+            } else
             u.st = mma_c<T>(ka[0], qf[0], cL);
             u.dp = mma_c<T>(va[0], dof[0], cD);
 #pragma unroll
@@ -678,9 +755,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
         auto soft = [&](int kb, Unit& u, Frag<T> (&dsf)[2]) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                float ds = fast_exp2(u.st[t]) * u.dp[t];
-                if (TAIL) ds = (k0 + 32 * kb + acc_row_swz(t, half) < kvl) ? ds : 0.f;
-                u.st[t] = ds;
+                u.st[t] = fast_exp2(u.st[t]) * u.dp[t];
             }
             dsf[0] = frag_from_acc<T>(u.st, 0);
             dsf[1] = frag_from_acc<T>(u.st, 1);
@@ -1144,12 +1219,25 @@ template <typename T> __global__ __launch_bounds__(256) void attn_cls_fwd_kernel
     float* red = s + p.N;                                   // [4]
     float* part = red + 4;                                  // [32][64] partial outputs
     const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H, tid = threadIdx.x;
-    const int kvl = max(1, min(p.kv_len ? p.kv_len[b] : p.N, p.N));
+    const int kv_raw = p.kv_len ? p.kv_len[b] : p.N;
+    if (p.row_start && kv_raw <= p.cls_tok) {               // packed stream: this sample has no such row (never the case in the fused
+        if (tid < DH) {                                     // path, where kv_len >= prefix + CLS): defined outputs, nothing read
+            const size_t oi = ((size_t)b * p.H + hd) * DH + tid;
+            p.o_cls[oi] = from_f32<T>(0.f);
+            p.r1_cls[oi] = from_f32<T>(0.f);
+            if (tid == 0) p.lse[b * p.H + hd] = 0.f;
+        }
+        return;
+    }
+    // all keys masked (padded layout): the reference's masked_fill(-65504) + softmax = the uniform average over all N keys, as in
+    // the dense kernel (`uniform`): every score 0 (q scaled by 0), all N keys taken
+    const bool uniform = kv_raw <= 0;
+    const int kvl = uniform ? p.N : min(kv_raw, p.N);
     const size_t row0 = p.row_start ? (size_t)p.row_start[b] : (size_t)b * p.N;
     const T* Kb = p.k + row0 * p.ld_qkv + hd * DH;
     const T* Vb = p.v + row0 * p.ld_qkv + hd * DH;
     const T* qrow = p.q + (row0 + p.cls_tok) * p.ld_qkv + hd * DH;
-    const float c2 = p.scale * LOG2E;
+    const float c2 = uniform ? 0.f : p.scale * LOG2E;
     float q[DH];
 #pragma unroll
     for (int c = 0; c < DH / 8; ++c) {
@@ -1216,14 +1304,17 @@ template <typename T> __global__ __launch_bounds__(256) void attn_cls_bwd_kernel
     float* red = sD + p.N;                                  // [4]
     float* part = red + 4;                                  // [32][64] partial dq
     const int b = blockIdx.x / p.H, hd = blockIdx.x % p.H, tid = threadIdx.x;
-    const int kvl = max(1, min(p.kv_len ? p.kv_len[b] : p.N, p.N));
+    const int kv_raw = p.kv_len ? p.kv_len[b] : p.N;
+    if (p.row_start && kv_raw <= p.cls_tok) return;         // packed stream without that row: no gradient rows either (see the forward)
+    const bool uniform = kv_raw <= 0;                       // forward = uniform average: constant scores, dS = 0, dV = dO / N
+    const int kvl = uniform ? p.N : min(kv_raw, p.N);
     const int nrows = p.row_start ? kvl : p.N;              // rows of this sample in the dense gradient buffers
     const size_t row0 = p.row_start ? (size_t)p.row_start[b] : (size_t)b * p.N;
     const T* Kb = p.k + row0 * p.ld_qkv + hd * DH;
     const T* Vb = p.v + row0 * p.ld_qkv + hd * DH;
     const T* qrow = p.q + (row0 + p.cls_tok) * p.ld_qkv + hd * DH;
     const size_t oi = ((size_t)b * p.H + hd) * DH;
-    const float c2 = p.scale * LOG2E, lse = p.lse[b * p.H + hd];
+    const float c2 = uniform ? 0.f : p.scale * LOG2E, lse = p.lse[b * p.H + hd];
     float q[DH], g[DH];                                     // q (scaled to log2 units) and dO: whole rows in every thread
     float dl = 0.f;
 #pragma unroll
@@ -1249,7 +1340,7 @@ template <typename T> __global__ __launch_bounds__(256) void attn_cls_bwd_kernel
         }
         const float pk = fast_exp2(a - lse);
         sP[k] = pk;
-        sD[k] = pk * (dp - dl);
+        sD[k] = uniform ? 0.f : pk * (dp - dl);
     }
     __syncthreads();
     // thread = (8-dim group dg, key lane kl): the gradient rows leave as 16-byte pieces; dq's partial sums meet in LDS

@@ -66,6 +66,7 @@ class GradReducer:
                 hi, cur_n = cur_lo, 0
         self.works = []
         self._sync = True
+        self.last_issued: List[tuple] = []
         self._reset()
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
         flat.ready_cb = self._ready          # gradients written straight into the flat buffer (ops.GradSink)
@@ -75,6 +76,7 @@ class GradReducer:
         self.pending = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.ready_log: List[int] = []           # buckets in the order they became complete this step
+        self.issued: List[tuple] = []            # [lo, hi) of every all-reduce issued this step, in order
         self.seen = {}                           # parameters that reported their gradient this step (-> who, if debug)
 
     def begin_step(self):
@@ -143,6 +145,7 @@ class GradReducer:
         """`behind`: the stream whose enqueued work the collective is ordered after (the process group's own stream waits for the
         CURRENT stream of the call); default: this reducer's side stream (which _join_producers made wait for the producers)"""
         buf = self.flat.grad[lo:hi]
+        self.issued.append((lo, hi))
         if self.cuda:
             with torch.cuda.stream(self.side if behind is None else behind):
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -160,6 +163,28 @@ class GradReducer:
             else:
                 out.append([lo, hi])
         return out
+
+    def plan(self, ready_per_stage) -> List[List[List[int]]]:
+        """The collectives a staged step issues: per stage the merged [lo, hi) ranges of the buckets it completed, in issue order;
+        whatever no stage completed goes out last, from wait()."""
+        done = {b for ids in ready_per_stage for b in ids}
+        rest = [b for b in range(len(self.buckets)) if b not in done]
+        return [self._ranges(ids) for ids in ready_per_stage] + [self._ranges(rest)]
+
+    def assert_same_plan(self, ready_per_stage):
+        """Once per capture: every rank must issue the same collectives over the same ranges in the same order -- a rank whose
+        stages completed other bucket sets (another model configuration, a step that fell back to eager hooks) would pair its
+        all-reduces with the wrong ones of its peers: wrong sums or a hang.  One small object all-gather; no-op with one rank."""
+        mine = self.plan(ready_per_stage)
+        if self.world <= 1:
+            return mine
+        plans = [None] * self.world
+        dist.all_gather_object(plans, mine, group=self.group)
+        for r, other in enumerate(plans):
+            if other != mine:
+                raise RuntimeError(f"GradReducer: rank {r} plans other collectives than this rank ({other} vs {mine}): the staged "
+                                   "steps of the ranks differ")
+        return mine
 
     def _launch(self, b: int, after: Optional[Iterable["torch.cuda.Stream"]] = None):
         """hook mode: one bucket, behind every stream a gradient slice of it may have been written from"""
@@ -201,6 +226,7 @@ class GradReducer:
         if self.cuda:
             torch.cuda.current_stream(self.flat.grad.device).wait_stream(self.side)
         self.works = []
+        self.last_issued = list(self.issued)     # the finished step's collectives, in issue order (tests, debugging)
         self._reset()
 
     def remove(self):

@@ -139,6 +139,8 @@ class GraphedTrainStep:
             graphs.append(g)
             # which gradient buckets this stage completed (the hooks ran while its Python was captured)
             ready.append(reducer.take_ready() if reducer is not None else [])
+        if reducer is not None:
+            reducer.assert_same_plan(ready)      # every rank must issue the same collectives in the same order (else: a hang)
         ent.update(graphs=graphs, ready=ready, static=static, loss=carry["loss"], fresh=True, publishes=self._captured_publish)
         self.captures += 1
 
@@ -151,7 +153,9 @@ class GraphedTrainStep:
             for stage in stages:
                 stage(inputs, carry)
                 if reducer is not None and reducer.staged:
-                    reducer.launch(reducer.take_ready(), after=self.stream)
+                    # an eager stage ends with its modality side streams still running (only a CAPTURED stage has joined
+                    # them at its end): the collective waits for each producer stream explicitly, not for this stream alone
+                    reducer.launch(reducer.take_ready(), after=[self.stream, *reducer.extra_streams])
         cur.wait_stream(self.stream)
         for v in inputs.values():
             v.record_stream(self.stream)

@@ -1301,7 +1301,9 @@ def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None, ff
                                                [P[11] for P in Ps], 4 * D, drop_p, [sd[0] for sd in seeds], packs)
     out = gemm_nt_grouped(h, [f[3] for f in fuseds], [P[13] for P in Ps], r1_2, drop_p, [sd[1] for sd in seeds], packs)
     if R is not None:
-        full = [torch.empty(B, N, D, dtype=zs[0].dtype, device=zs[0].device) for N in Ns]
+        # zeros, not empty: when this layer closes a graph segment these buffers become segment boundaries / outputs of the autograd
+        # node; nobody reads the other rows today, and a later reader (a dump, a NaN check) must not meet recycled memory
+        full = [torch.zeros(B, N, D, dtype=zs[0].dtype, device=zs[0].device) for N in Ns]
         for f_, o_ in zip(full, out):
             f_[:, :R] = o_.view(B, R, D)
         out = full

@@ -213,16 +213,21 @@ class FusedAdamW(torch.optim.Optimizer):
         where = {q: j for j, q in enumerate(posn)}
         self.exp_avg.zero_()
         self.exp_avg_sq.zero_()
-        steps, seen = set(), set()
+        steps, seen, dropped = set(), set(), 0
         for idx, st in state_dict["state"].items():
             j = where.get(int(idx))
             if j is None:
-                continue               # a parameter the hot path never trains (frozen Swin, unused heads)
+                dropped += 1           # a parameter the hot path never trains (frozen Swin, unused heads) that WAS trained there
+                continue
             lo, hi = self.flat.slice_of(j)
             self.exp_avg[lo:hi].copy_(st["exp_avg"].reshape(-1))
             self.exp_avg_sq[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
             steps.add(int(float(st["step"])))
             seen.add(j)
+        if dropped:
+            import warnings
+            warnings.warn(f"optimizer state: {dropped} entries belong to parameters this path does not train (e.g. the image "
+                          "encoder of bi_vsltimg_mbt_v1, which the reference trains) -- their moments are dropped", stacklevel=2)
         if steps and max(steps) > 0 and len(seen) < len(self.flat.params):
             # torch.optim.AdamW creates a parameter's state at its first gradient: a trained parameter WITHOUT an entry would
             # resume at step 0 there, but this optimizer keeps ONE step count for the flat buffer (its bias correction would be

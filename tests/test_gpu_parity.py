@@ -1794,6 +1794,16 @@ def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
             assert losses == ref[g][0], (g, losses, ref[g][0])
             assert torch.equal(flat, ref[g][1]), g
         assert made and all(len(r.buckets) >= 1 for r in made)
+        # Two independently constructed "ranks" (model + optimizer + reducer + captured graphs each) must issue the same merged
+        # collectives in the same order -- a mismatch is the classic multi-rank hang, and with one rank nothing else would notice.
+        n_before = len(made)
+        _, _, gs2 = _loop(1, 0.0, "fp32", 4, full)
+        a, b = made[n_before - 1], made[-1]
+        assert a is not b and a.last_issued and a.last_issued == b.last_issued, (a.last_issued, b.last_issued)
+        ent = next(iter(gs2.entries.values()))
+        plan = b.plan(ent["ready"])
+        assert b.last_issued == [tuple(r) for st in plan for r in st], (b.last_issued, plan)
+        assert len(ent["graphs"]) == 2 and sum(len(st) for st in plan) <= 3, plan       # two stages: neighbouring buckets merged
     finally:
         optim_mod.FusedAdamW.__init__ = orig_init
         for r in made:
@@ -2342,3 +2352,34 @@ def test_attn_cls_row_vs_dense_attention(ops, dt, packed):
     check(tag + ".dqkv", dqkv.float() * valid, g_ref * valid, 2e-4 if dt == torch.float32 else 2e-2)
     nz = dqkv[:, :, :256].float().abs().sum(-1) > 0
     assert not nz[:, :cls_tok].any() and not nz[:, cls_tok + 1:].any()    # dq lives in the CLS row only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", DT)
+def test_attn_cls_row_all_keys_masked(ops, dt):
+    """A sample whose keys are ALL masked (kv_len = 0, padded layout): the reference's masked_fill(-65504) + softmax gives the
+    uniform average over all N keys and no gradient to q / k (attention.py:36-41) -- the CLS-row kernels must agree with the
+    dense kernel's `uniform` path and with the oracle (they used to attend to key 0 alone)."""
+    torch.manual_seed(9)
+    B, N, cls_tok = 3, 70, 4
+    kv = torch.tensor([0, 40, 70], dtype=torch.int32, device=DEV)
+    qkv = (torch.randn(B, N, 768, device=DEV) * 0.7).to(dt)
+    z = torch.randn(B, N, 256, device=DEV).to(dt)
+    d_o = torch.randn(B, 256, device=DEV).to(dt)
+    qr = qkv.float().clone().requires_grad_(True)
+    q, k, v = (t.reshape(B, N, 4, 64).permute(0, 2, 1, 3) for t in qr.split(256, dim=2))
+    mask = (torch.arange(N, device=DEV)[None, :] >= kv[:, None])[:, None, None, :]
+    sc = ((q @ k.transpose(-1, -2)) / 8.0).masked_fill(mask, -65504.0)
+    o_ref = (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, 256)[:, cls_tok]
+    (o_ref * d_o.float()).sum().backward()
+    o, r1, lse = ops.attn_cls_fwd(qkv, z, kv, None, cls_tok)
+    tol = 1e-4 if dt == torch.float32 else 1e-2
+    tag = f"attn_cls_all_masked[{str(dt).replace('torch.', '')}]"
+    check(tag + ".o", o.float(), o_ref, tol)
+    assert torch.allclose(o.float()[0], qkv.float()[0, :, 512:].mean(0), atol=2e-2 if dt != torch.float32 else 1e-5)   # the plain mean of V
+    dqkv = ops.attn_cls_bwd(qkv, o, d_o, lse, kv, None, cls_tok)
+    check(tag + ".dqkv", dqkv.float(), qr.grad, 2e-4 if dt == torch.float32 else 2e-2)
+    assert float(dqkv[0, :, :512].float().abs().max()) == 0.0               # no gradient to q, k of the all-masked sample
+    # the dense kernels on the same inputs take the same path
+    od, _, _ = ops.attn_fwd_grouped([qkv], [kv], [z], [None], None)
+    assert torch.allclose(od[0][:, cls_tok].float(), o.float(), atol=tol * 4)

@@ -441,6 +441,21 @@ for step in range(2):                                                # the secon
     assert all(red.buckets[b][0] >= lo2 for b in per_stage[1]), per_stage
     for (n, p), e in zip(net.named_parameters(), exp):
         assert torch.allclose(p.grad, e, rtol=1e-5, atol=1e-6), (rank, step, n)
+    # the collectives went out in the order of the plan: per stage the merged ranges of its buckets
+    plan = red.plan(per_stage)
+    assert red.last_issued == [tuple(r) for st in plan for r in st], (red.last_issued, plan)
+# every rank must plan the same collectives in the same order (GraphedTrainStep checks this once per capture) ...
+plan = red.assert_same_plan(per_stage)
+assert sum(len(st) for st in plan) >= 3, plan
+# ... and a rank whose stages completed other bucket sets is caught on every rank instead of hanging in the first all-reduce
+bad = [list(ids) for ids in per_stage]
+if rank == 1:
+    bad[0], bad[1] = bad[1], bad[0]
+try:
+    red.assert_same_plan(bad)
+    raise SystemExit("differing plans were accepted")
+except RuntimeError as e:
+    assert "plans other collectives" in str(e), e
 dist.destroy_process_group()
 print("OK", rank)
 """

@@ -33,6 +33,8 @@ def build():
     procs = []
     for name, reps in VARIANTS.items():
         s = src
+        if reps and isinstance(reps[0], str):                # ("file.hip", (old, new), ...): another source file as the starting point
+            s, reps = open(os.path.join(LAB, reps[0])).read(), reps[1:]
         for old, new in reps:
             assert s.count(old) == 1, f"variant {name}: pattern occurs {s.count(old)} times: {old[:60]!r}"
             s = s.replace(old, new)

@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py: per (kernel, grid) launches per step, average and
-per-step time, per-stream busy time and the busy union -- steps are delimited by the vslt attention forward
-launches (6 per step at config 2).
+per-step time, per-stream busy time and the busy union -- steps are delimited by a kernel that is launched exactly ONCE per
+step (the fused AdamW kernel; --step-kernel to name another).  (Through round 3 the delimiter was "six dense attention-forward
+launches"; since the CLS-only last layer there are five per step, and the per-step columns of profiles/r03{d,e,f}_trace_summary.json
+were 6/5 too large -- profiles/r03f_trace_summary_corrected.json.)
 
     python tools/trace_summary.py gpurun_out/prof/x_kernel_trace.csv [--top 40] [--stream main|all] [--seq]
 """
@@ -23,15 +25,15 @@ def main():
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--stream", default="main")
     ap.add_argument("--seq", action="store_true", help="print the main-stream launch sequence of one step")
-    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--step-kernel", default="adamw_kernel", help="substring of a kernel launched once per step (its END closes a step)")
     ap.add_argument("--json", default="")
     ap.add_argument("--skip-last", type=int, default=0, help="ignore the last K steps (bench.py's eager probe steps)")
     a = ap.parse_args()
     rows = list(csv.DictReader(open(a.csv)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    big = max(int(r["Grid_Size_X"]) for r in rows if "attn_fwd" in r["Kernel_Name"])
-    fw = [r for r in rows if "attn_fwd" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == big]
-    starts = [int(fw[a.layers * k]["Start_Timestamp"]) for k in range(len(fw) // a.layers)]
+    starts = [int(r["End_Timestamp"]) + 1 for r in rows if a.step_kernel in r["Kernel_Name"]]      # a step = (end of one AdamW, end of the next]
+    if len(starts) < 4:
+        raise SystemExit(f"fewer than 4 launches of a kernel matching {a.step_kernel!r}: cannot delimit steps")
     if a.skip_last:
         starts = starts[:-a.skip_last]
     lo, hi = starts[len(starts) // 2], starts[-1]
@@ -51,7 +53,7 @@ def main():
         else:
             ce = max(ce, e)
     u += ce - cs
-    summary = {"steps": n, "wall_us_per_step": (hi - lo) / 1e3 / n, "busy_union_us_per_step": u / 1e3 / n,
+    summary = {"steps": n, "step_delimiter": a.step_kernel, "wall_us_per_step": (hi - lo) / 1e3 / n, "busy_union_us_per_step": u / 1e3 / n,
                "stream_busy_us_per_step": {s: v / n for s, v in by.items()}, "kernels_per_step": len(sel) / n}
     print(json.dumps(summary))
     pick = [r for r in sel if a.stream == "all" or r["Stream_Id"] == main_s]
