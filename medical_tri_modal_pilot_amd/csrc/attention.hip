@@ -148,7 +148,6 @@ template <typename T> MTMP_DEV Frag<T> frag_scale(const Frag<T>& f, float s) {
 // keeps 60 binades below its largest term.
 constexpr float FAST_BOUND = 64.0f;
 constexpr int FWD_QW = 64;                      // query rows per wave
-constexpr bool FWD_ROTATED = true;              // bounded body: unit pipeline carried across the tile barrier (body_rot)
 constexpr int FWD_QWG = 4 * FWD_QW;             // ... per workgroup
 
 template <typename T> constexpr int fwd_stage_elems() { return KT * LDT + tr_elems<T>(); }     // one K + V^T image pair
@@ -177,6 +176,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
     const size_t base = (size_t)row0 * p.ld_qkv + hd * DH;
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int q0w = qt * FWD_QWG + wave * FWD_QW;          // first query row of this wave
+    // Prologue: EVERY load of the workgroup's first phase is issued before anything waits -- this lane's entry of the key-norm
+    // table (clamped address, unconditional), the Q fragments, the first key tile -- so the wave pays one memory latency, not
+    // three in a row (Q -> ||q|| -> table -> first tile, as the code stood through round 3).
+    const int blk0 = row0 >> 5, blk1 = (row0 + Nq - 1) >> 5;
+    float km = 0.f;
+    if (p.knorm) km = p.knorm[(size_t)min(blk0 + lane, blk1) * p.H + hd];
     Frag<T> qf[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -187,28 +192,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
                                   qrow < Nq && !uniform);
     }
     const float c2 = p.scale * LOG2E;
-    // ---- which body?  (wave-uniform)
-    bool fast = false;
-    if (p.knorm) {
-        float qs = 0.f;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = fmaf(to_f32(qf[qb][c].v[j]), to_f32(qf[qb][c].v[j]), s);
-            qs = fmaxf(qs, s);
-        }
-        qs = half_sum(qs) ;                                   // >= either row's ||q||^2 (the half-lanes hold half rows)
-        const int blk0 = row0 >> 5, blk1 = (row0 + Nq - 1) >> 5;
-        float km = 0.f;
-        for (int i = blk0 + lane; i <= blk1; i += 64) km = fmaxf(km, p.knorm[(size_t)i * p.H + hd]);
-        km = wave_max(km);
-        // 1.02: the key norms may have been taken before the keys were rounded to bf16, q * c2 is rounded again below
-        const float bound = sqrtf(qs) * km * (c2 * 1.02f);
-        fast = wave_all(bound <= FAST_BOUND);                 // (a NaN anywhere fails the comparison: online body)
-    }
     f32x16 o[2][2] = {{{0}, {0}}, {{0}, {0}}};                // [query block][dh half]
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     const int nfull = kvl / KT, ntiles = (kvl + KT - 1) / KT;
@@ -240,6 +223,26 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
         put_tr_r(sK + KT * LDT, vreg, tid);
     };
     fetch(0);
+    // ---- which body?  (wave-uniform)
+    bool fast = false;
+    if (p.knorm) {
+        float qs = 0.f;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = fmaf(to_f32(qf[qb][c].v[j]), to_f32(qf[qb][c].v[j]), s);
+            qs = fmaxf(qs, s);
+        }
+        qs = half_sum(qs) ;                                   // >= either row's ||q||^2 (the half-lanes hold half rows)
+        for (int i = blk0 + lane + 64; i <= blk1; i += 64) km = fmaxf(km, p.knorm[(size_t)i * p.H + hd]);   // (samples of more than 2048 rows)
+        km = wave_max(km);
+        // 1.02: the key norms may have been taken before the keys were rounded to bf16, q * c2 is rounded again below
+        const float bound = sqrtf(qs) * km * (c2 * 1.02f);
+        fast = wave_all(bound <= FAST_BOUND);                 // (a NaN anywhere fails the comparison: online body)
+    }
     put(0);
     if (ntiles > 1) fetch(1);
     // start of tile `it`: its images become visible, the other buffer is free for tile it + 1
@@ -319,45 +322,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
                 }
             }
         };
-        auto body = [&](int it, auto tail_tag) {
-            constexpr bool TAIL = decltype(tail_tag)::value;
-            tile_begin(it);
-            const T* sK = sbase + (it & 1) * fwd_stage_elems<T>();
-            const T* sV = sK + KT * LDT;
-            const int k0 = it * KT;
-            f32x16 s00, s10, s01, s11;                       // s<qb><kb>
-            Frag<T> ka0[4], ka1[4], vt0[2][2], vt1[2][2], p00[2], p10[2], p01[2], p11[2];
-            load_k(sK, 0, ka0);
-            load_k(sK, 1, ka1);
-            f32x16 c0, c1;
-            if (TAIL) { c0 = tail_c(k0); c1 = tail_c(k0 + 32); }
-            if (TAIL) scores_c(s00, ka0, 0, c0); else scores(s00, ka0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (TAIL) scores_c(s10, ka0, 1, c0); else scores(s10, ka0, 1);      // slot 1: S(1,0) || softmax(0,0)
-            soft(s00, 0, p00);
-            load_v(sV, 0, vt0);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            if (TAIL) scores_c(s01, ka1, 0, c1); else scores(s01, ka1, 0);      // slot 2: S(0,1) + PV(0,0) || softmax(1,0)
-            pv(0, p00, vt0);
-            soft(s10, 1, p10);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            if (TAIL) scores_c(s11, ka1, 1, c1); else scores(s11, ka1, 1);      // slot 3: S(1,1) + PV(1,0) || softmax(0,1)
-            pv(1, p10, vt0);
-            soft(s01, 0, p01);
-            load_v(sV, 1, vt1);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            pv(0, p01, vt1);                                 // slot 4: PV(0,1) || softmax(1,1)
-            soft(s11, 1, p11);
-            interleave();
-            __builtin_amdgcn_sched_barrier(0);
-            pv(1, p11, vt1);                                 // slot 5
-        };
-        // ROTATED form (round 4): the unit pipeline runs ACROSS the tile boundary.  The form above drains at every barrier -- its
-        // first slot is four score MFMAs with nothing beside them, its last four P.V MFMAs likewise (6 slots for 4 units of
-        // vector work) -- and the K fragments of the next tile are waited for with an empty matrix pipe.  Here the last unit's
+        // The unit pipeline runs ACROSS the tile boundary (round 4).  Through round 3 it drained at every barrier -- a tile's
+        // first slot was four score MFMAs with nothing beside them, its last four P.V MFMAs likewise (6 slots for 4 units of
+        // vector work) -- and the K fragments of the next tile were waited for with an empty matrix pipe.  Here the last unit's
         // softmax and the last two units' P.V products of tile t run beside the first score products of tile t + 1, after
         // that tile's barrier (they read registers only: P, and the V fragments fetched one slot before the barrier): every
         // slot is 8 MFMAs beside one unit of softmax, 4 slots per tile.  The state crossing a barrier is s11 (raw scores of
@@ -400,7 +367,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
             interleave();
             __builtin_amdgcn_sched_barrier(0);
         };
-        if (FWD_ROTATED) {
+        {
             f32x16 s11;
             Frag<T> p01[2] = {frag_zero<T>(), frag_zero<T>()}, vtp[2][2] = {{frag_zero<T>(), frag_zero<T>()}, {frag_zero<T>(), frag_zero<T>()}};
 #pragma unroll
@@ -412,9 +379,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
             soft(s11, 1, p11);
             __builtin_amdgcn_sched_barrier(0);
             pv(1, p11, vtp);
-        } else {
-            for (int it = 0; it < nfull; ++it) body(it, std::false_type{});
-            if (ntiles > nfull) body(nfull, std::true_type{});
         }
         m[0] = m[1] = 0.f;
     } else {
@@ -471,6 +435,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
     // Epilogue.  A lane owns one query and 4-element pieces of its O row, so direct stores would be 8-byte pieces
     // at a row stride -- partial-line writes (PMC: 72 MB written per launch for a 33 MB output).  The wave's
     // 64 x 64 tile goes through a wave-private LDS tile instead and leaves as whole 128-byte head rows.
+    // Memory order (round 4): the residual pieces are REQUESTED first -- all passes at once, clamped rows, no branch around
+    // a load -- then O is normalised and staged while they fly, then all stores go out back to back.  Through round 3 every
+    // pass was "store O, load the residual, wait for it (vmcnt(0): for the store just issued as well), add, store": eight
+    // (fp32: sixteen) memory round trips in a row per wave.
+    constexpr int E = 16 / (int)sizeof(T);                            // elements per 16-byte piece
+    constexpr int CH = DH * (int)sizeof(T) / 16, RPP = 64 / CH, NPS = FWD_QW / RPP;   // pieces per row, rows per pass, passes
+    const int rsub = lane / CH, ch = lane % CH;
+    u32x4_t rv[NPS];
+    if (p.o_res) {
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            const int rowc = min(q0w + ps * RPP + rsub, Nq - 1);
+            rv[ps] = *reinterpret_cast<const u32x4_t*>(p.res + ((size_t)row0 + rowc) * p.ld_o + hd * DH + ch * E);
+        }
+    }
     __syncthreads();                                  // all waves are done with the K / V images: reuse them as staging
     T* sO = reinterpret_cast<T*>(smem_raw) + wave * FWD_QW * LDT;
 #pragma unroll
@@ -489,28 +468,28 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_fwd_kernel
         if (qrow < Nq && half == 0) p.lse[((size_t)b * p.H + hd) * p.N + qrow] = m[qb] + log2f(l[qb]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS, no barrier needed
-    constexpr int CH = DH * (int)sizeof(T) / 16, RPP = 64 / CH;       // 16-byte chunks per row, rows per pass
+    u32x4_t ovv[NPS];
 #pragma unroll
-    for (int ps = 0; ps < FWD_QW / RPP; ++ps) {
-        const int rl = ps * RPP + lane / CH, ch = lane % CH;
-        if (q0w + rl < Nq) {
-            const size_t off = ((size_t)row0 + q0w + rl) * p.ld_o + hd * DH + ch * (16 / (int)sizeof(T));
-            const u32x4_t ov = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sO + rl * LDT) + 16 * ch);
-            *reinterpret_cast<u32x4_t*>(p.o + off) = ov;
-            if (p.o_res) {
-                // residual epilogue (encoder.py:27 "outputs += residual"): the residual adds the
-                // value of O as stored (i.e. rounded to T), like the reference's tensor add.
-                constexpr int E = 16 / (int)sizeof(T);
-                T ob[E], rbv[E], sb[E];
-                __builtin_memcpy(ob, &ov, 16);
-                const u32x4_t rvv = *reinterpret_cast<const u32x4_t*>(p.res + off);
-                __builtin_memcpy(rbv, &rvv, 16);
+    for (int ps = 0; ps < NPS; ++ps)
+        ovv[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sO + (ps * RPP + rsub) * LDT) + 16 * ch);
+    T* orow = p.o + ((size_t)row0 + q0w + rsub) * p.ld_o + hd * DH + ch * E;
 #pragma unroll
-                for (int i = 0; i < E; ++i) sb[i] = from_f32<T>(to_f32(ob[i]) + to_f32(rbv[i]));
-                u32x4_t sv;
-                __builtin_memcpy(&sv, sb, 16);
-                *reinterpret_cast<u32x4_t*>(p.o_res + off) = sv;
-            }
+    for (int ps = 0; ps < NPS; ++ps)
+        if (q0w + ps * RPP + rsub < Nq) *reinterpret_cast<u32x4_t*>(orow + (size_t)ps * RPP * p.ld_o) = ovv[ps];
+    if (p.o_res) {
+        // residual epilogue (encoder.py:27 "outputs += residual"): the residual adds the
+        // value of O as stored (i.e. rounded to T), like the reference's tensor add.
+        T* rrow = p.o_res + ((size_t)row0 + q0w + rsub) * p.ld_o + hd * DH + ch * E;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+            T ob[E], rbv[E], sb[E];
+            __builtin_memcpy(ob, &ovv[ps], 16);
+            __builtin_memcpy(rbv, &rv[ps], 16);
+#pragma unroll
+            for (int i = 0; i < E; ++i) sb[i] = from_f32<T>(to_f32(ob[i]) + to_f32(rbv[i]));
+            u32x4_t sv;
+            __builtin_memcpy(&sv, sb, 16);
+            if (q0w + ps * RPP + rsub < Nq) *reinterpret_cast<u32x4_t*>(rrow + (size_t)ps * RPP * p.ld_o) = sv;
         }
     }
 }
@@ -683,34 +662,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
     const int qrow = qt * 128 + wave * 32 + r;
     const float c2 = p.scale * LOG2E;
-    Frag<T> qf[4], dof[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        qf[c] = frag_keep(frag_scale<T>(frag_load<T>(Qb + (size_t)min(qrow, Nq - 1) * p.ld_qkv + 16 * c + 8 * half), c2),
-                          qrow < Nq);
-        dof[c] = frag_keep(frag_load<T>(p.d_o + ((size_t)row0 + min(qrow, Nq - 1)) * p.ld_do + hd * DH + 16 * c + 8 * half),
-                           qrow < Nq);
-    }
+    // Prologue: every load of the first phase is issued before anything waits (round 4; it used to be three memory latencies in
+    // a row: Q / dO / O, then -- behind the delta store -- LSE, then the first key tile): LSE (clamped row, unconditional), the
+    // three row fragments, the first K / V tile.
     const size_t sidx = ((size_t)b * p.H + hd) * p.N + min(qrow, Nq - 1);
-    // delta[q] = sum_d dO[q,d] O[q,d] (the softmax backward's row constant) is computed here, from the dO fragments
-    // this lane already holds and the matching O fragments, and handed to the dK/dV kernel through p.delta -- the
-    // separate delta pass (one launch, 66 MB of traffic per call) is gone; the dQ kernel therefore runs FIRST.
-    float dsum = 0.f;
+    const float lse_v = p.lse[sidx];
+    Frag<T> qf[4], dof[4], of[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const Frag<T> of = frag_load<T>(p.o + ((size_t)row0 + min(qrow, Nq - 1)) * p.ld_o + hd * DH + 16 * c + 8 * half);
-#pragma unroll
-        for (int jx = 0; jx < 8; ++jx) dsum = fmaf(to_f32(dof[c].v[jx]), to_f32(of.v[jx]), dsum);
+        qf[c] = frag_load<T>(Qb + (size_t)min(qrow, Nq - 1) * p.ld_qkv + 16 * c + 8 * half);
+        dof[c] = frag_load<T>(p.d_o + ((size_t)row0 + min(qrow, Nq - 1)) * p.ld_do + hd * DH + 16 * c + 8 * half);
+        of[c] = frag_load<T>(p.o + ((size_t)row0 + min(qrow, Nq - 1)) * p.ld_o + hd * DH + 16 * c + 8 * half);
     }
-    dsum = half_sum(dsum);                                 // the two half-lanes hold the two halves of the row
-    if (qrow < Nq && half == 0) p.delta[sidx] = dsum;
-    // rows past N: -LSE = -inf makes p = 0 whatever the (zero) fragments give
-    const float nL = (qrow < Nq) ? -p.lse[sidx] : -INFINITY;
-    const float nD = (qrow < Nq) ? -dsum : 0.f;
-    f32x16 cL, cD;                            // the row constants in every register: C operands
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { cL[t] = nL; cD[t] = nD; }
-    f32x16 dq0 = {0}, dq1 = {0};
     const int ntiles = uniform ? 0 : (kvl + KT - 1) / KT;
     const int nfull = kvl / KT;
     TileStream<T> ks, vs;
@@ -723,22 +686,60 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
         DT::put(st_, t >= nfull ? ks.zero_tail(kreg, t) : kreg, tid);
         DT::put(st_ + DT::BYTES, vreg, tid);
     };
-    if (ntiles > 0) { fetch(0); put(0); }
+    if (ntiles > 0) fetch(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qf[c] = frag_keep(frag_scale<T>(qf[c], c2), qrow < Nq);
+        dof[c] = frag_keep(dof[c], qrow < Nq);
+    }
+    // delta[q] = sum_d dO[q,d] O[q,d] (the softmax backward's row constant) is computed here, from the dO fragments
+    // this lane already holds and the matching O fragments, and handed to the dK/dV kernel through p.delta -- the
+    // separate delta pass (one launch, 66 MB of traffic per call) is gone; the dQ kernel therefore runs FIRST.
+    float dsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int jx = 0; jx < 8; ++jx) dsum = fmaf(to_f32(dof[c].v[jx]), to_f32(of[c].v[jx]), dsum);
+    dsum = half_sum(dsum);                                 // the two half-lanes hold the two halves of the row
+    if (qrow < Nq && half == 0) p.delta[sidx] = dsum;
+    // rows past N: -LSE = -inf makes p = 0 whatever the (zero) fragments give
+    const float nL = (qrow < Nq) ? -lse_v : -INFINITY;
+    const float nD = (qrow < Nq) ? -dsum : 0.f;
+    f32x16 cL, cD;                            // the row constants in every register: C operands
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { cL[t] = nL; cD[t] = nD; }
+    f32x16 dq0 = {0}, dq1 = {0};
+    if (ntiles > 0) put(0);
     if (ntiles > 1) fetch(1);
     struct Unit { f32x16 st, dp; };
+    // One tile = two key blocks (units), four phases.  Every phase's LDS fragments are requested one phase AHEAD of the MFMAs that
+    // read them (round 4): as the code stood, each phase began with its own ds_reads and its MFMAs waited for them one by one -- the
+    // matrix pipe idled through an LDS latency per MFMA in the score phases and through the transposed reads in front of each
+    // gradient phase (the disassembly showed `ds_read, s_waitcnt lgkmcnt(0), v_mfma` eight times in a row).
+    //   after the barrier:  row fragments of key block 0            | staging stores of tile it + 1, loads of tile it + 2
+    //   phase 0:  S, dP (block 0)                                   | row fragments of block 1
+    //   phase 1:  S, dP (block 1)  ||  exp / mul / cvt (block 0)    | transposed K fragments of block 0
+    //   phase 2:  dQ += (block 0)  ||  exp / mul / cvt (block 1)    | transposed K fragments of block 1
+    //   phase 3:  dQ += (block 1)
     auto body = [&](int it, auto tail_tag) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         const int k0 = it * KT;
         __syncthreads();                       // tile `it` visible; the other stage is free for tile it + 1
-        if (it + 1 < ntiles) put(it + 1);
-        if (it + 2 < ntiles) fetch(it + 2);
         const char* sK = smem_raw + (it & 1) * dq_stage_bytes<T>();
         const char* sV = sK + DT::BYTES;
-        auto scores = [&](int kb, Unit& u) {
-            Frag<T> ka[4], va[4];
+        auto load_rows = [&](int kb, Frag<T> (&ka)[4], Frag<T> (&va)[4]) {
             const int row = 32 * kb + swz23(r);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { ka[c] = DT::row_frag(sK, row, c, half); va[c] = DT::row_frag(sV, row, c, half); }
+        };
+        auto load_tr = [&](int kb, Frag<T> (&trf)[2][2]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                trf[s][0] = DT::tr_frag(sK, 32 * kb + 16 * s, 0, lane);
+                trf[s][1] = DT::tr_frag(sK, 32 * kb + 16 * s, 32, lane);
+            }
+        };
+        auto scores = [&](int kb, Unit& u, const Frag<T> (&ka)[4], const Frag<T> (&va)[4]) {
             if (TAIL) {
                 // ragged last tile: -LSE becomes -inf in the accumulator rows of the keys >= kv_len (keys are rows of S^T), so
                 // their p -- and with it dS = p * dP' -- is exactly 0 with no select per score
@@ -748,62 +749,69 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
                 u.st = mma_c<T>(ka[0], qf[0], cLt);
             } else
             u.st = mma_c<T>(ka[0], qf[0], cL);
+            // (the score chain first, the dP chain behind it: the exponentials that follow read `st`)
+#pragma unroll
+            for (int c = 1; c < 4; ++c) mma<T>(u.st, ka[c], qf[c]);
             u.dp = mma_c<T>(va[0], dof[0], cD);
 #pragma unroll
-            for (int c = 1; c < 4; ++c) { mma<T>(u.st, ka[c], qf[c]); mma<T>(u.dp, va[c], dof[c]); }
+            for (int c = 1; c < 4; ++c) mma<T>(u.dp, va[c], dof[c]);
         };
-        auto soft = [&](int kb, Unit& u, Frag<T> (&dsf)[2]) {
+        auto soft = [&](Unit& u, Frag<T> (&dsf)[2]) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                u.st[t] = fast_exp2(u.st[t]) * u.dp[t];
-            }
+            for (int t = 0; t < 16; ++t) u.st[t] = fast_exp2(u.st[t]) * u.dp[t];
             dsf[0] = frag_from_acc<T>(u.st, 0);
             dsf[1] = frag_from_acc<T>(u.st, 1);
         };
-        auto grad = [&](int kb, const Frag<T> (&dsf)[2]) {       // dQ^T += K^T dS^T (transposed K fragments of the same image)
-            Frag<T> trf[2][2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                trf[s][0] = DT::tr_frag(sK, 32 * kb + 16 * s, 0, lane);
-                trf[s][1] = DT::tr_frag(sK, 32 * kb + 16 * s, 32, lane);
-            }
+        auto grad = [&](const Frag<T> (&dsf)[2], const Frag<T> (&trf)[2][2]) {       // dQ^T += K^T dS^T (transposed K fragments of the same image)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 mma<T>(dq0, trf[s][0], dsf[s]);
                 mma<T>(dq1, trf[s][1], dsf[s]);
             }
         };
-        // the two key blocks of the tile, pipelined: S,dP(1) beside exp/mul/cvt(0); dQ(0) beside exp/mul/cvt(1)
         Unit u0, u1;
-        Frag<T> d0[2], d1[2];
-        scores(0, u0);
+        Frag<T> d0[2], d1[2], ka0[4], va0[4], ka1[4], va1[4], tr0[2][2], tr1[2][2];
+        load_rows(0, ka0, va0);                // (ahead of the staging stores in this wave's LDS queue)
+        if (it + 1 < ntiles) put(it + 1);
+        if (it + 2 < ntiles) fetch(it + 2);
         __builtin_amdgcn_sched_barrier(0);
-        scores(1, u1);
-        soft(0, u0, d0);
+        load_rows(1, ka1, va1);                // phase 0
+        scores(0, u0, ka0, va0);
         if (sizeof(T) == 2) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_tr(0, tr0);                       // phase 1
+        scores(1, u1, ka1, va1);
+        soft(u0, d0);
+        if (sizeof(T) == 2) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        grad(0, d0);
-        soft(1, u1, d1);
+        load_tr(1, tr1);                       // phase 2
+        grad(d0, tr0);
+        soft(u1, d1);
         if (sizeof(T) == 2) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);         // under the LDS latency
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x400, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        grad(1, d1);
+        grad(d1, tr1);                         // phase 3
     };
     for (int it = 0; it < min(nfull, ntiles); ++it) body(it, std::false_type{});
     if (ntiles > nfull) body(nfull, std::true_type{});
@@ -939,10 +947,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
                 };
                 auto scores = [&](f32x16& st, f32x16& ds, const f32x16& cL, const f32x16& cD, const Frag<T> (&qa)[4],
                                   const Frag<T> (&oa)[4]) {
+                    // the score chain first, the dP chain behind it: the exponentials of the next phase read `st`, whose last MFMA
+                    // has then been out for four MFMA times instead of one
                     st = mma_c<T>(qa[0], kf[0], cL);
+#pragma unroll
+                    for (int c = 1; c < 4; ++c) mma<T>(st, qa[c], kf[c]);
                     ds = mma_c<T>(oa[0], vf[0], cD);
 #pragma unroll
-                    for (int c = 1; c < 4; ++c) { mma<T>(st, qa[c], kf[c]); mma<T>(ds, oa[c], vf[c]); }
+                    for (int c = 1; c < 4; ++c) mma<T>(ds, oa[c], vf[c]);
                 };
                 auto probs = [&](f32x16& st, f32x16& ds, Frag<T> (&pf)[2], Frag<T> (&dsf)[2]) {
 #pragma unroll
@@ -954,13 +966,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
 #pragma unroll
                     for (int s = 0; s < 2; ++s) { pf[s] = frag_from_acc<T>(st, s); dsf[s] = frag_from_acc<T>(ds, s); }
                 };
+                // dV^T += dO^T P, dK^T += Q^T dS: the transposed tile as the A operand, so the head dimension lands on the accumulator
+                // registers and the KEY on the lane -- a lane then stores 4 consecutive head-dimension elements of its own key row
+                // (8-byte pieces, 32 per lane) instead of 64 two-byte elements of 16 different rows (round 3: a 3.8 us store tail per
+                // workgroup, four rounds of workgroups per launch)
                 auto grads = [&](const Frag<T> (&pf)[2], const Frag<T> (&dsf)[2], const Frag<T> (&trf)[2][4]) {
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        mma<T>(dv0, pf[s], trf[s][0]);
-                        mma<T>(dv1, pf[s], trf[s][1]);
-                        mma<T>(dk0, dsf[s], trf[s][2]);
-                        mma<T>(dk1, dsf[s], trf[s][3]);
+                        mma<T>(dv0, trf[s][0], pf[s]);
+                        mma<T>(dv1, trf[s][1], pf[s]);
+                        mma<T>(dk0, trf[s][2], dsf[s]);
+                        mma<T>(dk1, trf[s][3], dsf[s]);
                     }
                 };
                 f32x16 st0, ds0, st1, ds1, cL1, cD1;
@@ -1014,22 +1030,25 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
             }
         }
     }
-    // rows = keys (registers), cols = dh (lanes); keys past kv_len (and the whole dK of a fully masked
-    // sample) are written as zeros
-    const size_t obase = (size_t)row0 * p.ld_dqkv + hd * DH;
-    const float kscale = uniform ? 0.f : p.scale;
+    // dK^T / dV^T: rows = head dimension (registers), cols = this wave's keys (lanes); keys past kv_len (and the whole dK of a
+    // fully masked sample) are written as zeros
+    if (key < Nq) {
+        const bool live = key < kvl;
+        const float ks = (live && !uniform) ? p.scale : 0.f, vs_ = live ? 1.f : 0.f;
+        const size_t orow = ((size_t)row0 + key) * p.ld_dqkv + hd * DH;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int krow = kw0 + acc_row(t, half);
-        if (krow < Nq) {
-            const bool live = krow < kvl;
-            T* dkp = p.dk + obase + (size_t)krow * p.ld_dqkv;
-            T* dvp = p.dv + obase + (size_t)krow * p.ld_dqkv;
-            dkp[r] = from_f32<T>(live && !uniform ? dk0[t] * kscale : 0.f);
-            dkp[32 + r] = from_f32<T>(live && !uniform ? dk1[t] * kscale : 0.f);
-            dvp[r] = from_f32<T>(live ? dv0[t] : 0.f);
-            dvp[32 + r] = from_f32<T>(live ? dv1[t] : 0.f);
-        }
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& ak = dt ? dk1 : dk0;
+                const f32x16& av = dt ? dv1 : dv0;
+                const int d0 = 32 * dt + 8 * g + 4 * half;
+                // (a select, not a product with 0: a key past kv_len may hold NaN / inf garbage in its own column)
+                store4<T>(p.dk + orow + d0, ks != 0.f ? ak[4 * g] * ks : 0.f, ks != 0.f ? ak[4 * g + 1] * ks : 0.f,
+                          ks != 0.f ? ak[4 * g + 2] * ks : 0.f, ks != 0.f ? ak[4 * g + 3] * ks : 0.f);
+                store4<T>(p.dv + orow + d0, vs_ != 0.f ? av[4 * g] : 0.f, vs_ != 0.f ? av[4 * g + 1] : 0.f,
+                          vs_ != 0.f ? av[4 * g + 2] : 0.f, vs_ != 0.f ? av[4 * g + 3] : 0.f);
+            }
     }
 }
 

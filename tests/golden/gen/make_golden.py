@@ -326,6 +326,31 @@ def gen_swin(model):
     save("swin", seed=np.array(21), feat=y, stem=stem[:, ::8, ::8, :], stage1=s1[:, ::8, ::8, :])
 
 
+def gen_swin_train():
+    """The real encoder in TRAIN mode (2_train.py:128 puts the frozen encoder back into it: its row-mode StochasticDepth draws are
+    live): SwinTransformerBlock.forward of the reference (swin_transformer.py:428-449) decides WHERE the noise multiplies -- each of
+    the two residual branches of a block, per sample -- and the shim's StochasticDepth records the draws it made, so the oracle's
+    ``row_scales`` path is pinned by the reference's own block code instead of by a stand-in that raised in train mode."""
+    args = ref_args(multiimages=0, batch_size=4, transformer_num_layers=2)
+    model = build_model(args)
+    sd_cls = ref_shims._StochasticDepth
+    enc = model.img_encoder
+    enc.train()
+    g = torch.Generator().manual_seed(41)
+    img = torch.rand(3, 1, 224, 224, generator=g)
+    sd_cls.rng, sd_cls.draws = torch.Generator().manual_seed(42), []
+    try:
+        with torch.no_grad():
+            y = enc(img)
+        draws = torch.stack(sd_cls.draws)                      # [calls, B] in call order: (block 0 attention, block 0 MLP, block 1 ...)
+    finally:
+        sd_cls.rng, sd_cls.draws = None, None
+    ps = [m.p for m in enc.modules() if isinstance(m, sd_cls)]
+    assert draws.shape[0] == 2 * sum(1 for p_ in ps if p_ > 0.0), (draws.shape, ps)      # one module per block, called for both branches
+    assert float(draws.min()) == 0.0 or len(set(draws.flatten().tolist())) > 1      # (some branch was dropped or scaled: the noise is live)
+    save("swin_train", seed=np.array(41), feat=y, draws=draws, p=np.array(ps, dtype=np.float64))
+
+
 def gen_swin_sizes():
     """The real encoder on maps that are NOT multiples of the 7x7 window (zero-padded windows, swin_transformer.py:150-152) and
     on odd-sized maps in front of a patch merging (_patch_merging_pad, :60-85 / :34-44): --image-size 512 (128 -> 64 -> 32 -> 16
@@ -497,6 +522,8 @@ if __name__ == "__main__":
         gen_misc()
     if "swin_sizes" in which:
         gen_swin_sizes()
+    if "swin_train" in which:
+        gen_swin_train()
     if "model" in which:
         gen_model_step(0, "model_step")
         gen_model_step(1, "model_step_multi")

@@ -5,7 +5,7 @@ installed in this image.  None of them carries arithmetic that the golden
 vectors depend on beyond three trivial containers (torchvision ``MLP`` =
 Linear/GELU/Dropout/Linear/Dropout, ``Permute``, ``StochasticDepth``, which is
 the identity in eval mode); those are restated here from their published
-semantics (torchvision >= 0.13, SURVEY.md §8c "third-party arithmetic").
+semantics (torchvision >= 0.13, SURVEY.md §8c "third-party arithmetic"; StochasticDepth's train mode too, with recorded draws).
 Everything else is an inert placeholder so that ``import`` succeeds.
 
 This module is never imported by the product package, the oracle, bench.py
@@ -48,6 +48,14 @@ class _Permute(nn.Module):
 
 
 class _StochasticDepth(nn.Module):
+    """torchvision.ops.StochasticDepth as published (torchvision >= 0.13, ops/stochastic_depth.py): identity in eval mode or at
+    p = 0; in train mode, mode "row": one bernoulli(1 - p) draw per sample, divided by the survival rate, multiplies the whole
+    residual branch of that sample.  The draws come from the class-level generator ``rng`` and are RECORDED in ``draws`` (one
+    float[B] per call, in call order) so that a golden of the real SwinTransformerBlock in train mode carries the noise it used
+    (make_golden.gen_swin_train); without a generator train mode raises, as before."""
+    rng = None
+    draws = None
+
     def __init__(self, p, mode):
         super().__init__()
         self.p, self.mode = p, mode
@@ -55,7 +63,15 @@ class _StochasticDepth(nn.Module):
     def forward(self, x):
         if not self.training or self.p == 0.0:
             return x
-        raise RuntimeError("golden vectors are generated with the image encoder in eval mode")
+        cls = type(self)
+        if cls.rng is None or self.mode != "row":
+            raise RuntimeError("train-mode StochasticDepth needs _StochasticDepth.rng / .draws (gen_swin_train) and mode 'row'")
+        survival = 1.0 - self.p
+        noise = torch.empty([x.shape[0]] + [1] * (x.ndim - 1), dtype=x.dtype).bernoulli_(survival, generator=cls.rng)
+        if survival > 0.0:
+            noise.div_(survival)
+        cls.draws.append(noise.flatten().clone())
+        return x * noise
 
 
 class _Weights:

@@ -764,7 +764,7 @@ def test_swin_stem_and_features(ops, dtype):
     check(f"swin[{dtype}].stem", stem[:, ::8, ::8, :].float(), torch.from_numpy(Gd["stem"]), tol)
     with torch.no_grad():
         feat = enc(img)
-    check(f"swin[{dtype}].features", feat.float(), torch.from_numpy(Gd["feat"]), 2e-4 if dtype == "fp32" else 6e-2)
+    check(f"swin[{dtype}].features", feat.float(), torch.from_numpy(Gd["feat"]), 2e-4 if dtype == "fp32" else 2.5e-2)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -865,6 +865,20 @@ def test_swin_attention_half_in_one_launch(ops, monkeypatch, n, H, C, heads, shi
     with ops.rows_live(word, 0):
         part = ops.swin_attn_block(*args)
     assert torch.equal(part[:n_live], full[:n_live])
+    # ... and against the ORACLE (not only against the HIP chain it replaces: VERDICT r3, P1): x + factor * attention(norm1(x)) of
+    # oracle/tri_mbt_oracle.py in fp32 on the same bf16-rounded input and weights -- the kernel is bf16-only, so the gate is a bf16
+    # one, and a second, tighter gate holds the error of the attention BRANCH (output minus the residual x, which dominates the sum)
+    if n <= 3:
+        xf = x.float().cpu()
+        sdo = {"a." + k[len("attn."):]: (v.to(torch.bfloat16).float() if k.endswith("weight") else v.float())
+               for k, v in sd.items() if k.startswith("attn.")}
+        h = torch.nn.functional.layer_norm(xf, (C,), sd["norm1.weight"].float(), sd["norm1.bias"].float(), blk.norm1.eps)
+        branch = O.swin_window_attention(sdo, "a", h, heads, shift)
+        ref = xf + sc.cpu().view(-1, 1, 1, 1) * branch
+        check(t + ".vs_oracle", full.float().cpu(), ref, 1.2e-2)
+        got_branch = (full.float().cpu() - xf)[sc.cpu() != 0]
+        ref_branch = (ref - xf)[sc.cpu() != 0]
+        check(t + ".branch_vs_oracle", got_branch, ref_branch, 2.5e-2)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -1002,6 +1016,19 @@ def test_swin_train_mode_stochastic_depth_vs_oracle(ops, dtype, monkeypatch):
     torch.cuda.synchronize()
     ref = O.swin_forward(_model_sd(2), "img_encoder", img, row_scales=pairs)
     check(f"swin_train_stochastic_depth[{dtype}].features", feat.float(), ref, 2e-4 if dtype == "fp32" else 6e-2)
+    # the same against the fixture of the REAL encoder in train mode (its recorded draws injected here)
+    Gt = G("swin_train")
+    gi = torch.Generator().manual_seed(int(Gt["seed"]))
+    img3 = torch.rand(3, 1, 224, 224, generator=gi)
+    draws, it = torch.from_numpy(Gt["draws"]), 0
+    for m in mods:
+        if m.p > 0.0:
+            m._predrawn = [draws[it + 1].to(DEV), draws[it].to(DEV)]        # popped in call order: attention branch, then MLP
+            it += 2
+    with torch.no_grad():
+        feat3 = enc(img3.to(DEV), tail_streams=(streams[0], streams[1]))
+    torch.cuda.synchronize()
+    check(f"swin_train_golden[{dtype}].features", feat3.float(), torch.from_numpy(Gt["feat"]), 2e-4 if dtype == "fp32" else 2.5e-2)
 
 
 def test_swin_tail_split_equals_single_stream(ops):
@@ -1396,7 +1423,10 @@ def test_packed_batch_training_steps_vs_golden(ops, graph):
     assert abs(tl - float(Gd["test_loss"])) < 1e-4
 
 
-BF16_STEP_GATES = dict(loss=3.5e-3, grad_norm=0.14, grad_digest=0.14, test_loss=1.8e-3)     # ~2 x the worst measured on MI355X (see the test)
+# ~2 x the figures measured on MI355X (see the test): the worst tensor, AND the median / 95th percentile over the tensors -- a
+# regression that doubles the error of every well-conditioned tensor moves the median, not the worst one
+BF16_STEP_GATES = dict(loss=3.5e-3, grad_norm=0.14, grad_digest=0.14, test_loss=1.8e-3,
+                       grad_norm_median=2e-2, grad_norm_p95=8e-2, grad_digest_median=2e-2, grad_digest_p95=8e-2)
 
 
 def test_full_training_step_bf16_tolerance(ops):
@@ -1412,6 +1442,7 @@ def test_full_training_step_bf16_tolerance(ops):
     names = [str(s) for s in Gd["grad_names"]]
     worst_n = worst_d = 0.0
     worst_name = ""
+    all_n, all_d = [], []
     med = float(np.median(Gd["grad_digest"][:, 0]))
     for n_, gd in zip(names, Gd["grad_digest"]):
         dg = _digest(grads[n_])
@@ -1424,13 +1455,21 @@ def test_full_training_step_bf16_tolerance(ops):
         if ed > worst_d:
             worst_d, worst_name = ed, n_
         worst_n = max(worst_n, en)
+        all_n.append(en)
+        all_d.append(ed)
     REPORT["step[bf16].worst_grad_norm_rel_err"] = {"rel_err": worst_n, "tol": gt["grad_norm"]}
     REPORT["step[bf16].worst_grad_digest_rel_err"] = {"rel_err": worst_d, "tol": gt["grad_digest"], "tensor": worst_name}
     REPORT["step[bf16].test_loss_abs_err"] = {"rel_err": abs(tl - float(Gd["test_loss"])), "tol": gt["test_loss"]}
+    stats = {"grad_norm_median": float(np.median(all_n)), "grad_norm_p95": float(np.percentile(all_n, 95)),
+             "grad_digest_median": float(np.median(all_d)), "grad_digest_p95": float(np.percentile(all_d, 95))}
+    for k, v in stats.items():
+        REPORT[f"step[bf16].{k}_rel_err"] = {"rel_err": v, "tol": gt[k], "tensors": len(all_n)}
     assert abs(loss1 - float(Gd["loss"])) < gt["loss"]
     assert worst_n < gt["grad_norm"], worst_n
     assert worst_d < gt["grad_digest"], (worst_d, worst_name)
     assert abs(tl - float(Gd["test_loss"])) < gt["test_loss"]
+    for k, v in stats.items():
+        assert v < gt[k], (k, v, gt[k])
 
 
 @pytest.mark.parametrize("M", [64320, 4990, 300])
@@ -1984,6 +2023,47 @@ def _unpack_rows(t, kv, pack):
     for b in range(B):
         out[b, :int(kv[b])] = flat[int(pack[b]):int(pack[b]) + int(kv[b])]
     return out
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+@pytest.mark.parametrize("N,lens", [(200, [200, 5, 64, 129, 1, 77]), (1005, [1005, 6, 700, 333]), (133, [5, 133, 64, 65, 1, 128, 129, 2, 97]),
+                                    (600, [257, 256, 255, 513, 512, 600])])
+def test_packed_attention_fp32_vs_oracle(ops, N, lens, bounded):
+    """The row_start addressing of the attention kernels in the fp32 PARITY build, against the oracle directly (the
+    packed layout used to meet the 1e-4 gate only through a chain -- fp32 padded == golden, bf16 packed == bf16 padded): forward
+    (O, O + residual, and the LSE through the backward), dQ and dK / dV at the 1e-4 gate on samples stored back to back, lengths on
+    both sides of the 64-key tile and 256-query item boundaries, every row behind the live ones poisoned with NaN.  The oracle runs
+    per sample on its own rows: a packed stream has no pad rows, so a sample's queries are its kv_len rows."""
+    dt = torch.float32
+    g = torch.Generator().manual_seed(1000 + N)
+    B = len(lens)
+    qkv = torch.randn(B, N, 768, generator=g)
+    res = torch.randn(B, N, 256, generator=g)
+    w = torch.randn(B, N, 256, generator=g)
+    kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    pack = ops.row_starts(kv, N)
+    pk = pack.cpu()
+    qd, rd, wd = (_pack_rows(t.to(DEV), lens, pk) for t in (qkv, res, w))
+    kn = None
+    if bounded:
+        kn = ops.key_norms(torch.nan_to_num(qd))                    # (the table is taken over the buffer's rows; poison would poison it)
+    o, o_res, lse = ops.attn_fwd_grouped([qd], [kv], [rd], [kn], [pack])
+    o_u, or_u = _unpack_rows(o[0], lens, pk).cpu(), _unpack_rows(o_res[0], lens, pk).cpu()
+    dqkv = ops.attn_bwd_grouped([qd], o, [torch.nan_to_num(wd)], lse, [kv], [pack])[0]
+    dq_u = _unpack_rows(dqkv, lens, pk).cpu()
+    worst = {"o": 0.0, "o_res": 0.0, "dqkv": 0.0}
+    for b, n in enumerate(lens):
+        q_ref = qkv[b:b + 1, :n].clone().requires_grad_()
+        o_ref = O.attention_core(q_ref, None)
+        (o_ref * w[b:b + 1, :n]).sum().backward()
+        rel = lambda a, r: float((a - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        worst["o"] = max(worst["o"], rel(o_u[b:b + 1, :n], o_ref.detach()))
+        worst["o_res"] = max(worst["o_res"], rel(or_u[b:b + 1, :n], o_ref.detach() + res[b:b + 1, :n]))
+        worst["dqkv"] = max(worst["dqkv"], rel(dq_u[b:b + 1, :n], q_ref.grad))
+    tag = f"attn_packed[fp32,N={N},B={B}{',bounded' if bounded else ''}]"
+    for k, v in worst.items():
+        REPORT[f"{tag}.{k}"] = {"rel_err": v, "tol": 1e-4}
+        assert v < 1e-4, (tag, k, v)
 
 
 @pytest.mark.parametrize("N,lens", [(200, [200, 5, 64, 129, 1, 77]), (1005, [1005, 6, 700, 333]), (300, [300] * 3), (70, [1]),

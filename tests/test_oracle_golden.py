@@ -256,6 +256,37 @@ def test_swin_forward(golden_dir):
     np.testing.assert_allclose(y.numpy(), G["feat"], rtol=2e-4, atol=2e-5)
 
 
+def _swin_train_pairs(G):
+    """the 12 (attention-branch, MLP-branch) row-scale pairs of O.swin_forward from the golden's recorded StochasticDepth draws
+    (call order; blocks with p = 0 made no draw)"""
+    draws, it = torch.from_numpy(G["draws"]), 0
+    pairs = []
+    for p_ in G["p"]:
+        if p_ == 0.0:
+            pairs.append((None, None))
+        else:
+            pairs.append((draws[it], draws[it + 1]))
+            it += 2
+    assert it == draws.shape[0]
+    return pairs
+
+
+def test_swin_forward_train_mode_stochastic_depth(golden_dir):
+    """The real encoder in TRAIN mode (tests/golden/gen/make_golden.py gen_swin_train): the reference's SwinTransformerBlock decides
+    where the row-mode StochasticDepth noise multiplies (swin_transformer.py:437,448-449); the draws it used are in the fixture.
+    Pins the oracle's ``row_scales`` path -- what the HIP encoder's train mode is checked against."""
+    G = _g(golden_dir, "swin_train")
+    sd = _model_sd(2)
+    g = torch.Generator().manual_seed(int(G["seed"]))
+    img = torch.rand(3, 1, 224, 224, generator=g)
+    assert float(G["draws"].min()) == 0.0                         # a dropped branch is part of the case
+    with torch.no_grad():
+        y = O.swin_forward(sd, "img_encoder", img, row_scales=_swin_train_pairs(G))
+        y_eval = O.swin_forward(sd, "img_encoder", img)
+    np.testing.assert_allclose(y.numpy(), G["feat"], rtol=2e-4, atol=2e-5)
+    assert float(np.abs(y_eval.numpy() - G["feat"]).max()) > 1e-2  # (the noise matters: eval mode is far from it)
+
+
 @pytest.mark.parametrize("size", [512, 200])
 def test_swin_forward_padded_windows_and_odd_merges(golden_dir, size):
     """--image-size 512 (maps of 128 / 64 / 32 / 16 tokens a side: every stage zero-pads its windows, swin_transformer.py:150-152)

@@ -12,7 +12,7 @@ def main():
     path, key = sys.argv[1], sys.argv[2]
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + re.escape(key) + r"\w*:", l))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end + 1]
     labels = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB\d+_\d+):", l))}
     INSTR = re.compile(r"^\s+[a-z]")

@@ -72,26 +72,47 @@ def run(what):
     first = next(iter(libs.values()))
     first.mtmp_key_norms(1, P(qkv, 512), P(kn), ctypes.c_longlong(B * N), 4, 768, st)
 
-    def fwd(L):
-        rc = L.mtmp_attn_fwd(1, P(qkv), P(qkv, 512), P(qkv, 1024), P(o), P(res), P(o_res), P(lse), P(kv), P(kn), B, N, 4, 768, 256,
-                             ctypes.c_float(0.125), st)
+    work = torch.zeros(16, dtype=torch.int32, device="cuda")
+    VP = ctypes.c_void_p
+
+    def fwd(L, name=""):
+        if hasattr(L, "mtmp_attn_work_words") and not name.endswith("static"):       # persistent kernel with its work queue
+            arr = lambda t, off=0: (VP * 1)(t.data_ptr() + off)
+            ints = lambda v: (ctypes.c_int * 1)(v)
+            rc = L.mtmp_attn_fwd_grouped(1, 1, arr(qkv), arr(qkv, 512), arr(qkv, 1024), arr(o), arr(res), arr(o_res), arr(lse), arr(kv),
+                                         None, arr(kn), ints(N), ints(768), ints(256), B, 4, ctypes.c_float(0.125), P(work), st)
+        else:
+            rc = L.mtmp_attn_fwd(1, P(qkv), P(qkv, 512), P(qkv, 1024), P(o), P(res), P(o_res), P(lse), P(kv), P(kn), B, N, 4, 768, 256,
+                                 ctypes.c_float(0.125), st)
         assert rc == 0
 
     def bwd(L):
         rc = L.mtmp_attn_bwd(1, P(qkv), P(qkv, 512), P(qkv, 1024), P(o), P(do), P(lse), P(kv), P(dqkv), P(dqkv, 512), P(dqkv, 1024),
                              P(delta), B, N, 4, 768, 256, 256, 768, ctypes.c_float(0.125), st)
         assert rc == 0
-    fn = fwd if what == "fwd" else bwd
+    fn = (lambda L, n: fwd(L, n)) if what == "fwd" else (lambda L, n: bwd(L))
     fwd(first)
     torch.cuda.synchronize()
+    ref_o = None
+    if what == "fwd":                      # outputs of every variant against the first one (ablation builds differ by design)
+        for n, L in libs.items():
+            o.zero_(); o_res.zero_(); lse.zero_()
+            fwd(L, n)
+            torch.cuda.synchronize()
+            cur = (o.float().clone(), o_res.float().clone(), lse.clone())
+            if ref_o is None:
+                ref_o = cur
+            else:
+                print(f"{n:28s} max |diff| vs {next(iter(libs))}: o {float((cur[0] - ref_o[0]).abs().max()):.3g} o_res "
+                      f"{float((cur[1] - ref_o[1]).abs().max()):.3g} lse {float((cur[2] - ref_o[2]).abs().max()):.3g}; work words {work.tolist()[:9]}")
     times = {n: [] for n in libs}
     for rnd in range(12):
         for n, L in libs.items():
-            fn(L)
+            fn(L, n)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                fn(L)
+                fn(L, n)
             e1.record()
             torch.cuda.synchronize()
             times[n].append(e0.elapsed_time(e1) / 5 * 1e3)
@@ -160,6 +181,138 @@ def timeline():
     print("resident workgroups over time:", conc)
 
 
+def clock(name="clock"):
+    """in-kernel clock (s_memtime / s_memrealtime) and phase durations of the forward, variant `clock` (or `clock_*`)"""
+    import torch
+    import numpy as np
+    B, N = 64, 1005
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B, N, 768, device="cuda", generator=g).bfloat16()
+    res = torch.randn(B, N, 256, device="cuda", generator=g).bfloat16()
+    kv = torch.full((B,), N, dtype=torch.int32, device="cuda")
+    o = torch.empty(B, N, 256, device="cuda", dtype=torch.bfloat16)
+    o_res = torch.empty_like(o)
+    lse = torch.empty(B, 4, N, device="cuda")
+    kn = torch.empty((B * N + 31) // 32, 4, device="cuda")
+    P = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = ctypes.CDLL(os.path.join(LAB, f"libattn_{name}.so"))
+    L.mtmp_key_norms(1, P(qkv, 512), P(kn), ctypes.c_longlong(B * N), 4, 768, st)
+    for _ in range(400):                    # the clock settles under sustained load (MI355X_MICROARCH, DVFS give-back item 6)
+        L.mtmp_attn_fwd(1, P(qkv), P(qkv, 512), P(qkv, 1024), P(o), P(res), P(o_res), P(lse), P(kv), P(kn), B, N, 4, 768, 256,
+                        ctypes.c_float(0.125), st)
+    torch.cuda.synchronize()
+    nwg = ((N + 255) // 256) * 4 * B
+    buf = (ctypes.c_ulonglong * (8 * nwg))()
+    assert L.mtmp_debug_read(buf, 8 * nwg) == 0
+    a = np.array(buf, dtype=np.uint64).reshape(nwg, 4, 2).astype(np.int64)
+    cyc, real = a[:, :, 0], a[:, :, 1]
+    t0 = real[:, 0].min()
+    for i, nm in enumerate(("prologue", "key loop", "epilogue")):
+        dc, dr = cyc[:, i + 1] - cyc[:, i], (real[:, i + 1] - real[:, i]) / 100.0
+        ok = dr > 0
+        print(f"{nm:9s}: median {np.median(dr):7.2f} us (min {dr.min():.2f} max {dr.max():.2f}); {np.median(dc):9.0f} cycles; "
+              f"clock {np.median(dc[ok] / dr[ok]) / 1e3:.3f} GHz")
+    s_, e_ = (real[:, 0] - t0) / 100.0, (real[:, 3] - t0) / 100.0
+    print(f"kernel span {e_.max():.1f} us; workgroup residency median {np.median(e_ - s_):.1f}; starts 0/50/100 % {np.percentile(s_, [0, 50, 100]).round(1)}; "
+          f"ends {np.percentile(e_, [0, 50, 100]).round(1)}")
+    late = s_ > 5.0
+    for nm, sel in (("first round", ~late), ("second round", late)):
+        if sel.any():
+            dr = (real[sel, 2] - real[sel, 1]) / 100.0
+            print(f"  {nm}: {sel.sum()} workgroups, key loop median {np.median(dr):.2f} us, residency {np.median((e_ - s_)[sel]):.2f} us")
+
+
+def pclock(name="pclock"):
+    """per-item real-time stamps of the persistent forward (variants pclock / pclock_static)"""
+    import torch
+    import numpy as np
+    B, N = 64, 1005
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B, N, 768, device="cuda", generator=g).bfloat16()
+    res = torch.randn(B, N, 256, device="cuda", generator=g).bfloat16()
+    kv = torch.full((B,), N, dtype=torch.int32, device="cuda")
+    o = torch.empty(B, N, 256, device="cuda", dtype=torch.bfloat16)
+    o_res = torch.empty_like(o)
+    lse = torch.empty(B, 4, N, device="cuda")
+    kn = torch.empty((B * N + 31) // 32, 4, device="cuda")
+    work = torch.zeros(16, dtype=torch.int32, device="cuda")
+    P = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)
+    VP = ctypes.c_void_p
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = ctypes.CDLL(os.path.join(LAB, f"libattn_{name}.so"))
+    L.mtmp_key_norms(1, P(qkv, 512), P(kn), ctypes.c_longlong(B * N), 4, 768, st)
+    arr = lambda t, off=0: (VP * 1)(t.data_ptr() + off)
+    ints = lambda v: (ctypes.c_int * 1)(v)
+
+    def fwd():
+        rc = L.mtmp_attn_fwd_grouped(1, 1, arr(qkv), arr(qkv, 512), arr(qkv, 1024), arr(o), arr(res), arr(o_res), arr(lse), arr(kv), None,
+                                     arr(kn), ints(N), ints(768), ints(256), B, 4, ctypes.c_float(0.125),
+                                     None if name.endswith("static") else P(work), st)
+        assert rc == 0
+    L.mtmp_debug_clear()
+    for _ in range(200):                     # back to back: the stamps of the LAST launch stay (warm clocks)
+        fwd()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * (32 * 1024))()
+    assert L.mtmp_debug_read(buf, 32 * 1024) == 0
+    a = np.array(buf, dtype=np.uint64).reshape(1024, 4, 8).astype(np.float64) / 100.0       # [workgroup][item][stamp] in us
+    live = a[:, 0, 0] > 0
+    t0 = a[live, 0, 0].min()
+    a = np.where(a > 0, a - t0, np.nan)
+    print(f"{name}: workgroups that ran: {int(live.sum())}; items per workgroup histogram {np.bincount((~np.isnan(a[live, :, 0])).sum(1))}")
+    for k in range(4):
+        sel = ~np.isnan(a[:, k, 3])
+        if not sel.any():
+            continue
+        x = a[sel, k]
+        print(f"item {k}: n {int(sel.sum())}: start median {np.median(x[:, 0]):6.1f} | first phase (to loop start) {np.median(x[:, 1] - x[:, 0]):5.2f} | key loop "
+              f"{np.median(x[:, 2] - x[:, 1]):5.2f} (min {np.min(x[:, 2] - x[:, 1]):.2f} max {np.max(x[:, 2] - x[:, 1]):.2f}) | epilogue {np.median(x[:, 3] - x[:, 2]):5.2f} | end median {np.median(x[:, 3]):6.1f} max {np.max(x[:, 3]):6.1f}")
+        print(f"        loop start -> all tiles but the last {np.nanmedian(x[:, 4] - x[:, 1]):5.2f} | publish + last tile {np.nanmedian(x[:, 5] - x[:, 4]):5.2f} | decode + request next "
+              f"{np.nanmedian(x[:, 6] - x[:, 5]):5.2f} | drain {np.nanmedian(x[:, 2] - x[:, 6]):5.2f}")
+
+
+def clock_bwd(name="clock_bwd"):
+    """in-kernel clock and phase durations of the two backward kernels (variant `clock_bwd`)"""
+    import torch
+    import numpy as np
+    B, N = 64, 1005
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B, N, 768, device="cuda", generator=g).bfloat16()
+    res = torch.randn(B, N, 256, device="cuda", generator=g).bfloat16()
+    do = torch.randn(B, N, 256, device="cuda", generator=g).bfloat16()
+    kv = torch.full((B,), N, dtype=torch.int32, device="cuda")
+    o = torch.empty(B, N, 256, device="cuda", dtype=torch.bfloat16)
+    o_res = torch.empty_like(o)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B * 4 * N, device="cuda")
+    lse = torch.empty(B, 4, N, device="cuda")
+    kn = torch.empty((B * N + 31) // 32, 4, device="cuda")
+    P = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + off)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L = ctypes.CDLL(os.path.join(LAB, f"libattn_{name}.so"))
+    L.mtmp_key_norms(1, P(qkv, 512), P(kn), ctypes.c_longlong(B * N), 4, 768, st)
+    L.mtmp_attn_fwd(1, P(qkv), P(qkv, 512), P(qkv, 1024), P(o), P(res), P(o_res), P(lse), P(kv), P(kn), B, N, 4, 768, 256, ctypes.c_float(0.125), st)
+    for _ in range(150):
+        L.mtmp_attn_bwd(1, P(qkv), P(qkv, 512), P(qkv, 1024), P(o), P(do), P(lse), P(kv), P(dqkv), P(dqkv, 512), P(dqkv, 1024),
+                        P(delta), B, N, 4, 768, 256, 256, 768, ctypes.c_float(0.125), st)
+    torch.cuda.synchronize()
+    nwg = ((N + 127) // 128) * 4 * B
+    for which, kname in ((0, "dQ"), (1, "dK/dV")):
+        buf = (ctypes.c_ulonglong * (8 * nwg))()
+        assert L.mtmp_debug_read(buf, 8 * nwg, which) == 0
+        a = np.array(buf, dtype=np.uint64).reshape(nwg, 4, 2).astype(np.int64)
+        cyc, real = a[:, :, 0], a[:, :, 1]
+        t0 = real[:, 0].min()
+        print(f"== {kname}: {nwg} workgroups")
+        for i, nm in enumerate(("prologue", "tile loop", "epilogue")):
+            dc, dr = cyc[:, i + 1] - cyc[:, i], (real[:, i + 1] - real[:, i]) / 100.0
+            ok = dr > 0
+            print(f"{nm:9s}: median {np.median(dr):7.2f} us (min {dr.min():.2f} max {dr.max():.2f}); {np.median(dc):9.0f} cycles; clock {np.median(dc[ok] / dr[ok]) / 1e3:.3f} GHz")
+        s_, e_ = (real[:, 0] - t0) / 100.0, (real[:, 3] - t0) / 100.0
+        print(f"kernel span {e_.max():.1f} us; residency median {np.median(e_ - s_):.1f}; starts 0/25/50/75/100 % {np.percentile(s_, [0, 25, 50, 75, 100]).round(1)}; ends {np.percentile(e_, [0, 25, 50, 75, 100]).round(1)}")
+
+
 def stamps():
     import torch
     B, N = 64, 1005
@@ -194,6 +347,12 @@ def stamps():
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "pclock":
+        pclock(*sys.argv[2:3])
+    elif sys.argv[1] == "clock_bwd":
+        clock_bwd(*sys.argv[2:3])
+    elif sys.argv[1] == "clock":
+        clock(*sys.argv[2:3])
     elif sys.argv[1] == "stamps":
         stamps()
     elif sys.argv[1] == "timeline":
