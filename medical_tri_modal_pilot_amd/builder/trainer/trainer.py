@@ -15,10 +15,8 @@ Differences, all required to run off-CUDA-autocast and on any device:
 """
 import torch
 
-from medical_tri_modal_pilot_amd import ops
+from medical_tri_modal_pilot_amd import ops, tuning
 from medical_tri_modal_pilot_amd.builder.data.tie_dataset import PackedTie, PackedTieBatch
-
-PREFORK_IMAGE_ENCODER = True      # model.prefork(): the frozen image encoder's stream forks before zero_grad (A/B: tools/dbg/ab_patch.py)
 
 GRAPH_LEN_BUCKET = 128
 GRAPH_EVENT_BUCKET = 4096       # packed batches: the event count is rounded up to this for hipGraph replays
@@ -155,7 +153,7 @@ def _staged_step(model, enc, optimizer, criterion, run_model, bounds):
         return res[:len(bnd)]
 
     def stage0(t, carry):
-        if PREFORK_IMAGE_ENCODER and hasattr(model, "prefork"):
+        if tuning.PREFORK_IMAGE_ENCODER and hasattr(model, "prefork"):
             model.prefork(t["x_img"])
         optimizer.zero_grad()
         step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
@@ -281,7 +279,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
                       txt_time=txt_time, final_target=final_target, **packed_extra)
         if len(bounds) <= 2:
             def fwd_bwd(t):
-                if PREFORK_IMAGE_ENCODER and hasattr(model, "prefork"):
+                if tuning.PREFORK_IMAGE_ENCODER and hasattr(model, "prefork"):
                     model.prefork(t["x_img"])            # the image encoder's stream forks at the head of the step
                 optimizer.zero_grad()
                 step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])

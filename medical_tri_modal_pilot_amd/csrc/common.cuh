@@ -171,15 +171,28 @@ template <> MTMP_DEV f32x4 load4<bf16>(const bf16* p) {
     return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
 }
 
+// Wave-wide reductions on the DPP path (round 4).  __shfl_xor lowers to ds_bpermute_b32 -- a round trip through the LDS crossbar,
+// ~100+ cycles each, six of them in a dependent chain per reduction: the one-wave-per-row kernels on the step's tail (TIE /
+// stream-input backward: a few waves per CU, nothing to hide the chain behind) spent most of their time there.  Here a 16-lane
+// row is reduced by four rotate-within-row DPP operands fused into the adds (row_ror:8/4/2/1: every lane of the row ends with
+// the row's result), and the four rows meet through v_readlane: ~12 plain vector instructions, no LDS.
+template <int CTRL> MTMP_DEV float dpp_row(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+MTMP_DEV float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 MTMP_DEV float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_row<0x128>(v);
+    v += dpp_row<0x124>(v);
+    v += dpp_row<0x122>(v);
+    v += dpp_row<0x121>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 MTMP_DEV float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_row<0x128>(v));
+    v = fmaxf(v, dpp_row<0x124>(v));
+    v = fmaxf(v, dpp_row<0x122>(v));
+    v = fmaxf(v, dpp_row<0x121>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 // max / sum over the two half-waves (lane i <-> lane i + 32) without the LDS crossbar: v_permlane32_swap
 MTMP_DEV float half_max(float x) {
@@ -264,11 +277,8 @@ MTMP_DEV f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p);
 
 // sum two values across the wave at once
 MTMP_DEV void wave_sum2(float& a, float& b) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        a += __shfl_xor(a, o, 64);
-        b += __shfl_xor(b, o, 64);
-    }
+    a = wave_sum(a);
+    b = wave_sum(b);
 }
 
 // block partials: every wave adds its per-lane accumulators acc[NV][4] into LDS, block writes one slab row

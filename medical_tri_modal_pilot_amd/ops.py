@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, tuning
 from ._lib import BF16, F32, call
 
 LN_EPS = 1e-6          # builder/models/src/transformer/module.py:132
@@ -46,67 +46,10 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-# Stream-ordered time stamps (mtmp_timestamp): off unless marks_enable() was called.  mark(name) launches a one-lane kernel on
-# the current stream that stores the wall clock into the slot of `name`; inside a captured step the launches become graph
-# nodes, so every replay refreshes the slots.  Users: bench.py (in-step duration of the roofline kernels: kernel_marks brackets
-# the grouped attention / weight-gradient launches) and tools/dbg/timeline.py (un-profiled per-stream timeline).
-_marks: Optional[torch.Tensor] = None
-_mark_slots: dict = {}
-_mark_only: Optional[tuple] = None
-_mark_seq: dict = {}
-
-
-def marks_enable(device, n: int = 1024, only: Optional[tuple] = None):
-    """only: name prefixes to record (None = every mark)."""
-    global _marks, _mark_only
-    _marks = torch.zeros(n, dtype=torch.int64, device=device)
-    _mark_only = only
-    _mark_slots.clear()
-    _mark_seq.clear()
-
-
-def marks_disable():
-    global _marks
-    _marks = None
-
-
-def marks_new_step():
-    """restart the per-step launch counters of kernel_marks (call before every eager step / before a capture)"""
-    _mark_seq.clear()
-
-
-def mark(name: str):
-    if _marks is None or (_mark_only is not None and not name.startswith(_mark_only)):
-        return
-    i = _mark_slots.setdefault(name, len(_mark_slots))
-    call("mtmp_timestamp", _p(_marks, 8 * i), _stream())
-
-
-class kernel_marks:
-    """with kernel_marks("attn_fwd", N): <launch>  -- stamps "k.attn_fwd.N<N>.<i>.s / .e" around the i-th such launch of a step"""
-
-    def __init__(self, kind: str, n_rows: int):
-        self.name = None
-        if _marks is not None:
-            key = f"k.{kind}.N{n_rows}"
-            i = _mark_seq.get(key, 0)
-            _mark_seq[key] = i + 1
-            self.name = f"{key}.{i}"
-
-    def __enter__(self):
-        if self.name is not None:
-            mark(self.name + ".s")
-
-    def __exit__(self, *exc):
-        if self.name is not None:
-            mark(self.name + ".e")
-        return False
-
-
-def marks_read() -> dict:
-    """{name: microseconds} of the last pass over every mark (100 MHz counter)."""
-    v = _marks.cpu().tolist()
-    return {k: v[i] / 100.0 for k, i in _mark_slots.items()}
+# Measurement instrumentation (stream-ordered time stamps around kernels inside a replayed step) lives in instrument.py; the names
+# are re-exported here because the model code and bench.py call them as ops.mark / ops.kernel_marks.  Off unless bench.py or a
+# tools/ script calls marks_enable(): mark() is then a no-op and no launch is added to the step.
+from .instrument import kernel_marks, mark, marks_disable, marks_enable, marks_new_step, marks_read  # noqa: E402,F401
 
 
 # Device-resident step word of the dropout masks.  The scalar `seed` arguments below are frozen into a captured
@@ -337,13 +280,7 @@ def swin_attn_block(x, ln_w, ln_b, eps, wqkv, bqkv, table, heads, shift, wproj, 
 
 
 REDUCE_BATCH_MAX = 8
-# FusionStackFn.backward: True = a layer's reduction launch goes out behind the NEXT bottleneck exchange (one layer late).  That
-# was worth 0.05 ms while every layer ran three dense streams; with the CLS-only last layer and the row-restricted FFN in front
-# of it the in-place order is the faster one (full 8.00 vs 8.06 ms/step, ragged 5.96 vs 6.01, --force-ddp 8.11 vs 8.20; four
-# A/B rounds in one box, tools/dbg/ab_modflag.sh).
-LATE_REDUCTIONS = False
-FOLD_DROPOUT_BWD = True         # layer_backward: drop2's backward inside the dH launch (A/B: tools/dbg/ab_patch.py)
-DEFER_REDUCTIONS = True        # layer_backward: one mtmp_reduce_batch per layer and stream instead of seven reduction launches
+# (scheduling switches -- LATE_REDUCTIONS, FOLD_DROPOUT_BWD, DEFER_REDUCTIONS, GROUP_MODE ... -- live in tuning.py)
 
 
 def gemm_tn(dy2d, x2d, want_bias=True, out=None, defer=None, pack=None):
@@ -1063,11 +1000,6 @@ class StreamInputFn(torch.autograd.Function):
 PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, c2
 
 
-# Order in which a layer's streams are issued (capture order = the order a replayed graph hands work to the hardware queues).
-# Measured inside one box (tools/dbg/ab_order.sh, ms/step): vital-sign stream first 9.23-9.37; text, image, vital-sign in the
-# backward only 9.38-9.39; side streams first both ways 9.51-9.65.
-STREAM_ISSUE_ORDER_FWD = (0, 1, 2)
-STREAM_ISSUE_ORDER_BWD = (0, 1, 2)
 
 def layer_forward(z, kv_len, P, fused, drop_p, seeds):
     """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T, wqkv^T, w1^T) in compute dtype.
@@ -1125,11 +1057,11 @@ def layer_backward(saved, d_out, sink=None, late=None):
     d_out = d_out.view(M, D)
     # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
     direct = sink is not None and sink.usable()
-    red = [] if DEFER_REDUCTIONS else None        # this layer's seven gradient reductions, issued as ONE launch at the end
+    red = [] if tuning.DEFER_REDUCTIONS else None        # this layer's seven gradient reductions, issued as ONE launch at the end
     # dH = dY2 W2, gated by h > 0 (which encodes ReLU and drop1's mask) in the GEMM epilogue: from the forward's sign bits
     # (bf16: M N / 8 bytes of gate instead of re-reading h) or, in the fp32 build, from h itself.  With the sign-bit kernel the
     # backward of drop2 (dY2 = dropout_bwd(d_out)) rides on its operand load: one launch and one read of d_out less.
-    if hsign is not None and p > 0 and FOLD_DROPOUT_BWD:
+    if hsign is not None and p > 0 and tuning.FOLD_DROPOUT_BWD:
         dh, dy2 = gemm_nt_signs(d_out, w2t, hsign, 1.0 / (1.0 - p), drop_p=p, seed=seeds[1])
     else:
         dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
@@ -1229,9 +1161,9 @@ def cls_layer_backward(saved, d_cls, sink=None, late=None):
     M = B * N
     d_out = _c(d_cls).to(z.dtype)
     direct = sink is not None and sink.usable()
-    red = [] if DEFER_REDUCTIONS else None
+    red = [] if tuning.DEFER_REDUCTIONS else None
     # ---- FFN of the B CLS rows
-    if hsign is not None and p > 0 and FOLD_DROPOUT_BWD:
+    if hsign is not None and p > 0 and tuning.FOLD_DROPOUT_BWD:
         dh, dy2 = gemm_nt_signs(d_out, w2t, hsign, 1.0 / (1.0 - p), drop_p=p, seed=seeds[1])
     else:
         dy2 = dropout_bwd(d_out, seeds[1], p) if p > 0 else d_out
@@ -1266,12 +1198,11 @@ def cls_layer_backward(saved, d_cls, sink=None, late=None):
 # One launch per layer step over the active streams (bf16): csrc/common.cuh, Grouped.  The three streams of a fusion layer are
 # 1005 / 54 / 133 tokens long; as three launches on three HIP streams the short ones held whole-CU workgroup slots beside the
 # long one's kernels (round 2: every vital-sign-stream kernel 15-40 % slower in the step than alone, ~1.2 ms per step, ~200
-# launches).  The parity (fp32) build keeps one launch per stream.
-GROUPED_LAUNCHES = True
+# launches).  The parity (fp32) build keeps one launch per stream.  (switch: tuning.GROUPED_LAUNCHES)
 
 
 def grouped_ok(z) -> bool:
-    return GROUPED_LAUNCHES and z.dtype == torch.bfloat16
+    return tuning.GROUPED_LAUNCHES and z.dtype == torch.bfloat16
 
 
 def layer_forward_grouped(zs, kv_lens, Ps, fuseds, drop_p, seeds, packs=None, ffn_rows=None):
@@ -1410,14 +1341,12 @@ def _exchange_w(dev):
 #   "all"   -- one launch per step over all active streams, on the caller's stream
 #   "small" -- the vital-sign stream alone on the caller's stream, image + text together on side stream 0
 #   "none"  -- one launch group per stream (vital signs on the caller's stream, image / text on the two side streams)
-# Measured in one box (bench.py, ms/step): see DESIGN.md section 7.
-GROUP_MODE = "small"
-FFN_ROWS_BEFORE_LAST = True
+# Measured in one box (bench.py, ms/step): see DESIGN.md section 7.  (switches: tuning.GROUP_MODE, tuning.FFN_ROWS_BEFORE_LAST)
 
 
 def launch_groups(ms, streams, z, solo=False):
     """[(stream indices, HIP side stream | None)] for the active streams `ms` of one layer."""
-    mode = "none" if (solo or not grouped_ok(z)) else GROUP_MODE
+    mode = "none" if (solo or not grouped_ok(z)) else tuning.GROUP_MODE
     if len(ms) == 1 or streams is None and mode != "all":
         return [([m], None) for m in ms] if mode != "all" else [(list(ms), None)]
     if mode == "all":
@@ -1431,7 +1360,7 @@ def stream_of_group(m, streams, z):
     """the HIP side stream on which the group led by stream m runs its backward (None = the caller's stream)"""
     if m == 0 or streams is None:
         return None
-    mode = GROUP_MODE if grouped_ok(z) else "none"
+    mode = tuning.GROUP_MODE if grouped_ok(z) else "none"
     if mode == "all":
         return None
     return streams[0] if mode == "small" else streams[(m - 1) % len(streams)]
@@ -1507,7 +1436,7 @@ class FusionStackFn(torch.autograd.Function):
             # inputs are still being made on the side streams (the vital-sign stream's first layer runs beside the image encoder)
             # the layer in front of a last layer that runs stream 0 alone, read by a CLS-only reader (the encoder names it, by its
             # index in this segment): the image / text outputs of THIS layer feed the bottleneck exchange (rows 0..3) and nothing else
-            exchange_only = li == cfg.get("exchange_only_layer", -1) and FFN_ROWS_BEFORE_LAST
+            exchange_only = li == cfg.get("exchange_only_layer", -1) and tuning.FFN_ROWS_BEFORE_LAST
             if last and cfg.get("cls_only"):       # the reader takes the CLS row only: ops.cls_layer_forward
                 P = params[(li * n_s) * PARAMS_PER_LAYER:(li * n_s + 1) * PARAMS_PER_LAYER]
                 mark(f"f{li}.g0.s")
@@ -1611,7 +1540,7 @@ class FusionStackFn(torch.autograd.Function):
             dz[0][:, NB, :] += d_cls.to(dt)
         pgrads = [None] * len(pshapes)
         d_prev_bott = None           # gradient flowing into the previous exchange's output through resbottle
-        # With LATE_REDUCTIONS a layer's gradient reductions (one mtmp_reduce_batch launch per stream) are issued one layer LATE, on the same stream:
+        # With tuning.LATE_REDUCTIONS a layer's gradient reductions (one mtmp_reduce_batch launch per stream) are issued one layer LATE, on the same stream:
         # the bottleneck exchange in between needs the streams' dz but none of their parameter gradients, and it is the image /
         # text streams' last launches that the vital-sign stream waits for there.
         late = [[], [], []]          # keyed by the first stream of the launch group that produced them
@@ -1637,7 +1566,7 @@ class FusionStackFn(torch.autograd.Function):
                 mark(f"b{li}.g0.s")
                 d1 = d_cls if d_cls is not None else torch.zeros(B, D_MODEL, dtype=dt, device=dev)
                 nxt[0], gg0 = cls_layer_backward(saved[li][0], d1, cfg["sinks"][li][0] if cfg.get("sinks") else None,
-                                                 late=late[0] if LATE_REDUCTIONS else None)
+                                                 late=late[0] if tuning.LATE_REDUCTIONS else None)
                 if gg0 is not None:
                     base = (li * n_s) * PARAMS_PER_LAYER
                     for k in range(PARAMS_PER_LAYER):
@@ -1659,7 +1588,7 @@ class FusionStackFn(torch.autograd.Function):
                 with (torch.cuda.stream(gs) if gs is not None else contextlib.nullcontext()):
                     mark(f"b{li}.g{gms[0]}.s")
                     flush_late(gms[0])                  # the layer above's reductions of this group: behind this layer's exchange
-                    lt = late[gms[0]] if LATE_REDUCTIONS else None
+                    lt = late[gms[0]] if tuning.LATE_REDUCTIONS else None
                     if grouped_ok(saved[li][ms[0]][0]):
                         gdz, gg = layer_backward_grouped([saved[li][m] for m in gms], [dz[m] for m in gms],
                                                          [cfg["sinks"][li][m] if cfg.get("sinks") else None for m in gms], lt)

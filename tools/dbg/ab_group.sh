@@ -1,5 +1,5 @@
 # A/B of the launch-group modes in one box: bash tools/dbg/ab_group.sh [rounds]
-O=medical_tri_modal_pilot_amd.ops
+O=medical_tri_modal_pilot_amd.tuning
 A="--no-cpu-baseline --steps 30 --warmup 10 --probe-launches 0"
 for r in $(seq 1 ${1:-2}); do
   for m in none small all; do
