@@ -187,59 +187,79 @@ __global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T
     for (int v = 0; v < 7; ++v)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[v][i] = 0.f;
-    for (int row = blockIdx.x * 4 + wave; row < B * R; row += gridDim.x * 4) {
-        const int b = row / R, r = row - b * R;
-        size_t grow = (size_t)row;
-        if (row_start) {                                                       // packed gradient rows (see the forward)
-            if (r >= kv_len[b]) {                                              // a pad row of the padded input x: zero gradient
+    // Two of the wave's rows are in flight: every load of both rows (gradient, input row, LayerNorm statistics; clamped
+    // addresses, no branch around a load) is issued before the first row is used -- one dependent load round per row made this
+    // a 52 us launch on the step's tail (1.9 TB/s), where nothing else runs.  Rows are still accumulated in order (same sums).
+    constexpr int PF = 2;
+    const int stride = gridDim.x * 4, nrows = B * R;
+    for (int row0 = blockIdx.x * 4 + wave; row0 < nrows; row0 += PF * stride) {
+        int bb[PF], rr[PF];
+        bool live[PF];
+        f32x4 gg[PF], vv[PF];
+        float mn[PF], rs[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int row = min(row0 + k * stride, nrows - 1);
+            const int b = row / R, r = row - b * R;
+            bb[k] = b; rr[k] = r;
+            live[k] = row0 + k * stride < nrows && !(row_start && r >= kv_len[b]);
+            const size_t grow = row_start ? (size_t)row_start[b] + min(r, max(kv_len[b] - 1, 0)) : (size_t)row;
+            gg[k] = load4<T>(dz + grow * D + 4 * lane);
+            const int t = max(r - nb, 0);
+            vv[k] = load4<T>(x + ((size_t)b * N + max(t - 1, 0)) * D + 4 * lane);
+            const size_t lnrow = (size_t)b * (N + 1) + t;
+            mn[k] = stats[2 * lnrow]; rs[k] = stats[2 * lnrow + 1];
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            if (row0 + k * stride >= nrows) continue;
+            const int b = bb[k], r = rr[k];
+            if (!live[k]) {                                                    // packed gradient rows: a pad row of the padded input x
                 if (r > nb) store4<T>(dx + ((size_t)b * N + r - nb - 1) * D + 4 * lane, 0.f, 0.f, 0.f, 0.f);
                 continue;
             }
-            grow = (size_t)row_start[b] + r;
-        }
-        f32x4 g = load4<T>(dz + grow * D + 4 * lane);
-        if (r < nb) {                                                          // wave-uniform
+            f32x4 g = gg[k];
+            if (r < nb) {                                                      // wave-uniform
 #pragma unroll
-            for (int k = 0; k < NB_MAX; ++k)
-                if (r == k)
+                for (int q = 0; q < NB_MAX; ++q)
+                    if (r == q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[3 + k][i] += g[i];
-            continue;
-        }
-        const int t = r - nb, lnrow = b * (N + 1) + t;
-        if (thr) {
-            const unsigned keep = dropout_keep4(seed, (unsigned)lnrow * 64u + lane, thr);
+                        for (int i = 0; i < 4; ++i) acc[3 + q][i] += g[i];
+                continue;
+            }
+            const int t = r - nb, lnrow = b * (N + 1) + t;
+            if (thr) {
+                const unsigned keep = dropout_keep4(seed, (unsigned)lnrow * 64u + lane, thr);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = (keep >> i) & 1u ? g[i] * sc : 0.f;
-        }
-        f32x4 v;
-        if (t == 0) {
-            const f32x4 c = ld4f(cls + 4 * lane);
-            v = f32x4{round_as<T>(c[0]), round_as<T>(c[1]), round_as<T>(c[2]), round_as<T>(c[3])};
-        } else {
-            v = load4<T>(x + ((size_t)b * N + t - 1) * D + 4 * lane);
-        }
-        const float mean = stats[2 * (size_t)lnrow], rstd = stats[2 * (size_t)lnrow + 1];
-        float xh[4], gy[4], sg = 0.f, sgx = 0.f;
+                for (int i = 0; i < 4; ++i) g[i] = (keep >> i) & 1u ? g[i] * sc : 0.f;
+            }
+            f32x4 v = vv[k];
+            if (t == 0) {
+                const f32x4 c = ld4f(cls + 4 * lane);
+                v = f32x4{round_as<T>(c[0]), round_as<T>(c[1]), round_as<T>(c[2]), round_as<T>(c[3])};
+            }
+            const float mean = mn[k], rstd = rs[k];
+            float xh[4], gy[4], sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xh[i] = (v[i] - mean) * rstd;
-            acc[0][i] += g[i] * xh[i];
-            acc[1][i] += g[i];
-            gy[i] = g[i] * gm[i];
-            sg += gy[i];
-            sgx += gy[i] * xh[i];
-        }
-        wave_sum2(sg, sgx);
-        const float mg = sg * (1.0f / D), mgx = sgx * (1.0f / D);
-        float dv[4];
+            for (int i = 0; i < 4; ++i) {
+                xh[i] = (v[i] - mean) * rstd;
+                acc[0][i] += g[i] * xh[i];
+                acc[1][i] += g[i];
+                gy[i] = g[i] * gm[i];
+                sg += gy[i];
+                sgx += gy[i] * xh[i];
+            }
+            wave_sum2(sg, sgx);
+            const float mg = sg * (1.0f / D), mgx = sgx * (1.0f / D);
+            float dv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dv[i] = rstd * (gy[i] - mg - xh[i] * mgx);
-        if (t == 0) {
+            for (int i = 0; i < 4; ++i) dv[i] = rstd * (gy[i] - mg - xh[i] * mgx);
+            if (t == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[2][i] += dv[i];
-        } else {
-            store4<T>(dx + ((size_t)b * N + t - 1) * D + 4 * lane, dv[0], dv[1], dv[2], dv[3]);
+                for (int i = 0; i < 4; ++i) acc[2][i] += dv[i];
+            } else {
+                store4<T>(dx + ((size_t)b * N + t - 1) * D + 4 * lane, dv[0], dv[1], dv[2], dv[3]);
+            }
         }
     }
     flush_partials<7>(acc, slab + (size_t)blockIdx.x * 7 * D, lds, lane, wave);
@@ -372,13 +392,16 @@ __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const flo
         }
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
-            if (e[k] < 0) continue;                                             // pad row / past the end: no event, no gradient
+            // pad row / past the end: no event -- its gradient row counts as zero (every sum below then adds +0: the same
+            // values as skipping it) so that the four rows' chains are straight-line code the scheduler can interleave: with a
+            // branch per row the wave ran one dependent chain of ~400 instructions per row at two waves per SIMD (79 us)
+            const f32x4 gk = e[k] < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : g[k];
             const int f = min(max((int)ff[k], 0), 19);
-            if (VAL) tie_chain_bwd(cv, val[k], g[k], acc, 0);
-            tie_chain_bwd(ct, tau[k], g[k], acc, 4);
+            if (VAL) tie_chain_bwd(cv, val[k], gk, acc, 0);
+            tie_chain_bwd(ct, tau[k], gk, acc, 4);
             f32x4* tp = reinterpret_cast<f32x4*>(my_tab + f * D + 4 * lane);    // wave-private: plain read-modify-write
             f32x4 tv = *tp;
-            tv += g[k];
+            tv += gk;
             *tp = tv;
         }
     }
