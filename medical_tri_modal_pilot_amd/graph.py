@@ -37,6 +37,13 @@ import torch
 from . import ops
 
 _GOLDEN = 0x9E3779B1          # odd increment of the step word
+# Captured graphs are NEVER destroyed while the process lives.  On ROCm 7.2 / torch 2.10, hipGraphExecDestroy of one captured step
+# (a dropped GraphedTrainStep, an entry evicted from its LRU) makes a LATER hipGraphLaunch of another one crash on the host in
+# hip::Graph::UpdateStreams (rocgdb backtrace of `pytest tests -m gpu -k packed`, round 4: twenty graph tests in a row, each
+# dropping its trainer, then a segfault in the replay of the next test's fresh graph; waiting for the device and collecting
+# garbage at a quiet point between the tests did not help, holding on to the graphs did).  A training run captures a handful of
+# graphs; their memory stays with the step's private pool anyway.
+_ALIVE = []
 
 
 class GraphedTrainStep:
@@ -129,6 +136,7 @@ class GraphedTrainStep:
         graphs, ready, carry = [], [], {}
         for i, stage in enumerate(stages):
             g = torch.cuda.CUDAGraph()
+            _ALIVE.append(g)                     # (before the capture: a failed capture's graph is not destroyed either)
             # thread_local: other threads (autograd workers, the RCCL watchdog) may keep making HIP calls during capture
             with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                 if i == 0:
