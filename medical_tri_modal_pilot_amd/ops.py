@@ -1001,22 +1001,38 @@ PARAMS_PER_LAYER = 14     # g1, b1, wq, bq, wk, bk, wv, bv, g2, b2, w1, c1, w2, 
 
 
 
-def layer_forward(z, kv_len, P, fused, drop_p, seeds):
+def _packed_full(rows2d, B, N):
+    """rows2d [live, C] -> a [B, N, C] buffer whose first `live` rows are rows2d (a PACKED stream buffer; the rest is never read)"""
+    full = torch.empty(B, N, rows2d.shape[1], dtype=rows2d.dtype, device=rows2d.device)
+    full.view(B * N, -1)[:rows2d.shape[0]] = rows2d
+    return full
+
+
+def layer_forward(z, kv_len, P, fused, drop_p, seeds, pack=None):
     """z [B,N,256] contiguous.  P: the 14 parameters; fused: (wqkv, bqkv, w1, w2, w2^T, wqkv^T, w1^T) in compute dtype.
-    Returns (out [B,N,256], saved tuple)."""
+    Returns (out [B,N,256], saved tuple).
+    pack (row_starts(kv_len, N)): z is a PACKED stream buffer (the samples' kv_len rows back to back) and so is `out`.  This
+    single-stream form (the fp32 parity build's) reads the row count on the HOST -- one sync, no hipGraph -- and runs the row
+    kernels on the live rows as dense [live, C] matrices; the attention kernels address the samples through pack exactly as the
+    bf16 grouped launches do (layer_forward_grouped takes the count from the device instead)."""
     B, N, D = z.shape
     M = B * N
     g1, b1, g2, b2, c1, c2 = P[0], P[1], P[8], P[9], P[11], P[13]
     wqkv, bqkv, w1c, w2c, w2t, wqkvt, w1t = fused
-    z2 = z.view(M, D)
+    live = M if pack is None else int(pack[B])
+    z2 = z.view(M, D)[:live]
     qkv, xn1, st1, knorm = ln_gemm_qkv(z2, g1, b1, wqkv, bqkv)
-    qkv = qkv.view(B, N, 3 * D)
-    o, r1, lse = attn_fwd(qkv, kv_len, res=z, knorm=knorm)
-    r1_2 = r1.view(M, D)
+    if pack is None:
+        qkv = qkv.view(B, N, 3 * D)
+        o, r1, lse = attn_fwd(qkv, kv_len, res=z, knorm=knorm)
+    else:
+        qkv = _packed_full(qkv, B, N)
+        (o,), (r1,), (lse,) = attn_fwd_grouped([qkv], [kv_len], [z], [knorm], [pack])
+    r1_2 = r1.view(M, D)[:live]
     h, xn2, st2, hsign = ln_gemm(r1_2, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
     out = gemm_nt(h, w2c, c2, res2d=r1_2, drop_p=drop_p, seed=seeds[1])
-    saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds, hsign)
-    return out.view(B, N, D), saved
+    saved = (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, drop_p, seeds, hsign, pack)
+    return (out.view(B, N, D) if pack is None else _packed_full(out, B, N)), saved
 
 
 class GradSink:
@@ -1052,9 +1068,11 @@ def layer_backward(saved, d_out, sink=None, late=None):
     in PARAMS order; weights as 2-D [out,in])) -- or (dz, None) when the gradients went straight into
     the flat gradient buffer through `sink`."""
     z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o, lse, r1, xn2, st2, h, p, seeds, hsign = saved[:19]
+    pack = saved[19] if len(saved) > 19 else None           # (layer_forward's packed single-stream form: rows counted on the host)
     B, N, D = z.shape
     M = B * N
-    d_out = d_out.view(M, D)
+    live = M if pack is None else int(pack[B])
+    d_out = d_out.view(M, D)[:live]
     # ---- FFN: out = drop2(h w2^T + c2) + r1,  h = drop1(relu(LN2(r1) w1^T + c1))
     direct = sink is not None and sink.usable()
     red = [] if tuning.DEFER_REDUCTIONS else None        # this layer's seven gradient reductions, issued as ONE launch at the end
@@ -1072,11 +1090,14 @@ def layer_backward(saved, d_out, sink=None, late=None):
     dw2, dc2 = gemm_tn(dy2, h, out=(sink.w2, sink.c2) if direct else None, defer=red)       # [256,1024], [256]
     dw1, dc1 = gemm_tn(dh, xn2, out=(sink.w1, sink.c1) if direct else None, defer=red)      # [1024,256], [1024]
     # dXn2 = dH W1 and the backward of LN2 (+ the residual gradient) in one launch; the M x 256 product stays in LDS
-    dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D), st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None, defer=red)
+    dr1, dg2, db2 = gemm_lnbwd(dh, w1t, r1.view(M, D)[:live], st2, g2, d_res2d=d_out, gb_out=sink.gb2 if direct else None, defer=red)
     # ---- attention: r1 = z + o  ->  d_o = dr1
-    dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
+    if pack is None:
+        dqkv = attn_bwd(qkv, o, dr1.view(B, N, D), lse, kv_len).view(M, 3 * D)
+    else:
+        dqkv = attn_bwd_grouped([qkv], [o], [_packed_full(dr1, B, N)], [lse], [kv_len], [pack])[0].view(M, 3 * D)[:live]
     dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None, defer=red)   # [768,256], [768]
-    dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z.view(M, D), st1, g1, d_res2d=dr1, gb_out=sink.gb1 if direct else None, defer=red)
+    dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z.view(M, D)[:live], st1, g1, d_res2d=dr1, gb_out=sink.gb1 if direct else None, defer=red)
     if late is not None and red:
         # the caller issues this layer's reduction (and marks the gradients ready) later on this stream -- behind the next
         # bottleneck exchange, which needs dz but none of the parameter gradients (FusionStackFn.backward)
@@ -1086,11 +1107,12 @@ def layer_backward(saved, d_out, sink=None, late=None):
             reduce_batch(red)
         if direct:
             sink.flat.mark_ready(sink.idx)
+    dz = dz.view(B, N, D) if pack is None else _packed_full(dz, B, N)
     if direct:
-        return dz.view(B, N, D), None
+        return dz, None
     grads = (dg1, db1, dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
              dg2, db2, dw1, dc1, dw2, dc2)
-    return dz.view(B, N, D), grads
+    return dz, grads
 
 
 # ----------------------------------------------------------------------------- the last layer of a CLS-only reader
