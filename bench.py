@@ -143,6 +143,10 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true",
                     help="run the RCCL reducer even with one rank (exercises the N>1 code path on a 1-GPU box)")
     ap.add_argument("--print-loss", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path on a one-GPU box (not a measurement): every rank uses GPU 0 and the "
+                         "collectives go through gloo -- the staged graphs, the merged collectives, the plan check, the broadcast "
+                         "and the rank-equality check at the end run exactly as with RCCL")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check without a GPU: every rank joins a gloo group, barriers, and rank 0 "
                          "prints a JSON line")
@@ -181,9 +185,13 @@ def main():
             print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(), "max_rank": int(t)}))
         dist.destroy_process_group()
         return
+    if a.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if ddp:
+    if ddp and a.rehearse_on_one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif ddp:
         # RCCL prints a version banner on stdout when its communicator comes up: keep stdout for the JSON line
         sys.stdout.flush()
         saved_fd = os.dup(1)
@@ -287,6 +295,18 @@ def main():
         dt, med = float(t[0]), float(t[1])
     if not math.isfinite(loss):
         raise SystemExit(f"non-finite loss {loss}")
+    ranks_agree = None
+    if world > 1:
+        # data-parallel ranks start from rank 0's parameters and apply the same all-reduced gradients: after the run every rank
+        # must hold the SAME parameters, bit for bit (outside the timed region; a violation is a bug in the reducer, not noise)
+        flat = opt.flat.data
+        cs = torch.stack([flat.double().sum(), flat.double().abs().sum(), flat[::997].double().square().sum()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(torch.equal(lo, hi))
+        if not ranks_agree:
+            raise SystemExit(f"rank {rank}: parameters differ across ranks after {a.warmup + a.steps} steps: {lo.tolist()} vs {hi.tolist()}")
 
     n_tok = TIE_LEN + 5
     flops_dense = {"attn_fwd": 4.0 * B_PER_GPU * 4 * n_tok * n_tok * 64,
@@ -414,7 +434,8 @@ def main():
             "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "graphs_per_step": n_graphs,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
-            "rccl_ranks": dist.get_world_size() if ddp else 1,
+            "rccl_ranks": dist.get_world_size() if ddp else 1, "ranks_hold_identical_parameters": ranks_agree,
+            "rehearsal_on_one_gpu_over_gloo": bool(a.rehearse_on_one_gpu),
             "config": {"workload": wl_text + f", dropout {a.dropout}, mbt-only-vslt 1, imgtxt-time 1"
                                    + (" -- events fed as PackedTieBatch" if a.packed else "")
                                    + ("" if a.pack_rows else " -- padded fusion stack (--pack-rows 0)")

@@ -2525,3 +2525,30 @@ def test_attn_cls_row_all_keys_masked(ops, dt):
     # the dense kernels on the same inputs take the same path
     od, _, _ = ops.attn_fwd_grouped([qkv], [kv], [z], [None], None)
     assert torch.allclose(od[0][:, cls_tok].float(), o.float(), atol=tol * 4)
+
+
+@pytest.mark.parametrize("workload", ["full", "ragged"])
+def test_two_rank_rehearsal_on_one_gpu(workload):
+    """The N > 1 code path end to end without a second GPU ("never run with a second rank"): two ranks of bench.py on
+    GPU 0, collectives over gloo (--rehearse-on-one-gpu; everything but RCCL itself is the production path -- broadcast of rank 0's
+    state, two captured graphs per step, merged bucket collectives issued behind each stage, the cross-rank plan check, AdamW on the
+    summed gradients with the 1 / world factor).  The ranks see DIFFERENT batches; after warm-up + timed steps they must hold
+    bit-identical parameters (bench.py checks it with MIN / MAX all-reduces of three checksums and fails otherwise)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--workload", workload,
+           "--steps", "3", "--warmup", "3", "--no-cpu-baseline", "--probe-launches", "0", "--instep-steps", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["graphs_per_step"] == 2 and d["hip_graph"]
+    assert d["ranks_hold_identical_parameters"] is True and d["rehearsal_on_one_gpu_over_gloo"] is True
+    REPORT[f"two_rank_rehearsal[{workload}].ranks_hold_identical_parameters"] = {"rel_err": 0.0, "tol": 0.0}
