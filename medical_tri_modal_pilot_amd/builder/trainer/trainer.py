@@ -164,10 +164,10 @@ def _staged_step(model, enc, optimizer, criterion, run_model, bounds):
         bnds = carry["bnds"] = list(enc.segment_boundaries)
         if len(bnds) != n_stage - 1:          # the encoder did not cut (torch input chain, resbottle, ...): one backward
             carry["bnds"] = []
-            step_loss.backward()
+            torch.autograd.backward([step_loss], [ops.unit_grad(step_loss)])
             return
         prm = model.backward_stage_params(n_pre + bounds[-2], n_pre + bounds[-1], head=True)
-        carry["g"] = partial([step_loss], None, bnds[-1], prm)
+        carry["g"] = partial([step_loss], [ops.unit_grad(step_loss)], bnds[-1], prm)
 
     def later(k):
         def stage(t, carry):
@@ -284,7 +284,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
                 optimizer.zero_grad()
                 step_loss = ops.bce_with_logits(criterion, run_model(t), t["final_target"])
                 gs.publish_loss(step_loss)           # the host takes the value from here (gs.wait_loss below)
-                step_loss.backward()
+                torch.autograd.backward([step_loss], [ops.unit_grad(step_loss)])
                 ops.mark("bwd.e")                    # (tools/dbg/timeline.py; nothing is launched unless marks are enabled)
                 return step_loss.detach()
             loss = gs.run(inputs, fwd_bwd, optimizer.flat.params, reducer=red, round_fp16=deferred)
@@ -306,7 +306,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         optimizer.zero_grad()
         output = run_model()
         loss = ops.bce_with_logits(criterion, output, final_target)
-        loss.backward()
+        torch.autograd.backward([loss], [ops.unit_grad(loss)])
         optimizer.step()
         scheduler.step(iteration)
         logger.log_lr(scheduler.get_lr()[0], iteration)

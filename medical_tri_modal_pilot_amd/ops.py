@@ -931,7 +931,23 @@ class BceLogitsMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
+        if g is _UNIT_GRAD.get((g.device.type, g.device.index)):      # loss.backward() through unit_grad(): d itself, no launch
+            return d.view(ctx.shape), None
         return (d * g).view(ctx.shape), None
+
+
+_UNIT_GRAD = {}
+
+
+def unit_grad(loss: torch.Tensor) -> torch.Tensor:
+    """The constant 1.0 a scalar loss is differentiated with, made once per device: `torch.autograd.backward(loss, unit_grad(loss))`
+    instead of `loss.backward()` spares the step the fill of a fresh ones tensor, and BceLogitsMean.backward -- which recognises
+    this very tensor -- the multiplication by it (two small launches between the forward and the backward, where nothing else runs)."""
+    key = (loss.device.type, loss.device.index)
+    one = _UNIT_GRAD.get(key)
+    if one is None or one.dtype != loss.dtype:
+        one = _UNIT_GRAD[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return one
 
 
 def bce_with_logits(criterion, output, target):
