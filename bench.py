@@ -38,6 +38,7 @@ The JSON line also carries
                    scaled linearly; 1 warm-up + 3 timed steps, median), rank 0, N = 1 only.
 """
 import argparse
+import datetime
 import json
 import math
 import os
@@ -197,7 +198,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # one node: RCCL's bootstrap goes over loopback (the host name of these boxes may not resolve); a rendezvous that does not
+            # complete fails after five minutes instead of holding the job for the default half hour
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
             dist.all_reduce(torch.zeros(1, device=dev))
             torch.cuda.synchronize()
         finally:

@@ -1805,6 +1805,7 @@ def test_cfg1_sample_data_windows_product_vs_oracle(ops):
     assert abs(loss1 - ref1) < 1e-4 and abs(loss2 - ref2) < 1e-4, (loss1, ref1, loss2, ref2)
 
 
+@pytest.mark.timeout(420, method="thread")      # (a stalled rendezvous / communicator must fail this test, not hang the suite)
 def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
     """The data-parallel path on the one GPU of this box: RCCL process group of one rank, ddp.GradReducer attached to
     FusedAdamW (bucketed all-reduce of the flat gradient on a side stream, ready callbacks from the kernels that write
@@ -1815,9 +1816,14 @@ def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
     import medical_tri_modal_pilot_amd.optim as optim_mod
     full = [[96, 96, 50, 7]] * 4
     ref = {g: _loop(g, 0.0, "fp32", 4, full)[:2] for g in (0, 1)}
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29677")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    import datetime
+    import socket
+    with socket.socket() as sk:                  # a port nobody holds (a fixed one can be taken on a shared host)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")       # one node: RCCL's bootstrap needs no routable interface
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV),
+                            timeout=datetime.timedelta(seconds=180))
     orig_init = optim_mod.FusedAdamW.__init__
     made = []
 
