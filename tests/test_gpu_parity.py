@@ -38,13 +38,34 @@ def check(name, got, ref, tol):
     assert math.isfinite(e) and e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
 
 
+IN_CHILD = os.environ.get("MTMP_TEST_CHILD") == "1"      # this session was started BY a test of the parent session (see _in_child_process)
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _dump_report():
     yield
+    if IN_CHILD:
+        return
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_report.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def _in_child_process(test_name, timeout=600):
+    """Run ONE test of this file in a pytest session of its own and assert that it passed.  For tests that create and DESTROY HIP
+    streams they do not own -- an RCCL process group: round 4, twice in eight runs the suite stalled inside, or segfaulted in the
+    graph replay right behind, the single-rank RCCL test (hip::Graph::UpdateStreams) -- so that nothing of it survives in the
+    process the other ~220 tests share.  Returns True in the parent (done), False in the child (run the body)."""
+    if IN_CHILD:
+        return False
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::{test_name}", "-x", "-q", "-m", "gpu",
+                        "-p", "no:cacheprovider"], env=dict(os.environ, MTMP_TEST_CHILD="1"), capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    return True
 
 
 @pytest.fixture(scope="module")
@@ -1811,6 +1832,9 @@ def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
     FusedAdamW (bucketed all-reduce of the flat gradient on a side stream, ready callbacks from the kernels that write
     gradients directly, the modality side streams joined before each bucket).  With one rank the all-reduce is the
     identity, so losses and parameters must equal the plain run bit for bit -- eager (overlapped buckets) and graph."""
+    if _in_child_process("test_ddp_reducer_single_rank_rccl_matches_plain_run", timeout=360):
+        REPORT["ddp_single_rank_vs_plain[fp32]"] = {"rel_err": 0.0, "tol": 0.0}
+        return
     import torch.distributed as dist
     from medical_tri_modal_pilot_amd.ddp import GradReducer
     import medical_tri_modal_pilot_amd.optim as optim_mod
