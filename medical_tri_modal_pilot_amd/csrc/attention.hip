@@ -1052,6 +1052,369 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkdv_k
     }
 }
 
+// ---- dK/dV, 64 keys per wave (bf16 build, round 5): ONE wave per SIMD, the accumulators in the AGPR half of the register file.
+// Why (round-4 ablations): in the 32-key kernel a wave's 32 MFMAs per tile stand against ~290 other instructions
+// (64 LDS fragment reads, 150 vector, 64 scalar, 18 waits); the MFMAs alone and everything else alone each take ~100 of its 139 us.
+// Here every Q / dO fragment read from LDS serves TWO key blocks (64 MFMAs per tile against the same 64 reads), and the structure
+// the compiler could not be talked into (round 4: 176-192 spills in VGPR form, 492 v_accvgpr moves per tile in AGPR form) is
+// written down by hand:
+//   * dV^T / dK^T of the wave's 64 keys (128 registers) and its K / V operand fragments (64) are `"+a"` / `"a"` operands of
+//     inline-asm MFMAs: they live in a[0:191] for the whole kernel, the compiler allocates and tracks them (no literal register
+//     names), and no vector instruction touches them before the epilogue.
+//   * S' / dP' are written by asm MFMAs into VGPRs (B operand from the AGPRs, C = the -LSE / -delta rows) and read by the
+//     exponentials one SLOT later.  The compiler does not know these statements are MFMAs, so the MFMA -> VALU read distance
+//     (11 wait states for an 8-pass MFMA) is guaranteed by construction: a slot issues its score products FIRST, then the eight
+//     gradient products, and every step ends in sched_barrier(0) -- nothing moves across, the first reader stands >= 8 MFMAs
+//     behind the last writer.  P / dS leave the vector unit one slot before the gradient products read them.
+//   * One slot = one 32 x 32 unit (query block, key block) in three stages of a software pipeline that never drains:
+//         S', dP' of unit u + 1 (8 MFMA)  |  exp2, mul, cvt of unit u (one score per MFMA gap)  |  dV, dK of unit u - 1 (8 MFMA)
+//     16 MFMAs beside 48 vector instructions and (every other slot) 32 LDS reads: per gap 1 v_exp + 1 v_mul + 1 v_cvt_pk + 2
+//     ds_read = ~24 issue cycles beside a 32-cycle MFMA (MI355X_MICROARCH: <= 24 hide at one wave per SIMD).
+//   * Operand registers roll: a Q / dO row fragment, a row-constant group or a transposed fragment is reloaded for the NEXT slot
+//     that needs it right behind the MFMA that read it last (A / B operands have no write-after-read hazard; the row constants
+//     are reloaded one step later, and an LDS return is > 50 cycles away anyway).
+//   * Three LDS stages, one barrier per tile in FRONT of the tile's last slot: that slot already loads the next tile's first
+//     fragments, so no MFMA ever waits for an LDS round trip behind a barrier.
+// Streams under BWD64_MIN_ROWS rows (config 2: 1005 / 54 / 133 tokens) and the fp32 parity build keep the 32-key kernel.
+#define MTMP_MFMA_FIRST(d, a, b, c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c))
+#define MTMP_MFMA_NEXT(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b))
+#define MTMP_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b))
+
+#ifdef MTMP_LAB_CLOCK                                         // lab builds only (tools/dbg/dkdv64_clock.py): s_memtime stamps of the first workgroups
+__device__ long long mtmp_dbg_stamps[64 * 4 * 160];
+#define STAMP(k) do { if (wg < 64 && lane == 0 && (k) < 160) mtmp_dbg_stamps[(wg * 4 + wave) * 160 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+constexpr int DKV64_KEYS = 256;                              // keys per workgroup
+// Launches whose longest stream is shorter keep the 32-key kernel.  Measured (round 5, B 64, H 4, one box, dQ + dK/dV in us): N 600:
+// 127 vs 119 for the 32-key kernel, N 1005: 261 vs 260 (in the step 316 vs 302), N 2005: 922 vs 960.  One wave per SIMD exposes
+// every workgroup's prologue + epilogue (~8.7 us per workgroup, 35 us of a 135 us launch at N 1005: four rounds of 256 workgroups
+// with nothing beside them on the CU); the tile loop itself holds 70 % of the MFMA rate (the 32-key kernel: 41 % over the launch).
+// The fixed part is amortised over N / 64 tiles, so the form pays from ~1500 rows on (configs[4]: TIE-len 2000).
+constexpr int BWD64_MIN_ROWS = 1536;
+constexpr int BWD64_STAGES = 3;
+constexpr int DKV64_OUT_BYTES = 2 * 64 * LDT * 2;            // per wave: dK | dV of its 64 keys as [key][LDT] bf16 rows (epilogue staging)
+
+// a value DEFINED in the accumulator file: later "a" operands then need no copy (an ordinary value given to an "a" operand is
+// copied into a fresh AGPR tuple in front of every statement that reads it)
+MTMP_DEV bf16x8 to_agpr(bf16x8 x) {
+    bf16x8 y;
+    asm volatile("" : "=a"(y) : "0"(x));
+    return y;
+}
+struct PackedUnit { u32x4_t p[2], d[2]; };                   // P and dS of a unit as the B fragments of k-steps 0, 1
+MTMP_DEV unsigned cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
+
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv64_kernel(Grouped<AttnBwdArgs<bf16>> grp) {
+    using T = bf16;
+    using DT = DualTile<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int seg = grp_find(grp, wg);
+    const AttnBwdArgs<T>& p = grp.seg[seg];
+    const int w = wg - grp.first[seg];
+    const int nkt = (p.N + DKV64_KEYS - 1) / DKV64_KEYS;
+    const int kt = w % nkt, bh = w / nkt, hd = bh % p.H;
+    const int b = p.row_start ? p.row_start[p.B + 1 + bh / p.H] : bh / p.H;      // packed: samples in mtmp_row_starts' balanced order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    int kvl = p.kv_len ? min(p.kv_len[b], p.N) : p.N;
+    const int row0 = p.row_start ? p.row_start[b] : b * p.N;
+    const int Nq = p.row_start ? max(kvl, 0) : p.N;
+    if (kt * DKV64_KEYS >= Nq) return;
+    STAMP(0);
+    const bool uniform = kvl <= 0;            // forward = uniform average: p = 1/N (K = 0 below), dS = 0
+    if (uniform) kvl = Nq;
+    const size_t base = (size_t)row0 * p.ld_qkv + hd * DH;
+    const T* Qb = p.q + base; const T* Kb = p.k + base; const T* Vb = p.v + base;
+    const T* dOb = p.d_o + (size_t)row0 * p.ld_do + hd * DH;
+    const float* Lb = p.lse + ((size_t)b * p.H + hd) * p.N;
+    const float* Db = p.delta + ((size_t)b * p.H + hd) * p.N;
+    const int kw0 = kt * DKV64_KEYS + wave * 64;             // first key of this wave
+    f32x16 dv00 = {0}, dv01 = {0}, dk00 = {0}, dk01 = {0}, dv10 = {0}, dv11 = {0}, dk10 = {0}, dk11 = {0};   // d<k|v><key block><dh half>
+    if (kt * DKV64_KEYS < kvl) {              // workgroup-uniform: keys past kv_len get zero gradients
+        const float c2 = p.scale * LOG2E;
+        Frag<T> kx[2][4], vx[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int key = kw0 + 32 * kb + r;
+                kx[kb][c] = frag_load<T>(Kb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half);
+                vx[kb][c] = frag_load<T>(Vb + (size_t)min(key, kvl - 1) * p.ld_qkv + 16 * c + 8 * half);
+            }
+        const int nq = (Nq + KT - 1) / KT;
+        TileStream<T> qs, os;
+        qs.init(Qb, p.ld_qkv, Nq, tid);
+        os.init(dOb, p.ld_do, Nq, tid);
+        TileR<T> qreg, oreg;
+        const int lrow = tid & (KT - 1);
+        float lreg, dreg;
+        auto stage = [&](int t) { return smem_raw + (t % BWD64_STAGES) * dkdv_stage_bytes<T>(); };
+        // Staging of a tile (global -> registers one tile ahead, registers -> LDS) in six pieces, so that an active wave can issue
+        // them between the MFMAs of a slot that has no LDS reads of its own (as one block in front of the slot they cost ~800
+        // cycles per tile with an empty matrix pipe: in-kernel stamps, round 5).  Pieces 0-2 put tile tp, 3-5 fetch tile tf; the
+        // loads are unconditional (clamped addresses) and their values untouched before the put (see the 32-key kernel).
+        auto stage_piece = [&](int k, int tp, int tf) {
+            if (k < 3) {
+                if (tp >= nq) return;
+                char* st_ = stage(tp);
+                if (k == 0) DT::put(st_, qreg, tid);
+                else if (k == 1) DT::put(st_ + DT::BYTES, oreg, tid);
+                else if (tid < KT) {               // C operands of the score products: -lse (-inf past N), -delta
+                    float* sL = reinterpret_cast<float*>(st_ + 2 * DT::BYTES);
+                    sL[tid] = (tp * KT + tid < Nq) ? -lreg : -INFINITY;
+                    sL[KT + tid] = (tp * KT + tid < Nq) ? -dreg : 0.f;
+                }
+            } else {
+                if (tf >= nq) return;
+                if (k == 3) qreg = qs.fetch(tf);
+                else if (k == 4) oreg = os.fetch(tf);
+                else {
+                    const int qn = min(tf * KT + lrow, Nq - 1);
+                    lreg = Lb[qn];
+                    dreg = Db[qn];
+                }
+            }
+        };
+        auto stage_all = [&](int tp, int tf) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) stage_piece(k, tp, tf);
+        };
+        stage_all(nq, 0);                      // fetch tile 0
+        bf16x8 kf[2][4], vf[2][4];             // "a" operands from here on
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool live = kw0 + 32 * kb + r < kvl;
+                kf[kb][c] = to_agpr(frag_keep(frag_scale<T>(kx[kb][c], c2), live && !uniform).v);
+                vf[kb][c] = to_agpr(frag_keep(vx[kb][c], live).v);
+            }
+        stage_all(0, 1);                       // put tile 0, fetch tile 1
+        __syncthreads();                       // tile 0 visible
+        const bool active = kw0 < kvl;         // wave-uniform: a wave whose keys are all past kv_len only stages tiles
+        // rolling operand registers (see the header): rows / row constants of ONE query block, transposed fragments of ONE query block
+        bf16x8 qa[4], oa[4], tr[2][4];
+        f32x16 cL, cD;
+        // LDS addressing: every fragment address is  stage base + a LANE pattern + a compile-time constant.  The five lane patterns
+        // (DualTile<bf16>::off at the lane's row / chunk) are computed once; per tile one add each gives the stage's bases, and
+        // everything else is the ds_read's immediate offset (the form the compiler found by itself rebuilt ~90 addresses per tile).
+        struct LaneOffs { unsigned rowE, rowO, cst, trA, trB; };
+        LaneOffs lo;
+        {
+            const int sr = swz23(r), G = lane >> 4, i16 = lane & 15;
+            lo.rowE = DT::off(sr, half);                               // row fragments, k-steps 0 / 2 (+512)
+            lo.rowO = DT::off(sr, 2 + half);                           //                k-steps 1 / 3 (+512)
+            lo.cst = 2 * DT::BYTES + 32 * half;                        // row constants (floats 8 half ..)
+            const int trow = 8 * (G >> 1) + (i16 >> 2), tch = 2 * (G & 1) + ((i16 & 3) >> 1);
+            lo.trA = DT::off(trow, tch) + 8 * (i16 & 1);               // transposed fragments: rows q16 + ..
+            lo.trB = DT::off(trow + 4, tch) + 8 * (i16 & 1);           //                       rows q16 + 4 + ..
+            const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_raw;
+            lo.rowE += lds0; lo.rowO += lds0; lo.cst += lds0; lo.trA += lds0; lo.trB += lds0;
+        }
+        typedef __attribute__((address_space(3))) const char lds_cchar;
+        auto lds_at = [](unsigned ofs) { return (lds_cchar*)(size_t)ofs; };
+        auto bases = [&](int t) {
+            const unsigned sb = (unsigned)((t % BWD64_STAGES) * dkdv_stage_bytes<T>());
+            LaneOffs x{lo.rowE + sb, lo.rowO + sb, lo.cst + sb, lo.trA + sb, lo.trB + sb};
+            asm volatile("" : "+v"(x.rowE), "+v"(x.rowO), "+v"(x.cst), "+v"(x.trA), "+v"(x.trB));      // opaque: keep base + immediate
+            return x;
+        };
+        auto load_rows = [&](const LaneOffs& bs, int qb, int c, bool dO) {
+            typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+            const bf16x8 v = *(lds_bf16x8*)(lds_at((c & 1) ? bs.rowO : bs.rowE) + 512 * (c >> 1) + 4096 * qb + (dO ? DT::BYTES : 0));
+            if (dO) oa[c] = v; else qa[c] = v;
+        };
+        auto load_const = [&](const LaneOffs& bs, int qb, int k4, bool dlt) {   // registers 4 k4 .. 4 k4 + 3: queries 32 qb + 16 (k4 >> 1) + 8 half + 4 (k4 & 1) ..
+            typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+            const f32x4 v4 = *(lds_f32x4*)(lds_at(bs.cst) + (dlt ? 4 * KT : 0) + 4 * (32 * qb + 16 * (k4 >> 1) + 4 * (k4 & 1)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { if (dlt) cD[4 * k4 + i] = v4[i]; else cL[4 * k4 + i] = v4[i]; }
+        };
+        auto load_tr = [&](const LaneOffs& bs, int qb, int s2, int j) {         // j: 0, 1 = dO^T (dh halves), 2, 3 = Q^T
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const int imm = 4096 * qb + 2048 * s2 + 512 * (j & 1) + (j < 2 ? DT::BYTES : 0);
+            const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_at(bs.trA) + imm));
+            const s16x4 b4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_at(bs.trB) + imm));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            tr[s2][j] = __builtin_bit_cast(bf16x8, s16x8{a[0], a[1], a[2], a[3], b4[0], b4[1], b4[2], b4[3]});
+        };
+        // One slot (see the header).  (sN, dN): the unit whose scores are produced; (sC, dC) -> out: the unit whose probabilities are
+        // taken; in: the unit whose gradients are accumulated into the key block's four accumulators.  MODE 1: this slot reloads
+        // the row operands from (st_rows, qb_rows) and the transposed fragments from (st_tr, qb_tr) behind their last readers;
+        // MODE 2: it carries the staging pieces of tiles (tp, tf) instead.
+        auto slot = [&](auto mode_tag, f32x16& sN, f32x16& dN, const bf16x8 (&kfb)[4], const bf16x8 (&vfb)[4], f32x16& sC, f32x16& dC,
+                        PackedUnit& out, const PackedUnit& in, f32x16& dv0, f32x16& dv1, f32x16& dk0, f32x16& dk1,
+                        const LaneOffs& st_rows, int qb_rows, const LaneOffs& st_tr, int qb_tr, int tp, int tf) {
+            constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                // ---- matrix pipe
+                if (i == 0) MTMP_MFMA_FIRST(sN, qa[0], kfb[0], cL);
+                else if (i < 4) MTMP_MFMA_NEXT(sN, qa[i], kfb[i]);
+                else if (i == 4) MTMP_MFMA_FIRST(dN, oa[0], vfb[0], cD);
+                else if (i < 8) MTMP_MFMA_NEXT(dN, oa[i - 4], vfb[i - 4]);
+                else {
+                    const int s2 = (i - 8) >> 2, j = (i - 8) & 3;
+                    if (j == 0) MTMP_MFMA_ACC(dv0, tr[s2][0], in.p[s2]);
+                    else if (j == 1) MTMP_MFMA_ACC(dv1, tr[s2][1], in.p[s2]);
+                    else if (j == 2) MTMP_MFMA_ACC(dk0, tr[s2][2], in.d[s2]);
+                    else MTMP_MFMA_ACC(dk1, tr[s2][3], in.d[s2]);
+                }
+                // ---- vector unit: one score of the current unit (the product one step behind its exponential: a transcendental
+                // result read by the very next vector instruction costs a wait state)
+                const float e = fast_exp2(sC[i]);
+                if (i > 0) dC[i - 1] *= sC[i - 1];
+                sC[i] = e;
+                if (i & 1) out.p[i >> 3][(i & 7) >> 1] = cvt_pk_bf16(sC[i - 1], e);
+                if (i >= 2 && !(i & 1)) out.d[(i - 2) >> 3][((i - 2) & 7) >> 1] = cvt_pk_bf16(dC[i - 2], dC[i - 1]);
+                if (i == 15) {
+                    dC[15] *= e;
+                    out.d[1][3] = cvt_pk_bf16(dC[14], dC[15]);
+                }
+                // ---- LDS: operands of the next slots into the registers this step's MFMA has just read
+                if (MODE == 1) {
+                    if (i < 4) load_rows(st_rows, qb_rows, i, false);
+                    else if (i < 8) load_rows(st_rows, qb_rows, i - 4, true);
+                    else load_tr(st_tr, qb_tr, (i - 8) >> 2, (i - 8) & 3);
+                    if (i >= 1 && i < 5) load_const(st_rows, qb_rows, i - 1, false);
+                    else if (i >= 5 && i < 9) load_const(st_rows, qb_rows, i - 5, true);
+                }
+                // ---- staging of the next tiles, a piece every other step
+                if (MODE == 2 && (i & 1) && i < 12) stage_piece(i >> 1, tp, tf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        f32x16 sA, dA, sB, dB;                 // the two units in flight
+        PackedUnit fX, fY;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { sB[t] = -INFINITY; dB[t] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            fX.p[s2] = u32x4_t{0, 0, 0, 0}; fX.d[s2] = u32x4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tr[s2][j] = frag_zero<T>().v;
+        }
+        if (active) {
+            const LaneOffs b0 = bases(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                load_rows(b0, 0, c, false); load_rows(b0, 0, c, true);
+                load_const(b0, 0, c, false); load_const(b0, 0, c, true);
+            }
+        }
+        const std::integral_constant<int, 0> plain{};
+        const std::integral_constant<int, 1> loads{};
+        const std::integral_constant<int, 2> staging{};
+        STAMP(1);
+        for (int it = 0; it < nq; ++it) {
+            STAMP(2 + 8 * it);
+            const LaneOffs cur = bases(it);
+            const LaneOffs nxt = bases(it + 1 < nq ? it + 1 : it);     // (last tile: harmless reloads of its own rows)
+            if (active) {
+                __builtin_amdgcn_sched_barrier(0);
+                STAMP(3 + 8 * it);
+                // A: scores (0,0) | probabilities of the previous tile's (1,1) | gradients of its (1,0); staging: put tile it + 1, fetch tile it + 2
+                slot(staging, sA, dA, kf[0], vf[0], sB, dB, fY, fX, dv00, dv01, dk00, dk01, cur, 0, cur, 0, it + 1, it + 2);
+                STAMP(4 + 8 * it);
+                // B: scores (0,1) | probabilities (0,0) | gradients of the previous (1,1); reload: rows of block 1, transposed block 0
+                slot(loads, sB, dB, kf[1], vf[1], sA, dA, fX, fY, dv10, dv11, dk10, dk11, cur, 1, cur, 0, 0, 0);
+                STAMP(5 + 8 * it);
+                // C: scores (1,0) | probabilities (0,1) | gradients (0,0)
+                slot(plain, sA, dA, kf[0], vf[0], sB, dB, fY, fX, dv00, dv01, dk00, dk01, cur, 0, cur, 0, 0, 0);
+                STAMP(6 + 8 * it);
+            } else {
+                stage_all(it + 1, it + 2);
+            }
+            __syncthreads();                   // tile it + 1 visible; stage (it + 2) % 3 is free (its last readers: slot D of tile it - 1)
+            if (active) {
+                STAMP(7 + 8 * it);
+                // D: scores (1,1) | probabilities (1,0) | gradients (0,1); reload: rows of the NEXT tile's block 0, transposed block 1
+                slot(loads, sB, dB, kf[1], vf[1], sA, dA, fX, fY, dv10, dv11, dk10, dk11, nxt, 0, cur, 1, 0, 0);
+                STAMP(8 + 8 * it);
+            }
+        }
+        if (active) {                          // drain: probabilities of the last (1,1) beside the gradients of the last (1,0), then its own
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < 8) {
+                    const int s2 = i >> 2, j = i & 3;
+                    if (j == 0) MTMP_MFMA_ACC(dv00, tr[s2][0], fX.p[s2]);
+                    else if (j == 1) MTMP_MFMA_ACC(dv01, tr[s2][1], fX.p[s2]);
+                    else if (j == 2) MTMP_MFMA_ACC(dk00, tr[s2][2], fX.d[s2]);
+                    else MTMP_MFMA_ACC(dk01, tr[s2][3], fX.d[s2]);
+                }
+                const float e = fast_exp2(sB[i]);
+                dB[i] *= e;
+                sB[i] = e;
+                if (i & 1) {
+                    fY.p[i >> 3][(i & 7) >> 1] = cvt_pk_bf16(sB[i - 1], e);
+                    fY.d[i >> 3][(i & 7) >> 1] = cvt_pk_bf16(dB[i - 1], dB[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                MTMP_MFMA_ACC(dv10, tr[s2][0], fY.p[s2]);
+                MTMP_MFMA_ACC(dv11, tr[s2][1], fY.p[s2]);
+                MTMP_MFMA_ACC(dk10, tr[s2][2], fY.d[s2]);
+                MTMP_MFMA_ACC(dk11, tr[s2][3], fY.d[s2]);
+            }
+        }
+        STAMP(150);
+        // the compiler reads the accumulators below without knowing that MFMAs wrote them: cover the last products' passes here
+        asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dv00), "+a"(dv01), "+a"(dk00), "+a"(dk01), "+a"(dv10), "+a"(dv11), "+a"(dk10), "+a"(dk11));
+    }
+    // Epilogue.  dK^T / dV^T: rows = head dimension (registers), columns = this wave's keys (lanes): a lane owns 4-element pieces of
+    // its key's rows, so direct stores are 64 eight-byte pieces per lane at a row stride (store-issue bound: ~9.8k cycles per
+    // workgroup, stamps).  The wave's two 64 x 64 tiles go through a wave-private LDS region of their own (no barrier: the
+    // stages may still be read by slower waves) and leave as whole 128-byte rows, 16 sixteen-byte stores per lane.  Keys past
+    // kv_len (and the whole dK of a fully masked sample) are written as zeros -- a select, not a product with 0: such a key
+    // may hold NaN / inf garbage in its own column.
+    T* sOut = reinterpret_cast<T*>(smem_raw + BWD64_STAGES * dkdv_stage_bytes<T>() + wave * DKV64_OUT_BYTES);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int key = kw0 + 32 * kb + r;
+        const bool live = key < kvl;
+        const bool wk = live && !uniform;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x16& ak = kb ? (dt ? dk11 : dk10) : (dt ? dk01 : dk00);
+                const f32x16& av = kb ? (dt ? dv11 : dv10) : (dt ? dv01 : dv00);
+                const int d0 = 32 * dt + 8 * g + 4 * half;
+                store4<T>(sOut + (32 * kb + r) * LDT + d0, wk ? ak[4 * g] * p.scale : 0.f, wk ? ak[4 * g + 1] * p.scale : 0.f,
+                          wk ? ak[4 * g + 2] * p.scale : 0.f, wk ? ak[4 * g + 3] * p.scale : 0.f);
+                store4<T>(sOut + (64 + 32 * kb + r) * LDT + d0, live ? av[4 * g] : 0.f, live ? av[4 * g + 1] : 0.f,
+                          live ? av[4 * g + 2] : 0.f, live ? av[4 * g + 3] : 0.f);
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: in-order LDS, no barrier needed
+    {
+        const int rsub = lane >> 3, ch = lane & 7;
+        u32x4_t ok[8], ov[8];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            ok[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sOut + (8 * ps + rsub) * LDT) + 16 * ch);
+            ov[ps] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const char*>(sOut + (64 + 8 * ps + rsub) * LDT) + 16 * ch);
+        }
+        T* krow = p.dk + ((size_t)row0 + kw0 + rsub) * p.ld_dqkv + hd * DH + 8 * ch;
+        T* vrow = p.dv + ((size_t)row0 + kw0 + rsub) * p.ld_dqkv + hd * DH + 8 * ch;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps)
+            if (kw0 + 8 * ps + rsub < Nq) {
+                *reinterpret_cast<u32x4_t*>(krow + (size_t)8 * ps * p.ld_dqkv) = ok[ps];
+                *reinterpret_cast<u32x4_t*>(vrow + (size_t)8 * ps * p.ld_dqkv) = ov[ps];
+            }
+    }
+    STAMP(151);
+}
+
 template <typename T> size_t fwd_smem() { return (size_t)2 * fwd_stage_elems<T>() * sizeof(T); }   // >= 4 x 64 x LDT staging rows
 template <typename T> size_t dq_smem() { return (size_t)2 * dq_stage_bytes<T>(); }
 template <typename T> size_t dkdv_smem() { return (size_t)2 * dkdv_stage_bytes<T>(); }
@@ -1096,6 +1459,21 @@ template <typename T> int launch_bwd(int n, const AttnBwdArgs<T>* segs, hipStrea
     if (int e = set_smem(attn_bwd_dq_kernel<T>, dq_smem<T>())) return e;
     hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(nwg), dim3(256), dq_smem<T>(), st, g);      // also writes delta
     MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dq)");
+    if constexpr (sizeof(T) == 2) {
+        // long streams (the vital-sign stream): 64 keys per wave, 256 per workgroup; short ones keep the 32-key kernel
+        int nmax = 0;
+        for (int i = 0; i < n; ++i) nmax = segs[i].N > nmax ? segs[i].N : nmax;
+        if (nmax >= BWD64_MIN_ROWS) {
+            int nwg64;
+            const Grouped<AttnBwdArgs<T>> g64 =
+                make_group(n, segs, [](const AttnBwdArgs<T>& a) { return ((a.N + DKV64_KEYS - 1) / DKV64_KEYS) * a.H * a.B; }, nwg64);
+            const size_t sm64 = (size_t)BWD64_STAGES * dkdv_stage_bytes<T>() + 4 * DKV64_OUT_BYTES;
+            if (int e = set_smem(attn_bwd_dkdv64_kernel, sm64)) return e;
+            hipLaunchKernelGGL(attn_bwd_dkdv64_kernel, dim3(nwg64), dim3(256), sm64, st, g64);
+            MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dkdv64)");
+            return MTMP_OK;
+        }
+    }
     if (int e = set_smem(attn_bwd_dkdv_kernel<T>, dkdv_smem<T>())) return e;
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<T>, dim3(nwg), dim3(256), dkdv_smem<T>(), st, g);
     MTMP_CHECK_LAUNCH("mtmp_attn_bwd(dkdv)");
@@ -1458,6 +1836,11 @@ extern "C" int mtmp_attn_cls_bwd(int dtype, const void* q, const void* k, const 
     return MTMP_OK;
 }
 
+#ifdef MTMP_LAB_CLOCK
+extern "C" int mtmp_dbg_read_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mtmp_dbg_stamps), (size_t)n * sizeof(long long));
+}
+#endif
 extern "C" long long mtmp_key_norms_floats(long long rows, int H) { return ((rows + 31) / 32) * H; }
 
 extern "C" int mtmp_key_norms(int dtype, const void* k, float* out, long long rows, int H, int ld, void* stream) {

@@ -2098,6 +2098,49 @@ def test_packed_attention_fp32_vs_oracle(ops, N, lens, bounded):
         assert v < 1e-4, (tag, k, v)
 
 
+@pytest.mark.parametrize("N,lens", [(1005, [1005, 6, 700, 333, 257, 256, 512, 513, 64, 65, 769, 1]),
+                                    (2005, [2005, 1290, 255, 1025])])
+def test_packed_attention_bf16_long_streams_vs_oracle(ops, N, lens):
+    """The bf16 build's long-stream backward (64 rows per wave, accumulators in the AGPR file: attention.hip `attn_bwd_dkdv64_kernel`,
+    `attn_bwd_dq64_kernel`) on a PACKED stream against the oracle: lengths on both sides of the 64-row tile, the 256-row workgroup
+    and the 512-row dispatch boundaries (waves and whole workgroups without a live row), dead rows poisoned with NaN."""
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(2000 + N)
+    B = len(lens)
+    qkv = torch.randn(B, N, 768, generator=g).to(dt).float()
+    res = torch.randn(B, N, 256, generator=g).to(dt).float()
+    w = torch.randn(B, N, 256, generator=g).to(dt).float()
+    kv = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    pack = ops.row_starts(kv, N)
+    pk = pack.cpu()
+    qd, rd, wd = (_pack_rows(t.to(DEV, dt), lens, pk) for t in (qkv, res, w))
+    kn = ops.key_norms(torch.nan_to_num(qd))
+    o, o_res, lse = ops.attn_fwd_grouped([qd], [kv], [rd], [kn], [pack])
+    dqkv = ops.attn_bwd_grouped([qd], o, [torch.nan_to_num(wd)], lse, [kv], [pack])[0]
+    o_u = _unpack_rows(o[0], lens, pk).float().cpu()
+    dq_u = _unpack_rows(dqkv, lens, pk).float().cpu()
+    # errors are taken against the largest reference entry of the whole batch: a sample of one row has dq = dk = 0 exactly, and
+    # what the bf16 kernels leave there (the rounding of O inside delta) is noise on the scale of the other samples' gradients
+    err = {"o": 0.0, "dq": 0.0, "dk": 0.0, "dv": 0.0}
+    top = {"o": 0.0, "dq": 0.0, "dk": 0.0, "dv": 0.0}
+    for b, n in enumerate(lens):
+        q_ref = qkv[b:b + 1, :n].clone().requires_grad_()
+        o_ref = O.attention_core(q_ref, None)
+        (o_ref * w[b:b + 1, :n]).sum().backward()
+        err["o"] = max(err["o"], float((o_u[b:b + 1, :n] - o_ref.detach()).abs().max()))
+        top["o"] = max(top["o"], float(o_ref.abs().max()))
+        for i, nm in enumerate(("dq", "dk", "dv")):
+            ref = q_ref.grad[..., 256 * i:256 * (i + 1)]
+            err[nm] = max(err[nm], float((dq_u[b:b + 1, :n, 256 * i:256 * (i + 1)] - ref).abs().max()))
+            top[nm] = max(top[nm], float(ref.abs().max()))
+    worst = {k: err[k] / top[k] for k in err}
+    tag = f"attn_packed[bf16,N={N},B={B}]"
+    for k, v in worst.items():
+        REPORT[f"{tag}.{k}"] = {"rel_err": v, "tol": 4e-2}
+        assert v < 4e-2, (tag, k, v)
+
+
+
 def test_packed_layer_fp32_vs_golden_and_oracle(ops):
     """One encoder layer on a PACKED stream in the fp32 parity build ("a packed layer meets the layer golden at 1e-4
     directly"): the layer, inputs and key lengths of test_encoder_layer_vs_golden, the samples' valid rows back to back, every
