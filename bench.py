@@ -293,6 +293,11 @@ def main():
     gs = getattr(model, "_mtmp_graph_step", None)
     graphed = gs is not None and gs.replays >= a.steps and not gs.disabled
     n_graphs = 0 if not graphed else max(len(e.get("graphs", [])) for e in gs.entries.values())
+    # what the captured graphs hold on to (they cannot be released on this ROCm: graph.py): taken HERE, for the timed steps' cache
+    graph_cache = gs.stats() if gs is not None else None
+    if graph_cache is not None:
+        graph_cache["device_reserved_bytes"] = int(torch.cuda.memory_reserved(dev))
+        graph_cache["device_peak_reserved_bytes"] = int(torch.cuda.max_memory_reserved(dev))
     if world > 1:
         t = torch.tensor([dt, med], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -436,6 +441,7 @@ def main():
             "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_median_host": 1e3 * med,
             "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "graphs_per_step": n_graphs,
+            "graph_cache": graph_cache,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
             "rccl_ranks": dist.get_world_size() if ddp else 1, "ranks_hold_identical_parameters": ranks_agree,

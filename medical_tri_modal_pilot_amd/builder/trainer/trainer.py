@@ -21,6 +21,15 @@ from medical_tri_modal_pilot_amd.builder.data.tie_dataset import PackedTie, Pack
 GRAPH_LEN_BUCKET = 128
 GRAPH_EVENT_BUCKET = 4096       # packed batches: the event count is rounded up to this for hipGraph replays
 
+
+def graph_len_bucket(max_len: int, limit: int) -> int:
+    """Row count a graph-replayed step pads a ragged batch to: multiples of 128 up to 1024 rows, of 256 above (graphs cannot be
+    released on this ROCm -- graph.MAX_ALIVE_GRAPHS -- so the buckets a loader can visit are kept few: TIE-len 1000 -> 8,
+    TIE-len 2000 -> 12; graph.GraphedTrainStep runs whatever exceeds its capture budget eagerly), never more than ``limit``
+    (the batch's own padded length / --TIE-len).  The extra rows lie behind kv_len like every other pad row."""
+    step = GRAPH_LEN_BUCKET if max_len <= 1024 else 2 * GRAPH_LEN_BUCKET
+    return min(limit, -(-max_len // step) * step)
+
 _TEMPLATE = {
     3: [[0., 0., 0.], [0., 0., 1.], [0., 1., 0.], [0., 1., 1.]],
     2: [[0., 0.], [0., 1.]],
@@ -213,7 +222,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         graphed = _use_graph(args, flow_type, device, optimizer, scaler)
         max_len = int(torch.max(input_lengths))
         if graphed:
-            max_len = min(int(args.TIE_len), -(-max_len // GRAPH_LEN_BUCKET) * GRAPH_LEN_BUCKET)
+            max_len = graph_len_bucket(max_len, int(args.TIE_len))
         pk = train_x.on_device(device, max_len, GRAPH_EVENT_BUCKET if graphed else 0)   # fp16 rounding inside
         data, cu_seqlens, t_pad = pk.events, pk.cu_seqlens, pk.t_pad
     elif args.vslt_type == "carryforward":
@@ -224,7 +233,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         # pad rows feed nothing -- instead of zero-length launches)
         max_len = max(1, int(torch.max(input_lengths)))
         if _use_graph(args, flow_type, device, optimizer, scaler):
-            max_len = min(train_x.shape[1], -(-max_len // GRAPH_LEN_BUCKET) * GRAPH_LEN_BUCKET)
+            max_len = graph_len_bucket(max_len, train_x.shape[1])
         data = fp16_round(train_x[:, :max_len, :], "data")                    # 2_train.py:164
     if "rmse" in args.auxiliary_loss_type:
         final_target = train_y[0].float().to(device, non_blocking=True)
@@ -264,7 +273,7 @@ def missing_trainer(args, iteration, train_x, static_x, input_lengths, train_y, 
         from medical_tri_modal_pilot_amd.graph import GraphedTrainStep
         gs = getattr(model, "_mtmp_graph_step", None)
         if gs is None or gs.device != data.device:
-            gs = model._mtmp_graph_step = GraphedTrainStep(data.device,
+            gs = model._mtmp_graph_step = GraphedTrainStep(data.device, max_graphs=int(getattr(args, "hip_graph_max", 12)),
                                                            fallback=bool(int(getattr(args, "hip_graph_fallback", 0))))
         # Data-parallel steps are captured as a few graphs cut at layer boundaries: the all-reduce of the gradient
         # buckets a stage completed starts right behind its replay and overlaps the next stage (ddp.py, staged mode).

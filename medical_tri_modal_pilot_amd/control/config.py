@@ -129,6 +129,9 @@ _BUILD_FLAGS = [
     (("--hip-graph-fallback",), dict(type=int, default=0, choices=[0, 1],
                                      help="1: a failed hipGraph capture falls back to eager launches with a warning "
                                           "(default: it raises -- the eager step is host-bound)")),
+    (("--hip-graph-max",), dict(type=int, default=12,
+                                help="input shapes (length buckets) a trainer captures at most; further shapes run as eager "
+                                     "launches (captured graphs cannot be released on ROCm 7.2: graph.py)")),
     (("--graph-stages",), dict(type=int, default=0,
                                help="number of hipGraphs the captured step is cut into at fusion-layer boundaries "
                                     "(k > 0: k even groups of layers; 0 = auto: one graph, under --ddp 1 two, cut behind the first fusion layer, so "

@@ -17,8 +17,8 @@
 // The score tile is computed transposed (S^T = K Q^T) so that a query is a lane:
 // row max / row sum are in-register, the online-softmax rescale of O^T is a
 // per-lane multiply, and P^T is consumed by the P.V MFMA directly from the
-// accumulator registers (common.cuh: acc -> Frag).
-#include "common.cuh"
+// accumulator registers (common.hip.h: acc -> Frag).
+#include "common.hip.h"
 #include <math.h>
 #include <type_traits>
 

@@ -176,8 +176,13 @@ template <> MTMP_DEV f32x4 load4<bf16>(const bf16* p) {
 // stream-input backward: a few waves per CU, nothing to hide the chain behind) spent most of their time there.  Here a 16-lane
 // row is reduced by four rotate-within-row DPP operands fused into the adds (row_ror:8/4/2/1: every lane of the row ends with
 // the row's result), and the four rows meet through v_readlane: ~12 plain vector instructions, no LDS.
+// PRECONDITION of dpp_row / wave_sum / wave_max: the whole wave is active (EXEC all ones).  All call sites are wave-uniform.
+// (`old` = the lane's own value: a lane without a source lane would keep x -- neutral for max, but it would double-count in a
+// sum, and the v_readlane of lanes 0 / 16 / 32 / 48 below reads whatever an inactive lane's register holds: do not call these
+// under divergence.)
 template <int CTRL> MTMP_DEV float dpp_row(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+    const int xi = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xf, 0xf, false));
 }
 MTMP_DEV float lane_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 MTMP_DEV float wave_sum(float v) {

@@ -4,7 +4,7 @@
 // accesses, 1 KiB / 512 B contiguous per wave instruction), row statistics are wave reductions,
 // parameter gradients are accumulated in registers over a grid-stride loop and combined through
 // a [blocks][cols] partial slab + a second pass (bitwise reproducible, no float atomics in HBM).
-#include "common.cuh"
+#include "common.hip.h"
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
 // two-level tree: [rows][cols] -> [G][cols] (in ws_tail) -> out[cols].  G is chosen so that the first level has >= 512
 // workgroups (a 2048 x 512 slab with 16 groups ran on 128 workgroups, 32 dependent loads per thread: 12-15 us).
 }  // namespace
-// (also used by the fused dX + LayerNorm-backward GEMM of gemm.hip; declared in common.cuh)
+// (also used by the fused dX + LayerNorm-backward GEMM of gemm.hip; declared in common.hip.h)
 void launch_slab_reduce(const float* slab, int rows, int cols, float* ws_tail, float* out, hipStream_t st) {
     const int gx = (cols + 63) / 64;
     if (rows <= 64) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* z, int ldz, const 
 // Stream input of the fusion encoder (K4, mbt_encoder.py:697-729 + the concatenation of :745):
 //     z[b] = [ bottleneck tokens (nb rows) | dropout(LN(CLS) + PE[0]) | dropout(LN(x[b,t]) + PE[t+1]) ... ]
 // nn.LayerNorm (biased variance, eps inside the root) in fp32 on the stream's compute-dtype embeddings, the
-// sinusoid rows only for the stream that uses them, dropout by the counter hash of common.cuh (regenerated in
+// sinusoid rows only for the stream that uses them, dropout by the counter hash of common.hip.h (regenerated in
 // the backward), output straight into the [B, nb+1+N, 256] buffer the fusion stack reads -- one launch instead
 // of cat + layer_norm + add + dropout + cast + two copies per stream.  One wave per row.
 constexpr int NB_MAX = 4;
@@ -871,7 +871,7 @@ extern "C" int mtmp_stream_lengths(const long long* len_v, const long long* len_
 // the rows in use.  That last word is what the row-panel / weight-gradient kernels take as `rows_live`; the buffers and
 // the launch grids keep the padded size B * n_max, so a captured hipGraph replays whatever the lengths are.
 // out[B + 1 .. 2 B + 1) = the order in which the attention kernels walk the samples: their grids are cut into eight contiguous
-// chunks, one per XCD (common.cuh xcd_remap), and the cost of a sample grows with the square of its length -- in batch order one
+// chunks, one per XCD (common.hip.h xcd_remap), and the cost of a sample grows with the square of its length -- in batch order one
 // XCD gets the eight longest samples of a ragged batch and the launch waits for it.  The samples are ranked by length and
 // dealt round-robin: slot i of XCD x (x = 0..7) holds the sample of rank 8 i + x, so every XCD gets the same mix and starts
 // with its longest samples.

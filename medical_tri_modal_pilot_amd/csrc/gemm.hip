@@ -16,11 +16,11 @@
 //      config 2) while the output is tiny -- split over M into partial slabs + one reduce pass.
 //
 // "NT" operands are contiguous along the contraction index, which is exactly the MFMA fragment
-// shape (common.cuh).  The product is computed as W-rows x token-columns so that a TOKEN is a
+// shape (common.hip.h).  The product is computed as W-rows x token-columns so that a TOKEN is a
 // lane: each lane then owns 4 consecutive output features per accumulator group and stores
 // 8/16-byte pieces of its own row.  Weights arrive in the compute dtype (bf16 shadow copy or
 // fp32 master), gamma/beta/bias always fp32.
-#include "common.cuh"
+#include "common.hip.h"
 #include <type_traits>
 template <int N> using template_int = std::integral_constant<int, N>;
 
@@ -34,7 +34,7 @@ template <typename T> struct GemmArgs {
     int M, N, K, lda, ldy, ldr;
     float eps;
     float drop_p;        // nn.Dropout probability applied after act (0 = off), module.py:77-79
-    unsigned seed;       // per-call seed of the counter-based mask (common.cuh: dropout_keep4)
+    unsigned seed;       // per-call seed of the counter-based mask (common.hip.h: dropout_keep4)
     const unsigned* seed_dev;   // optional device word XOR-ed into seed (advanced by the host/graph every step,
                                 // so a replayed hipGraph does not repeat its masks)
     const T* gate;       // optional [M,N]: y = gate > 0 ? y * gate_scale : 0  (ReLU/dropout backward)
@@ -44,7 +44,7 @@ template <typename T> struct GemmArgs {
     int rows_per_scale;
     unsigned short* signs = nullptr;   // row-panel kernels (bf16): 1 bit per output, "y > 0" -- written by the forward, read as the gate
     float* knorm = nullptr;            // Q/K/V projection (N = 768): [ceil(M / 32)][4] max ||k_h|| per 32-row block (attention.hip, AttnArgs::knorm)
-    const int* m_live = nullptr;       // packed stream: device word holding the rows in use (<= M); common.cuh live_rows
+    const int* m_live = nullptr;       // packed stream: device word holding the rows in use (<= M); common.hip.h live_rows
 };
 
 // 128 x 64 tile of a row-major matrix -> registers (4 x 16 B per thread).  The loads are
@@ -431,7 +431,7 @@ template <bool RELU, bool DROP, bool GATE, bool SIGNS, bool KNORM = false>
 __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf16>> grp) {
     using T = bf16;
     constexpr int K = 256;
-    const int seg = grp_find(grp, (int)blockIdx.x);          // row blocks of up to three token streams in one grid (common.cuh)
+    const int seg = grp_find(grp, (int)blockIdx.x);          // row blocks of up to three token streams in one grid (common.hip.h)
     const GemmArgs<bf16>& p = grp.seg[seg];
     const int bx = (int)blockIdx.x - grp.first[seg];
     using P = PanelDma;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_dma_kernel(Grouped<GemmArgs<bf
     const int tok = lane / P::LPT, ch = lane % P::LPT;           // store phase: this lane's token (+ 16 per pass), 16 B chunk
     // reader: row 32g + r, k-step c -> chunk (2c + half) ^ (r & 15); the XOR only touches chunk bits 0-3, so c >> 3 and g are
     // immediate offsets on eight per-lane addresses
-    // (rows through swz23, common.cuh: accumulator registers 8s..8s+7 of a lane then hold 8 CONSECUTIVE features, 16s + 8 half + j
+    // (rows through swz23, common.hip.h: accumulator registers 8s..8s+7 of a lane then hold 8 CONSECUTIVE features, 16s + 8 half + j
     //  -- 16-byte pieces for the staging tile, and exactly the k-step-s operand fragment of a product that consumes this one)
     const char* rd[8];
     const int rs = swz23(r);
@@ -1541,7 +1541,7 @@ template <typename T> struct LnBwdGemmArgs {
     const T* dy; const T* wt; const T* z; const float* stats; const float* gamma; const T* d_res; T* dz; float* slab;
     int M, K, ldy, ldz, ldr;
     float eps;
-    const int* m_live = nullptr;       // packed stream: rows in use (common.cuh live_rows)
+    const int* m_live = nullptr;       // packed stream: rows in use (common.hip.h live_rows)
 };
 
 template <typename T>
@@ -1998,7 +1998,7 @@ extern "C" int mtmp_gemm_tn_live(int dtype, const void* dy, const void* x, float
 namespace {
 // g_out[i] = keep(seed, i) ? g_in[i] / (1-p) : 0 -- backward of the epilogue dropout (same mask).
 // ------------------------------------------------------------------------------------------------------------------------
-// Grouped forms (bf16): the same operation of up to three token streams of one fusion layer in ONE launch (common.cuh, Grouped).
+// Grouped forms (bf16): the same operation of up to three token streams of one fusion layer in ONE launch (common.hip.h, Grouped).
 // All pointer / int arrays are HOST arrays of n entries; scalars are common to the streams.  rows_live (may be NULL, entries may be
 // NULL): per stream a DEVICE word with the rows in use this step (<= M[i]) -- the packed vital-sign stream, whose buffers and
 // grids are sized for the padded maximum M[i] (mtmp_row_starts); rows past it are neither read nor written.  Same kernels, same results as n

@@ -9,7 +9,7 @@
 //   backward: head_fc_bwd (feature-parallel: BatchNorm / Linear weight gradients, dh) -> head_x_bwd (row-parallel:
 //             dx = dh W1, both LayerNorm backwards, per-row partials of the row-summed gradients) -> slab reduce
 // fp32 throughout (the reference runs the head in fp32 under autocast too).  Deterministic: no float atomics.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

@@ -8,7 +8,7 @@
 // channels of a patch sit in that lane pair's accumulators: the LayerNorm statistics are an
 // in-register sum plus one cross-half add.  Memory-bound (reads the image once, writes the
 // feature map once).
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

@@ -11,7 +11,7 @@
 //      the query is a lane (softmax in registers), P feeds P.V from the accumulators.
 //      The additive table [4 window types][heads][64][64] (bias + mask, -30000 on pad keys) is
 //      constant per block and precomputed once by the host.
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* 
 //     only things staged in LDS (two buffers, one barrier per panel, next panel prefetched into registers);
 //   * H^T = W1_j xn^T comes out of the MFMA with hidden units on the accumulator ROWS; W1's rows are read through
 //     swz23() so that, after bias + GELU, accumulator registers 8s..8s+7 ARE the k-step-s operand fragment of the
-//     second product (common.cuh, "acc -> Frag") -- no LDS round trip between the two GEMMs;
+//     second product (common.hip.h, "acc -> Frag") -- no LDS round trip between the two GEMMs;
 //   * out^T += W2[:, panel] H accumulates over the panels; the epilogue adds b2, rounds, applies the per-image
 //     StochasticDepth factor and the residual exactly like mtmp_gemm_nt's epilogue, through a wave-private LDS tile so
 //     that HBM sees 64-byte row pieces.
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256, 3) void swin_ln_linear_kernel(const bf16* x, c
 //     into LDS, bf16 -- the B operand of every head's projections;
 //   * Q^T, K^T = W_{q,k}[head] xn^T come out of the MFMA with the head dims on the accumulator ROWS and tokens on the lanes,
 //     V = xn W_v[head]^T with tokens on the rows and head dims on the lanes: accumulator registers 8s..8s+7 of each ARE the
-//     k-step-s operand fragments of S^T = K Q^T and O^T = V^T P^T (common.cuh, "acc -> Frag": both operands of a product
+//     k-step-s operand fragments of S^T = K Q^T and O^T = V^T P^T (common.hip.h, "acc -> Frag": both operands of a product
 //     come from accumulators with the same row order, so the contraction index pairs up) -- q, k, v never leave registers;
 //   * the additive table (relative-position bias + shift mask, PAD_LOGIT on the 15 pad keys) is stored by the host with its
 //     key columns in accumulator-register order, so a lane reads its 16 keys of a block as two 16-byte loads;

@@ -35,6 +35,11 @@ import torch.distributed as dist
 from .optim import FlatParams
 
 
+class PlanMismatch(RuntimeError):
+    """The ranks of a staged step would issue different collectives (or this rank deviates from the agreed plan): never
+    swallowed by GraphedTrainStep's capture fallback -- continuing would pair all-reduces of different ranges."""
+
+
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
     """Initial replica sync: parameters and buffers (BatchNorm running stats included) from rank `src`."""
     with torch.no_grad():
@@ -67,6 +72,8 @@ class GradReducer:
         self.works = []
         self._sync = True
         self.last_issued: List[tuple] = []
+        # the collectives of a staged step as ALL ranks agreed on them: set by the first staged step's wait() (see _check_plan)
+        self.verified_plan = None
         self._reset()
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(i)) for i, p in enumerate(flat.params)]
         flat.ready_cb = self._ready          # gradients written straight into the flat buffer (ops.GradSink)
@@ -77,6 +84,7 @@ class GradReducer:
         self.launched = [False] * len(self.buckets)
         self.ready_log: List[int] = []           # buckets in the order they became complete this step
         self.issued: List[tuple] = []            # [lo, hi) of every all-reduce issued this step, in order
+        self.launch_log: List[List[int]] = []    # staged mode: the bucket ids of every launch() of this step, in order
         self.seen = {}                           # parameters that reported their gradient this step (-> who, if debug)
 
     def begin_step(self):
@@ -165,25 +173,43 @@ class GradReducer:
         return out
 
     def plan(self, ready_per_stage) -> List[List[List[int]]]:
-        """The collectives a staged step issues: per stage the merged [lo, hi) ranges of the buckets it completed, in issue order;
-        whatever no stage completed goes out last, from wait()."""
+        """The collectives a staged step issues: per stage that completed buckets the merged [lo, hi) ranges of those buckets, in
+        issue order; whatever no stage completed goes out last, from wait().  (Stages without a finished bucket issue nothing
+        and do not appear: the plan of a captured step, of its replays and of an eager staged step are then the same list.)"""
         done = {b for ids in ready_per_stage for b in ids}
         rest = [b for b in range(len(self.buckets)) if b not in done]
-        return [self._ranges(ids) for ids in ready_per_stage] + [self._ranges(rest)]
+        return [self._ranges(ids) for ids in ready_per_stage if ids] + [self._ranges(rest)]
+
+    def _check_plan(self, mine, where: str):
+        """Every rank must issue the same collectives over the same ranges in the same order -- a rank whose stages completed
+        other bucket sets would pair its all-reduces with the wrong ones of its peers: wrong sums or a hang.  The plan is a
+        function of the model and of the stage cut, not of the batch shape, so it is agreed on ONCE, at a point every rank
+        reaches together: the wait() of the first staged step (an eager warm-up step logs its stages exactly like a replay).
+        That is the only collective of the check.  Everything later -- every further staged step, every capture, whenever a
+        rank happens to capture (ragged batches give the ranks different shape signatures, so they capture on different
+        steps: ADVICE r4) -- is compared with the agreed plan LOCALLY."""
+        if self.verified_plan is not None:
+            if mine != self.verified_plan:
+                raise PlanMismatch(f"GradReducer ({where}): this step's collectives {mine} differ from the plan the ranks agreed on "
+                                   f"{self.verified_plan}")
+            return mine
+        if self.world > 1:
+            plans = [None] * self.world
+            dist.all_gather_object(plans, mine, group=self.group)
+            for r, other in enumerate(plans):
+                if other != mine:
+                    raise PlanMismatch(f"GradReducer ({where}): rank {r} plans other collectives than this rank ({other} vs {mine}): "
+                                       "the staged steps of the ranks differ")
+        self.verified_plan = mine
+        return mine
 
     def assert_same_plan(self, ready_per_stage):
-        """Once per capture: every rank must issue the same collectives over the same ranges in the same order -- a rank whose
-        stages completed other bucket sets (another model configuration, a step that fell back to eager hooks) would pair its
-        all-reduces with the wrong ones of its peers: wrong sums or a hang.  One small object all-gather; no-op with one rank."""
+        """Called by GraphedTrainStep right after a capture with the buckets each captured stage completed: NO collective here
+        (capture timing is per rank) -- the captured plan must equal the plan the ranks agreed on in the first staged step; a
+        capture in front of that step (warmup = 0) is checked by that step's wait()."""
         mine = self.plan(ready_per_stage)
-        if self.world <= 1:
-            return mine
-        plans = [None] * self.world
-        dist.all_gather_object(plans, mine, group=self.group)
-        for r, other in enumerate(plans):
-            if other != mine:
-                raise RuntimeError(f"GradReducer: rank {r} plans other collectives than this rank ({other} vs {mine}): the staged "
-                                   "steps of the ranks differ")
+        if self.verified_plan is not None:
+            self._check_plan(mine, "capture")
         return mine
 
     def _launch(self, b: int, after: Optional[Iterable["torch.cuda.Stream"]] = None):
@@ -208,6 +234,8 @@ class GradReducer:
             return
         for b in ids:
             self.launched[b] = True
+        if self.staged:
+            self.launch_log.append(list(ids))
         behind = None
         if self.cuda and after and len(after) == 1:
             behind = after[0]        # issued "from" the replay stream itself: one cross-stream hop less in front of the optimizer
@@ -220,7 +248,11 @@ class GradReducer:
     def wait(self):
         """Launch whatever has not been launched (parameters without a gradient this step keep their
         zeroed slice), then make the compute stream wait for every bucket."""
+        if self.staged and self._sync:
+            self._check_plan(self.plan(self.launch_log), "step")      # before the last launch: a mismatch must not hang in it
+        staged, self.staged = self.staged, False                       # (the remainder is not a stage of its own in the log)
         self.launch([b for b in range(len(self.buckets)) if not self.launched[b]])
+        self.staged = staged
         for w in self.works:
             w.wait()
         if self.cuda:

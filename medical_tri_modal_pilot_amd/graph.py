@@ -35,6 +35,7 @@ from typing import Callable, Dict, List, Union
 import torch
 
 from . import ops
+from .ddp import PlanMismatch
 
 _GOLDEN = 0x9E3779B1          # odd increment of the step word
 # Captured graphs are NEVER destroyed while the process lives.  On ROCm 7.2 / torch 2.10, hipGraphExecDestroy of one captured step
@@ -44,6 +45,13 @@ _GOLDEN = 0x9E3779B1          # odd increment of the step word
 # garbage at a quiet point between the tests did not help, holding on to the graphs did).  A training run captures a handful of
 # graphs; their memory stays with the step's private pool anyway.
 _ALIVE = []
+# Because graphs cannot be released, captures are BUDGETED (ADVICE r4 / VERDICT r4): a GraphedTrainStep never evicts a captured
+# signature (an evicted one would be captured again on its next visit, leaking a step's worth of pool memory per round trip) --
+# past ``max_graphs`` signatures, and past MAX_ALIVE_GRAPHS captured graphs in the whole process (invalidate() parks the old
+# ones), further signatures run eagerly (host-bound, correct).  All captures of one GraphedTrainStep share ONE memory pool: the
+# blocks a capture frees at its end are reused by the next capture, so N shape buckets cost one step's activations plus N sets
+# of static inputs / outputs, not N steps' worth (capture_log records the device memory reserved after every capture).
+MAX_ALIVE_GRAPHS = 64
 
 
 class GraphedTrainStep:
@@ -63,6 +71,9 @@ class GraphedTrainStep:
         self.pool = None
         self.captures = 0
         self.replays = 0
+        self.eager_over_budget = 0           # steps of signatures past the capture budget (run eagerly)
+        self.capture_log: List[dict] = []    # per capture: signature, device memory reserved before / after, graphs alive
+        self._warned_budget = False
         # early loss hand-over (publish_loss / wait_loss): [loss bits, sequence number] on the device and in pinned host memory
         self.loss_dev = torch.zeros(2, dtype=torch.int32, device=device)
         self.loss_host = torch.zeros(2, dtype=torch.int32).pin_memory()
@@ -119,8 +130,22 @@ class GraphedTrainStep:
         return tuple((k, tuple(v.shape), v.dtype) for k, v in inputs.items())
 
     def invalidate(self):
-        """Drop every captured graph (call after load_state_dict / any change of module structure or flags)."""
+        """Forget every captured graph (call after load_state_dict / any change of module structure or flags).  The graphs
+        themselves stay parked in _ALIVE (see above) and keep counting against MAX_ALIVE_GRAPHS."""
         self.entries.clear()
+
+    def stats(self) -> dict:
+        """What bench.py reports: captures, replays, eager steps past the budget, device memory reserved after the last capture."""
+        last = self.capture_log[-1] if self.capture_log else {}
+        return {"captures": self.captures, "replays": self.replays, "eager_over_budget": self.eager_over_budget,
+                "signatures_captured": sum(1 for e in self.entries.values() if "graphs" in e),
+                "graphs_alive_in_process": len(_ALIVE), "max_graphs": self.max_graphs,
+                "reserved_bytes_after_last_capture": last.get("reserved_after"),
+                "reserved_bytes_grown_by_captures": sum(c["reserved_after"] - c["reserved_before"] for c in self.capture_log)}
+
+    def _budget_left(self, n_stages: int) -> bool:
+        captured = sum(1 for e in self.entries.values() if "graphs" in e)
+        return captured < self.max_graphs and len(_ALIVE) + n_stages <= MAX_ALIVE_GRAPHS
 
     @staticmethod
     def _stages(fn) -> List[Callable]:
@@ -130,6 +155,7 @@ class GraphedTrainStep:
 
     def _capture(self, ent: dict, inputs: Dict[str, torch.Tensor], stages: List[Callable], reducer):
         static = {k: v.detach().clone() for k, v in inputs.items()}
+        reserved_before = torch.cuda.memory_reserved(self.device)
         self._captured_publish = False
         ops.bump_fused_epoch()      # per-layer derived weights (W2^T, casts) must be re-made INSIDE the graph
         torch.cuda.synchronize(self.device)
@@ -148,9 +174,11 @@ class GraphedTrainStep:
             # which gradient buckets this stage completed (the hooks ran while its Python was captured)
             ready.append(reducer.take_ready() if reducer is not None else [])
         if reducer is not None:
-            reducer.assert_same_plan(ready)      # every rank must issue the same collectives in the same order (else: a hang)
+            reducer.assert_same_plan(ready)      # a LOCAL comparison with the plan the ranks agreed on (ddp._check_plan): no collective here
         ent.update(graphs=graphs, ready=ready, static=static, loss=carry["loss"], fresh=True, publishes=self._captured_publish)
         self.captures += 1
+        self.capture_log.append({"signature": ent.get("key"), "stages": len(stages), "reserved_before": reserved_before,
+                                 "reserved_after": torch.cuda.memory_reserved(self.device), "graphs_alive": len(_ALIVE)})
 
     def _eager_on_side_stream(self, inputs, stages, reducer):
         cur = torch.cuda.current_stream(self.device)
@@ -187,16 +215,28 @@ class GraphedTrainStep:
         key = self.signature(inputs) + (len(stages),)
         ent = self.entries.get(key)
         if ent is None:
-            ent = self.entries[key] = {"seen": 0}
-            while len(self.entries) > self.max_graphs:
-                self.entries.popitem(last=False)
-        self.entries.move_to_end(key)
+            ent = self.entries[key] = {"seen": 0, "key": key}
+            # un-captured signatures are only counters: forget the oldest of them, never a captured one
+            idle = [k for k, e in self.entries.items() if "graphs" not in e]
+            while len(idle) > 4 * self.max_graphs:
+                self.entries.pop(idle.pop(0))
         if "graphs" not in ent:
             if ent["seen"] < self.warmup:
                 ent["seen"] += 1
                 return self._eager_on_side_stream(rounded(), stages, reducer)
+            if not self._budget_left(len(stages)):
+                # the capture budget is spent (graphs cannot be released on this ROCm): this signature stays eager
+                self.eager_over_budget += 1
+                if not self._warned_budget:
+                    self._warned_budget = True
+                    warnings.warn(f"hipGraph capture budget spent ({self.max_graphs} signatures per trainer, {MAX_ALIVE_GRAPHS} "
+                                  "graphs per process): further input shapes run as eager launches (host-bound); coarser "
+                                  "length buckets (trainer.graph_len_bucket) keep a ragged loader inside the budget")
+                return self._eager_on_side_stream(rounded(), stages, reducer)
             try:
                 self._capture(ent, rounded(), stages, reducer)
+            except PlanMismatch:
+                raise                                   # never a fallback case: the ranks would pair different all-reduces
             except Exception as e:                      # noqa: BLE001
                 self.entries.clear()
                 torch.cuda.synchronize(self.device)

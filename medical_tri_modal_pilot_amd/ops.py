@@ -410,7 +410,7 @@ def image_slots(pattern, present_below: int, hw0: int):
 # A stream is PACKED when its samples' valid rows (bottleneck prefix + CLS + events = kv_len[b]) sit back to back in the
 # [B * N_max, 256] buffers instead of N_max rows apart: `pack` = row_starts(kv_len, N_max), int32[2 B + 1] on the device --
 # pack[b] = sample b's first row, pack[B] = the rows in use, pack[B + 1:] = the attention kernels' sample order.  Buffers, launch grids and the hipGraph keep the padded size; the
-# kernels read the live row count from pack[B] (csrc/common.cuh live_rows) and the attention kernels address samples through
+# kernels read the live row count from pack[B] (csrc/common.hip.h live_rows) and the attention kernels address samples through
 # pack[b].  Nothing behind the live rows is read or written.
 def row_starts(kv_len, n_max: int):
     """kv_len int32[B] (device) -> int32[2 B + 1]: exclusive prefix sums of min(kv_len, n_max), their total, and the
@@ -931,7 +931,11 @@ class BceLogitsMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d,) = ctx.saved_tensors
-        if g is _UNIT_GRAD.get((g.device.type, g.device.index)):      # loss.backward() through unit_grad(): d itself, no launch
+        # loss.backward() through unit_grad(): d itself, no launch.  The saved tensor is handed out as the gradient, so it is
+        # handed out ONCE: a second backward over the same graph (retain_graph) gets a copy -- a consumer that accumulates in
+        # place into its incoming gradient must not reach into what is saved here
+        if g is _UNIT_GRAD.get((g.device.type, g.device.index, g.dtype)) and not getattr(ctx, "handed_out", False):
+            ctx.handed_out = True
             return d.view(ctx.shape), None
         return (d * g).view(ctx.shape), None
 
@@ -943,9 +947,9 @@ def unit_grad(loss: torch.Tensor) -> torch.Tensor:
     """The constant 1.0 a scalar loss is differentiated with, made once per device: `torch.autograd.backward(loss, unit_grad(loss))`
     instead of `loss.backward()` spares the step the fill of a fresh ones tensor, and BceLogitsMean.backward -- which recognises
     this very tensor -- the multiplication by it (two small launches between the forward and the backward, where nothing else runs)."""
-    key = (loss.device.type, loss.device.index)
+    key = (loss.device.type, loss.device.index, loss.dtype)      # per dtype too: a cached tensor is never dropped (a captured graph may read it)
     one = _UNIT_GRAD.get(key)
-    if one is None or one.dtype != loss.dtype:
+    if one is None:
         one = _UNIT_GRAD[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
     return one
 
@@ -1233,7 +1237,7 @@ def cls_layer_backward(saved, d_cls, sink=None, late=None):
     return dz.view(B, N, D), grads
 
 
-# One launch per layer step over the active streams (bf16): csrc/common.cuh, Grouped.  The three streams of a fusion layer are
+# One launch per layer step over the active streams (bf16): csrc/common.hip.h, Grouped.  The three streams of a fusion layer are
 # 1005 / 54 / 133 tokens long; as three launches on three HIP streams the short ones held whole-CU workgroup slots beside the
 # long one's kernels (round 2: every vital-sign-stream kernel 15-40 % slower in the step than alone, ~1.2 ms per step, ~200
 # launches).  The parity (fp32) build keeps one launch per stream.  (switch: tuning.GROUPED_LAUNCHES)

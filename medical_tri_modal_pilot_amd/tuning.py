@@ -15,7 +15,7 @@ DEFER_REDUCTIONS = True
 # ops.FusionStackFn.backward: issue a layer's reduction launch one layer LATE (behind the next bottleneck exchange).  Worth
 # 0.05 ms while every layer ran three dense streams; with the CLS-only last layer the in-place order is faster (8.00 vs 8.06).
 LATE_REDUCTIONS = False
-# One launch per kernel over the streams of a fusion layer (csrc/common.cuh, Grouped): three launches on three HIP streams held
+# One launch per kernel over the streams of a fusion layer (csrc/common.hip.h, Grouped): three launches on three HIP streams held
 # whole-CU workgroup slots beside the long stream's kernels (round 2: +1.2 ms / step).  bf16 build only.
 GROUPED_LAUNCHES = True
 # How a layer's streams are cut into launches: "small" = the vital-sign stream alone on the caller's stream, image + text together

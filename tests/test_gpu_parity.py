@@ -1833,7 +1833,9 @@ def test_ddp_reducer_single_rank_rccl_matches_plain_run(ops):
     gradients directly, the modality side streams joined before each bucket).  With one rank the all-reduce is the
     identity, so losses and parameters must equal the plain run bit for bit -- eager (overlapped buckets) and graph."""
     if _in_child_process("test_ddp_reducer_single_rank_rccl_matches_plain_run", timeout=360):
-        REPORT["ddp_single_rank_vs_plain[fp32]"] = {"rel_err": 0.0, "tol": 0.0}
+        # the comparison ran (and passed: the child's exit code) in the child session, whose own report is not merged: say so
+        # instead of writing a measured-looking 0.0 here (ADVICE r4)
+        REPORT["ddp_single_rank_vs_plain[fp32]"] = {"ran_in_child": True, "passed": True, "tol": 0.0}
         return
     import torch.distributed as dist
     from medical_tri_modal_pilot_amd.ddp import GradReducer
@@ -1939,6 +1941,38 @@ def test_graph_length_buckets_match_trimmed_eager(ops):
     check("graph_bucketed_vs_trimmed[fp32].params", pg, pe, 5e-3)
 
 
+def test_graph_cache_is_bounded_and_length_buckets_share_one_pool(ops):
+    """VERDICT r4 item 5 / ADVICE r4: captured graphs cannot be released on this ROCm (graph.py), so (i) a trainer captures at most
+    --hip-graph-max input shapes and runs further shapes EAGERLY (never evicts and re-captures), (ii) all its captures share one
+    memory pool -- N length buckets cost about one step's activations, not N -- and (iii) the growth is reported.  Twelve
+    layers (configs[4]'s depth), TIE-len 2000: the loader's batch maximum wanders over all twelve length buckets, largest first."""
+    from medical_tri_modal_pilot_amd.builder.trainer.trainer import graph_len_bucket
+    T, B, L, CAP = 2000, 4, 12, 5
+    maxima = [2000, 1700, 1500, 1200, 1000, 880, 760, 630, 500, 380, 250, 100]
+    buckets = [graph_len_bucket(m, T) for m in maxima]
+    assert buckets == [2000, 1792, 1536, 1280, 1024, 896, 768, 640, 512, 384, 256, 128] and len(set(buckets)) == 12
+    order = [m for m in maxima for _ in range(2)] + maxima          # every shape twice (eager warm-up, capture), then once more
+    lens = [[m, max(3, m // 2), max(3, m // 3), 3] for m in order]
+    torch.cuda.reset_peak_memory_stats()
+    lg, _, gs = _loop(1, 0.0, "bf16", len(lens), lens, L=L, B=B, T=T, hip_graph_max=CAP)
+    st = gs.stats()
+    assert gs.captures == CAP and st["signatures_captured"] == CAP and not gs.disabled, st
+    assert gs.replays == CAP                                           # the third visit of the five captured shapes
+    assert st["eager_over_budget"] == 2 * (12 - CAP), st               # second and third visit of the seven others
+    assert all(math.isfinite(v) for v in lg)
+    le, _, _ = _loop(0, 0.0, "bf16", len(lens), lens, L=L, B=B, T=T)
+    err = max(abs(a - b) for a, b in zip(le, lg))
+    REPORT["graph_cache_budget[bf16,L12,T2000].loss_vs_eager"] = {"rel_err": err, "tol": 5e-3}
+    assert err < 5e-3, (le[:6], lg[:6])
+    grow = [c["reserved_after"] - c["reserved_before"] for c in gs.capture_log]
+    first, total = grow[0], sum(grow)
+    REPORT["graph_cache_budget[bf16,L12,T2000].reserved_growth_bytes"] = {"rel_err": float(total), "tol": float(2 * max(first, 1))}
+    REPORT["graph_cache_budget[bf16,L12,T2000].peak_reserved_bytes"] = {"rel_err": float(torch.cuda.max_memory_reserved()), "tol": 8.0 * 2 ** 30}
+    # one pool: the four later (smaller) shapes reuse the blocks of the first capture -- under twice its growth in all
+    assert total <= 2 * first + (64 << 20), grow
+    assert torch.cuda.max_memory_reserved() < 8 * 2 ** 30
+
+
 def test_graph_replay_draws_fresh_dropout_masks(ops):
     """Scalar seeds are frozen in a captured graph; the device step word must still change the masks per replay."""
     from medical_tri_modal_pilot_amd.graph import GraphedTrainStep
@@ -1983,7 +2017,18 @@ def test_evaluator_metrics_on_gpu(ops):
     auc, apr, f1 = ev.performance_metric()
     yy, pp = torch.cat(ys).numpy(), torch.cat(ps).numpy()
     assert auc == round(roc_auc_score(yy, pp), 4) and apr == round(average_precision_score(yy, pp), 4)
-    assert 0.0 <= f1 <= 1.0
+    # F1 (the exact value, not a range): the reference's threshold loop binarises its predictions in place in the
+    # first pass (metrics.py:76-83), so what it reports is F1 at threshold 0.01 -- brute force here; the sweep that loop was
+    # meant to be (best_f1_over_thresholds) against its own brute force as well
+    from medical_tri_modal_pilot_amd.builder.utils.metrics import best_f1_over_thresholds
+
+    def f1_at(th):
+        pred = pp >= th
+        tp, fp, fn = float((pred & (yy == 1)).sum()), float((pred & (yy == 0)).sum()), float((~pred & (yy == 1)).sum())
+        return 2 * tp / (2 * tp + fp + fn) if tp > 0 else 0.0
+    assert f1 == round(f1_at(0.01), 4), (f1, f1_at(0.01))
+    sweep = float(best_f1_over_thresholds(torch.from_numpy(pp).to(DEV), torch.from_numpy(yy).to(DEV)))
+    assert abs(sweep - max(f1_at(k / 100.0) for k in range(1, 100))) < 1e-6
 
 
 def test_resume_from_reference_optimizer_state(ops):

@@ -321,6 +321,7 @@ STAGED_WORKER = r"""
 import os, sys, types, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["MTMP_ROOT"])
 from medical_tri_modal_pilot_amd.optim import FlatParams
+from medical_tri_modal_pilot_amd import ddp as T_ddp
 from medical_tri_modal_pilot_amd.ddp import GradReducer, broadcast_module_state
 from medical_tri_modal_pilot_amd.builder.trainer import trainer as T
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -444,18 +445,62 @@ for step in range(2):                                                # the secon
     # the collectives went out in the order of the plan: per stage the merged ranges of its buckets
     plan = red.plan(per_stage)
     assert red.last_issued == [tuple(r) for st in plan for r in st], (red.last_issued, plan)
-# every rank must plan the same collectives in the same order (GraphedTrainStep checks this once per capture) ...
-plan = red.assert_same_plan(per_stage)
-assert sum(len(st) for st in plan) >= 3, plan
-# ... and a rank whose stages completed other bucket sets is caught on every rank instead of hanging in the first all-reduce
+# The plan was agreed on by all ranks in the first staged step's wait() (ONE collective, at a point every rank reaches together) ...
+assert red.verified_plan == red.plan(per_stage), (red.verified_plan, per_stage)
+assert sum(len(st) for st in red.verified_plan) >= 3, red.verified_plan
+# ... so a capture is compared with it LOCALLY: ranks whose ragged batches give them different shape signatures capture on
+# different steps (ADVICE r4), and a collective tied to the capture would pair with the peers' gradient all-reduces.  Here the
+# ranks "capture" one after the other, with a barrier in between: a collective inside assert_same_plan would deadlock.
+for turn in range(world):
+    if rank == turn:
+        assert red.assert_same_plan(per_stage) == red.verified_plan
+    dist.barrier()
+# a capture that completed other bucket sets is refused on the spot, on the rank it happened on
 bad = [list(ids) for ids in per_stage]
-if rank == 1:
-    bad[0], bad[1] = bad[1], bad[0]
+bad[0], bad[1] = bad[1], bad[0]
 try:
     red.assert_same_plan(bad)
+    raise SystemExit("a differing captured plan was accepted")
+except T_ddp.PlanMismatch as e:
+    assert "differ from the plan the ranks agreed on" in str(e), e
+# ... and the agreement itself catches a rank that differs -- on EVERY rank, in front of the step's last all-reduce.  (Only the
+# LOG of rank 1 is tampered with: the collectives actually issued still pair up, so nothing hangs while the check is tested.)
+red.verified_plan = None
+with torch.no_grad():
+    for q, s in zip(list(net.parameters()) + list(net.buffers()), state):
+        q.copy_(s)
+carry = {}
+for st in stages:
+    st(dict(data=xs[rank], final_target=ys[rank]), carry)
+    red.launch(red.take_ready())
+if rank == 1:
+    red.launch_log[0], red.launch_log[1] = red.launch_log[1], red.launch_log[0]
+try:
+    red.wait()
     raise SystemExit("differing plans were accepted")
-except RuntimeError as e:
+except T_ddp.PlanMismatch as e:
     assert "plans other collectives" in str(e), e
+for w in red.works:
+    w.wait()
+red.works = []
+red._reset()
+# parameter equality after an update from the reduced gradients (what the optimizer does with 1 / world folded in)
+red.verified_plan = None
+with torch.no_grad():
+    for q, s in zip(list(net.parameters()) + list(net.buffers()), state):
+        q.copy_(s)
+carry = {}
+for st in stages:
+    st(dict(data=xs[rank], final_target=ys[rank]), carry)
+    red.launch(red.take_ready())
+red.wait()
+with torch.no_grad():
+    for q in net.parameters():
+        q -= 0.1 * q.grad / world
+    chk = torch.stack([q.double().sum() for q in net.parameters()] + [q.double().abs().sum() for q in net.parameters()])
+both = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(both, chk)
+assert all(torch.equal(both[0], b) for b in both), "replicas diverged"
 dist.destroy_process_group()
 print("OK", rank)
 """
@@ -575,16 +620,19 @@ def test_grad_reducer_two_ranks_gloo(tmp_path):
         assert p.returncode == 0 and f"OK {r}" in o, o
 
 
-def test_product_staged_step_two_ranks_gloo(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_product_staged_step_two_ranks_gloo(tmp_path, world):
     """E3: trainer._stage_bounds / _staged_step (the stage callables of the hipGraph step under DDP) with ddp.GradReducer in
-    staged mode on two gloo ranks: three stages, every bucket launched once behind the stage that completed it, gradients =
-    the sum of the single-rank gradients; broadcast_module_state carries the BatchNorm buffers."""
+    staged mode on gloo ranks (2, and the 8 of one MI355X node): three stages, every bucket launched once behind the stage that
+    completed it, gradients = the sum of the single-rank gradients; broadcast_module_state carries the BatchNorm buffers; the
+    plan agreement (one collective in the first staged step, local comparisons at every capture: ranks capture on different
+    steps), a differing plan caught on every rank; replicas equal after an update."""
     script = tmp_path / "staged_worker.py"
     script.write_text(STAGED_WORKER)
-    env = dict(os.environ, MTMP_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", WORLD_SIZE="2",
+    env = dict(os.environ, MTMP_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29617 + world), WORLD_SIZE=str(world),
                OMP_NUM_THREADS="1")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+                              stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=400)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o
