@@ -401,6 +401,26 @@ int mtmp_swin_mlp_live(int dtype, const void* x, const float* ln_w, const float*
 int mtmp_swin_window_attn_live(int dtype, const void* qkv, const void* table, void* out, int n_img, int H, int W, int C, int heads,
                                int shift, float scale, const int32_t* rows_live, void* stream);
 
+/* ---- Backward of the image encoder's building blocks (ABI 5): the sibling models that TRAIN the Swin-T encoder -- the reference
+ * calls self.img_encoder(img) without torch.no_grad() in builder/models/8_missing_models/bi_vsltimg_mbt_v1.py:203-206,
+ * tri_mbt_v2.py:208-211, tri_mbt_vmulti.py:145 -- replace torch autograd of builder/models/src/swin_transformer.py as follows
+ * (the GEMM-shaped parts, dX = dY W and dW = dY^T X, run on mtmp_gemm_nt / mtmp_gemm_tn):
+ *
+ * mtmp_layernorm_rows_bwd: autograd of nn.LayerNorm(C, eps) as mtmp_layernorm_rows computes it (:428-449 norm1 / norm2, :34-85
+ *   the patch-merging norm, :611 the final norm).  x, dy, dx [rows, C] (dtype), w float[C]; slab float[slab_rows][2][C] receives one
+ *   row of partial (dw | db) sums per workgroup -- the caller adds the rows (mtmp_layernorm_rows_bwd_slab_rows tells how many).
+ * mtmp_gelu_fwd / mtmp_gelu_bwd: nn.GELU of the MLP (:437-439) as its own pass, and dx = dy GELU'(x); n % 8 == 0.
+ * mtmp_swin_window_attn_bwd: autograd of mtmp_swin_window_attn (:115-225).  dout [n,H,W,C] -> dqkv [n,H,W,3C] (every element
+ *   written once; H, W multiples of 7) and dtab float[4][heads][64][64], the gradient of the additive table, which the caller
+ *   ZEROES first (float atomics). */
+int mtmp_layernorm_rows_bwd_slab_rows(long long rows, int C);
+int mtmp_layernorm_rows_bwd(int dtype, const void* x, const float* w, const void* dy, void* dx, float* slab, long long rows, int C,
+                            float eps, void* stream);
+int mtmp_gelu_fwd(int dtype, const void* x, void* y, long long n, void* stream);
+int mtmp_gelu_bwd(int dtype, const void* x, const void* dy, void* dx, long long n, void* stream);
+int mtmp_swin_window_attn_bwd(int dtype, const void* qkv, const void* table, const void* dout, void* dqkv, float* dtab, int n_img,
+                              int H, int W, int C, int heads, int shift, float scale, void* stream);
+
 /* Attention half of a Swin block in ONE launch (ABI 4): out = x + row_scale[image] * (proj(window_attention(qkv(norm1(x)))) + b_proj).
  * Replaces builder/models/src/swin_transformer.py:428-449 (norm1, attn, stochastic_depth, residual) with :115-225
  * (shifted_window_attention) for maps that are multiples of the 7x7 window.  bf16 only (dtype MTMP_BF16); x, out [n_img, H, W, C]

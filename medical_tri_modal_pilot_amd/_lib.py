@@ -59,6 +59,11 @@ SIGNATURES = {
     "mtmp_layernorm_rows_live": (c_int, [c_int] + [c_void_p] * 4 + [c_longlong, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mtmp_swin_window_attn": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p]),
     "mtmp_swin_window_attn_live": (c_int, [c_int] + [c_void_p] * 3 + [c_int] * 6 + [c_float, c_void_p, c_void_p]),
+    "mtmp_layernorm_rows_bwd_slab_rows": (c_int, [c_longlong, c_int]),
+    "mtmp_layernorm_rows_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_longlong, c_int, c_float, c_void_p]),
+    "mtmp_gelu_fwd": (c_int, [c_int, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "mtmp_gelu_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "mtmp_swin_window_attn_bwd": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 6 + [c_float, c_void_p]),
     "mtmp_gemm_tn_ws_floats": (c_longlong, [c_int, c_int, c_int]),
     "mtmp_gemm_tn": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "mtmp_gemm_tn_live": (c_int, [c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_void_p]),

@@ -11,16 +11,13 @@ trainer.py:102-104).
 On the HIP path: ``--vslt-type TIE``, ``--img-model-type swin`` (the ViT / MONAI branches and the report decoder
 (``--auxiliary-loss-type tdecoder``, :150-164) raise).  The head over 2 B rows is small fp32 torch code.
 
-DEVIATION FROM THE REFERENCE (training only): the reference calls ``self.img_encoder(img)`` WITH gradients (:203-206), so its
-AdamW trains the 27.5 M Swin-T parameters; the HIP encoder is forward-only, so here they are frozen
-(``requires_grad_(False)``, said once in a warning at construction).  Forward outputs, the loss and the gradients of every
-other parameter match the reference (golden ``bi_vsltimg_step.npz``); the parameter trajectory does not once the encoder would
-have moved, and ``img_encoder.*`` optimizer moments of a reference checkpoint are dropped on resume (with a warning).
-BIIMG_MBT_VFLEXIBLE1, which subclasses this file, is frozen in the reference too (biimg_mbt_vflexible1.py:210-211): no deviation
-there.
+The image encoder is TRAINED here as in the reference, which calls ``self.img_encoder(img)`` with gradients (:203-206): the
+27.5 M Swin-T parameters are part of ``hot_parameters()`` (all but its never-evaluated classification head), the encoder runs
+its autograd path (``SwinTransformer.forward_train``: mtmp_gemm_nt / mtmp_gemm_tn, mtmp_layernorm_rows(_bwd),
+mtmp_gelu_fwd / _bwd, mtmp_swin_window_attn(_bwd)) and the feature projection passes its input gradient on.  In ``eval()`` /
+under ``torch.no_grad()`` the forward-only kernels run.  BIIMG_MBT_VFLEXIBLE1, which subclasses this file, keeps the encoder
+frozen like its reference (biimg_mbt_vflexible1.py:210-211).
 """
-import warnings
-
 import torch
 import torch.nn as nn
 
@@ -32,7 +29,7 @@ from .tri_mbt_vsltcls import _compute_dtype, flat_layout
 
 
 class BI_VSLTIMG_MBT_V1(nn.Module):
-    TRAINS_ENCODER_IN_REFERENCE = True       # the one deviation of this model (module docstring); subclasses say for themselves
+    TRAINS_ENCODER_IN_REFERENCE = True       # the reference back-propagates into the image encoder (:203-206); subclasses say for themselves
 
     def __init__(self, args):
         super().__init__()
@@ -70,11 +67,8 @@ class BI_VSLTIMG_MBT_V1(nn.Module):
         self.img_pretrain = args.img_pretrain
         # pretrained Swin weights come in through load_state_dict (the reference reads ImageNet / a private CXR checkpoint, :88-100)
         self.img_encoder = swin_t_m(compute_dtype=self.compute_dtype)
-        self.img_encoder.requires_grad_(False)               # forward-only HIP encoder: frozen, explicitly (module docstring)
-        if self.TRAINS_ENCODER_IN_REFERENCE:
-            warnings.warn("BI_VSLTIMG_MBT_V1 on the MI355X path keeps the Swin-T image encoder frozen; the reference trains it "
-                          "(bi_vsltimg_mbt_v1.py:203-206).  Inference and the gradients of all other parameters match; training "
-                          "is NOT reference-equivalent for img_encoder.*", stacklevel=2)
+        if not self.TRAINS_ENCODER_IN_REFERENCE:
+            self.img_encoder.requires_grad_(False)           # (sibling models whose reference runs the encoder under no_grad)
         self.linear = nn.Linear(768, 256)
         self.flatten = nn.Flatten(1, 2)
         self.fusion_transformer = BimodalTransformerEncoder_MBT(
@@ -90,10 +84,12 @@ class BI_VSLTIMG_MBT_V1(nn.Module):
             self.rmse_layer = nn.Linear(classifier_dim, 1, bias=True)
 
     def hot_parameters(self):
-        """Parameters that receive a gradient on this path, laid out for optim.FlatParams (the image encoder is frozen in
-        the tri-modal model's forward only -- here the reference trains it; on this path it stays frozen like there:
-        ``requires_grad`` of its parameters is the caller's switch and the HIP encoder has no backward)."""
-        skip = ("fusion_transformer.layer_norms_after_concat.", "activations.", "rmse_layer.", "img_encoder.")
+        """Parameters that receive a gradient on this path, laid out for optim.FlatParams: everything the reference's AdamW
+        moves -- the image encoder included when the reference trains it (its classification head is never evaluated,
+        swin_transformer.py:611-618, and gets no gradient there either)."""
+        skip = ("fusion_transformer.layer_norms_after_concat.", "activations.", "rmse_layer.", "img_encoder.head.")
+        if not self.TRAINS_ENCODER_IN_REFERENCE:
+            skip += ("img_encoder.",)
         named = [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
         return flat_layout(named, self.fusion_transformer.layer_stacks)
 
@@ -106,9 +102,13 @@ class BI_VSLTIMG_MBT_V1(nn.Module):
         vslt_embedding = ops.TieEmbed.apply(x.float(), self.ie_vslt[0].weight, self.ie_vslt[0].bias, self.ie_vslt[1].weight,
                                             self.ie_vslt[1].bias, self.ie_time[0].weight, self.ie_time[0].bias,
                                             self.ie_time[1].weight, self.ie_time[1].bias, self.ie_feat.weight, dt)
-        with torch.no_grad():                                                                # frozen encoder (no HIP backward)
+        if self.img_encoder.trains():                                                        # (:203-206) with gradients
             feat = self.flatten(self.img_encoder(img))                                       # [B,49,768]
-        img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
+            img_embedding = ops.LinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
+        else:
+            with torch.no_grad():                                                            # eval / frozen: forward-only kernels
+                feat = self.flatten(self.img_encoder(img))
+            img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
         if self.args.imgtxt_time == 1:                                                       # (:212-218)
             ev = torch.zeros(B, 3, device=x.device)
             ev[:, 0], ev[:, 2] = img_time.reshape(-1).float(), 18.0

@@ -1,4 +1,8 @@
-"""Swin-T chest-X-ray encoder (forward only; the model runs it frozen under no_grad).
+"""Swin-T chest-X-ray encoder.  The tri-modal model runs it frozen under no_grad (the forward-only kernels below); the sibling
+models that TRAIN it (bi_vsltimg_mbt_v1.py:203-206, tri_mbt_v2.py:208-211 call it with gradients) take `forward_train`: the
+same blocks as autograd nodes over libmtmp_hip.so kernels (ops.LinearFn, LayerNormRowsFn, GeluFn, WindowAttnFn: mtmp_gemm_nt /
+mtmp_gemm_tn, mtmp_layernorm_rows(_bwd), mtmp_gelu_fwd / _bwd, mtmp_swin_window_attn(_bwd)); residual adds, StochasticDepth
+scaling and the 2x2 patch gather are torch glue.
 
 Parameter tree / state_dict keys equal the reference's torchvision fork
 (builder/models/src/swin_transformer.py:503-654: 1-channel 4x4/4 stem, depths [2,2,6,2],
@@ -150,6 +154,30 @@ class ShiftedWindowAttention(nn.Module):
             self._tab, self._tab_key = tab.to(dtype).contiguous(), key
         return self._tab
 
+    def additive_table_train(self, shift: int, device) -> torch.Tensor:
+        """The same [4][heads][64][64] table in fp32, built from relative_position_bias_table by differentiable torch ops: the
+        gradient ops.WindowAttnFn returns for the table reaches the parameter through the index gather (swin_transformer.py:47-55)."""
+        L, h = WS * WS, self.num_heads
+        bias = self.relative_position_bias_table[self.relative_position_index.long()].view(L, L, h).permute(2, 0, 1).float()
+        key = (shift, str(device))
+        if getattr(self, "_base_key", None) != key:
+            base = torch.zeros(4, h, 64, 64, dtype=torch.float32, device=device)
+            base[:, :, :, L:] = PAD_LOGIT
+            if shift > 0:
+                base[:, :, :L, :L] += _shift_mask(2 * WS, 2 * WS, WS, shift, shift).to(device).unsqueeze(1)
+            self._base, self._base_key = base, key
+        return self._base + torch.nn.functional.pad(bias, (0, 64 - L, 0, 64 - L)).unsqueeze(0)
+
+    def forward_train(self, xn: torch.Tensor) -> torch.Tensor:
+        """xn [n,H,W,C] (normalised) -> attention output BEFORE the output projection, with gradients."""
+        n, H, W, C = xn.shape
+        if H % WS or W % WS:
+            raise NotImplementedError("training the image encoder needs feature maps that are multiples of the 7x7 window "
+                                      "(--image-size 224 / 448)")
+        shift = 0 if WS >= H else self.shift_size[0]
+        qkv = ops.LinearFn.apply(xn, self.qkv.weight, self.qkv.bias, xn.dtype)
+        return ops.WindowAttnFn.apply(qkv, self.additive_table_train(shift, xn.device), self.num_heads, shift)
+
     def forward(self, xn: torch.Tensor, norm: nn.LayerNorm = None) -> torch.Tensor:
         """xn [n,H,W,C] (already normalised, or raw with `norm` = the block's norm1 to be fused into the qkv
         projection) -> attention output [n,H,W,C] BEFORE the output projection."""
@@ -193,6 +221,23 @@ class SwinTransformerBlock(nn.Module):
         """(attention-branch, MLP-branch) StochasticDepth factors of one forward, float32[n] each or None."""
         return self.stochastic_depth.row_scale(n, device), self.stochastic_depth.row_scale(n, device)
 
+    def forward_train(self, x):
+        """The block as autograd nodes (swin_transformer.py:428-449): x + sd(proj(attn(norm1 x))), then x + sd(mlp(norm2 x))."""
+        n, H, W, C = x.shape
+        dt = x.dtype
+        s_attn, s_mlp = self.draw_scales(n, x.device)
+        a = self.attn.forward_train(ops.LayerNormRowsFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps))
+        a = ops.LinearFn.apply(a, self.attn.proj.weight, self.attn.proj.bias, dt)
+        if s_attn is not None:
+            a = a * s_attn.view(n, 1, 1, 1).to(dt)
+        x = x + a
+        h = ops.LayerNormRowsFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        h = ops.GeluFn.apply(ops.LinearFn.apply(h, self.mlp[0].weight, self.mlp[0].bias, dt))
+        h = ops.LinearFn.apply(h, self.mlp[3].weight, self.mlp[3].bias, dt)
+        if s_mlp is not None:
+            h = h * s_mlp.view(n, 1, 1, 1).to(dt)
+        return x + h
+
     def forward(self, x, scales=None):
         """x [n,H,W,C]; scales: this call's slice of draw_scales() when the batch is processed in parts (None = draw)."""
         n, H, W, C = x.shape
@@ -230,6 +275,14 @@ class PatchMerging(nn.Module):
         self.dim = dim
         self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
         self.norm = nn.LayerNorm(4 * dim, eps=1e-5)
+
+    def forward_train(self, x):
+        n, H, W, C = x.shape
+        if H % 2 or W % 2:
+            x = torch.nn.functional.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        y = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)      # (:40-44)
+        y = ops.LayerNormRowsFn.apply(y.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps)
+        return ops.LinearFn.apply(y, self.reduction.weight, None, x.dtype)
 
     def forward(self, x):
         n, H, W, C = x.shape
@@ -284,6 +337,28 @@ class SwinTransformer(nn.Module):
         ev.record(torch.cuda.current_stream())
         self._predrawn_ev = (ev, n)
 
+    def trains(self) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
+    def forward_train(self, x):
+        """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] with gradients for every encoder parameter (module docstring): the 4x4/4 patch
+        embedding as a projection of the 16-pixel patches (:559-567), the blocks, the patch mergings, the final norm."""
+        stem = self.features[0]
+        n, _, H, W = x.shape
+        dt = self.compute_dtype
+        draw_row_scales(self, n, x.device)
+        ph, pw = stem[0].kernel_size
+        patches = x.reshape(n, H // ph, ph, W // pw, pw).permute(0, 1, 3, 2, 4).reshape(n, H // ph, W // pw, ph * pw)
+        y = ops.LinearFn.apply(patches.to(dt), stem[0].weight.view(stem[0].weight.shape[0], -1), stem[0].bias, dt)
+        y = ops.LayerNormRowsFn.apply(y, stem[2].weight, stem[2].bias, stem[2].eps)
+        for layer in list(self.features)[1:]:
+            if isinstance(layer, nn.Sequential):
+                for blk in layer:
+                    y = blk.forward_train(y)
+            else:
+                y = layer.forward_train(y)
+        return ops.LayerNormRowsFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)
+
     def forward(self, x, tail_streams=None, slots=None):
         """x [B,1,H,W] fp32 -> [B,H/32,W/32,768] in the compute dtype.
 
@@ -299,6 +374,8 @@ class SwinTransformer(nn.Module):
         batches side by side on s0 and s1, s0 joins s1, and the result is valid ON s0: the caller goes on there.  (The
         halves cannot come back to the caller's stream: under hipGraph capture this ROCm crashes in hipStreamEndCapture
         when a forked non-origin stream is joined by the stream that forked it -- tools/dbg/capture_topology.py.)"""
+        if slots is None and self.trains():
+            return self.forward_train(x)
         stem = self.features[0]
         n = x.shape[0]
         drawn = getattr(self, "_predrawn_ev", None)

@@ -856,9 +856,117 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, wc = ctx.saved_tensors
         dy2 = _c(dy.reshape(-1, dy.shape[-1]).to(x2.dtype))
-        dw, db = gemm_tn(dy2, x2)
-        dx = gemm_nt(dy2, _c(wc.t()))
-        return (dx.view(*dy.shape[:-1], x2.shape[1]).to(ctx.xdtype), dw.view(ctx.wshape), db if ctx.has_bias else None, None)
+        dw, db = gemm_tn_any(dy2, x2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nt(dy2, _c(wc.t())).view(*dy.shape[:-1], x2.shape[1]).to(ctx.xdtype)
+        return dx, dw.view(ctx.wshape), db if ctx.has_bias else None, None
+
+
+def gemm_tn_any(dy2d, x2d):
+    """(dW [N,K], db [N]) in fp32 like gemm_tn, for any width: mtmp_gemm_tn tiles need N and K in multiples of 128 (every product of
+    the fusion layers; stages 3-4 of the image encoder).  The 96- / 192-wide stages of the image encoder, its 16-wide stem and
+    the odd-sized patch-merging products take a plain library TN product in fp32 -- weight gradients of the sibling models that
+    train the encoder only, not on the benchmarked path."""
+    N, K = dy2d.shape[1], x2d.shape[1]
+    if N % 128 == 0 and K % 128 == 0:
+        return gemm_tn(dy2d, x2d)
+    dyf = dy2d.float()
+    return dyf.t() @ x2d.float(), dyf.sum(0)
+
+
+# ----------------------------------------------------------------------------- image encoder, trainable path (Swin-T backward)
+def layernorm_rows_bwd(x, w, dy, eps=1e-5):
+    """autograd of layernorm_rows (plain mode): (dx like x, dw fp32 [C], db fp32 [C])"""
+    _gpu(x, dy)
+    x, dy = _c(x), _c(dy)
+    C = x.shape[-1]
+    rows = x.numel() // C
+    nslab = _lib.lib().mtmp_layernorm_rows_bwd_slab_rows(rows, C)
+    slab = torch.empty(nslab, 2, C, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    call("mtmp_layernorm_rows_bwd", _dt(x), _p(x), _p(w), _p(dy), _p(dx), _p(slab), rows, C, float(eps), _stream())
+    g = slab.sum(0)
+    return dx, g[0], g[1]
+
+
+def gelu_fwd(x):
+    _gpu(x)
+    x = _c(x)
+    y = torch.empty_like(x)
+    call("mtmp_gelu_fwd", _dt(x), _p(x), _p(y), x.numel(), _stream())
+    return y
+
+
+def gelu_bwd(x, dy):
+    _gpu(x, dy)
+    x, dy = _c(x), _c(dy)
+    dx = torch.empty_like(x)
+    call("mtmp_gelu_bwd", _dt(x), _p(x), _p(dy), _p(dx), x.numel(), _stream())
+    return dx
+
+
+def swin_window_attn_bwd(qkv, table, dout, heads, shift):
+    """autograd of swin_window_attn: (dqkv like qkv, dtab fp32 [4][heads][64][64])"""
+    _gpu(qkv, dout)
+    qkv, dout = _c(qkv), _c(dout)
+    n, H, W, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = torch.empty_like(qkv)
+    dtab = torch.zeros(4, heads, 64, 64, dtype=torch.float32, device=qkv.device)
+    call("mtmp_swin_window_attn_bwd", _dt(qkv), _p(qkv), _p(table), _p(dout), _p(dqkv), _p(dtab), n, H, W, C, heads, int(shift),
+         float((C // heads) ** -0.5), _stream())
+    return dqkv, dtab
+
+
+class LayerNormRowsFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim (swin_transformer.py:428-449 norm1 / norm2, the merge norm, the final norm) with
+    gradients: mtmp_layernorm_rows forward, mtmp_layernorm_rows_bwd backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y = layernorm_rows(x, w.detach().float(), b.detach().float(), eps)
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = layernorm_rows_bwd(x, w.detach().float(), dy.to(x.dtype), ctx.eps)
+        return dx, dw.to(w.dtype), db.to(w.dtype), None
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return gelu_bwd(x, dy.to(x.dtype))
+
+
+class WindowAttnFn(torch.autograd.Function):
+    """Shifted-window attention (swin_transformer.py:115-225) on a [n,H,W,3C] qkv map with gradients for the map and for the
+    additive table (fp32 [4][heads][64][64]: relative-position bias + shift mask; its gradient flows on into
+    relative_position_bias_table through the torch indexing that built it)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table32, heads, shift):
+        tab = _c(table32.detach().to(qkv.dtype))
+        out = swin_window_attn(_c(qkv), tab, heads, shift)
+        ctx.save_for_backward(qkv, tab)
+        ctx.heads, ctx.shift = heads, shift
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, tab = ctx.saved_tensors
+        dqkv, dtab = swin_window_attn_bwd(qkv, tab, dout.to(qkv.dtype), ctx.heads, ctx.shift)
+        return dqkv, dtab, None, None
 
 
 # ----------------------------------------------------------------------------- classification head (K10)

@@ -43,7 +43,7 @@ def one_trainer(i, dev):
     opt = FusedAdamW(model.hot_parameters(), lr=1e-4, weight_decay=a.weight_decay)
     sched = CosineAnnealingWarmupRestarts(opt, first_cycle_steps=100, cycle_mult=1, max_lr=1e-3, min_lr=1e-6, warmup_steps=10, gamma=1.0)
     crit = torch.nn.BCEWithLogitsLoss(reduction="mean")
-    for it in range(4):             # eager warm-up, capture, two replays
+    for it in range(4):             # eager warm-up, capture (replayed at once), two more replays
         bt = synthetic.make_batch(900 + it, 4, 96, ragged=False, missing_mode="none")
         static = torch.stack([bt["gen"], bt["age"]], 1)
         _, loss = get_trainer(args=a, iteration=it + 1, x=bt["x"], static=static, y=bt["y"], output_lengths=None, model=model,
@@ -52,7 +52,7 @@ def one_trainer(i, dev):
                               input_lengths=bt["input_lengths"], txt_lengths=bt["txt_lengths"], flow_type="train",
                               reports_tokens=None, reports_lengths=None, criterion_aux=(None, None))
     gs = model._mtmp_graph_step
-    assert gs.captures == 1 and gs.replays == 2, (gs.captures, gs.replays)
+    assert gs.captures == 1 and gs.replays == 3, (gs.captures, gs.replays)
     return loss
 
 
