@@ -234,24 +234,34 @@ def gen_bimodel():
     ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls")     # leave the global args as the other sections expect
 
 
-def _sibling_step(model_name, input_types, tag, fold, out_squeeze):
+def _sibling_step(model_name, input_types, tag, fold, out_squeeze, encoder_train=False):
     """One train-mode forward + BCE + backward of a sibling model's REAL class (dropout 0, image encoder in eval mode):
-    logits, loss, every parameter gradient's digest, the no-gradient set, and the state_dict shapes."""
+    logits, loss, every parameter gradient's digest, the no-gradient set, and the state_dict shapes.
+    encoder_train: the image encoder stays in TRAIN mode as 2_train.py:128 leaves it -- its row-mode StochasticDepth is live (the
+    shim draws from a seeded generator and RECORDS the draws, gen_swin_train) -- for the models that back-propagate into it
+    (bi_vsltimg_mbt_v1.py:203-206); saved as <tag>_train_step with the draws."""
     import json
     args = ref_args(input_types=input_types, model=model_name, batch_size=4, transformer_num_layers=2, output_dim=1)
     from builder.models import get_model
     model = get_model(args)(args)
     load_filled(model)
     model.train()
-    if hasattr(model, "img_encoder"):
+    sd_cls = ref_shims._StochasticDepth
+    if hasattr(model, "img_encoder") and not encoder_train:
         model.img_encoder.eval()
     seed, B, T = 5151, 4, 24
     bt = filler.make_batch(seed, B, T)
     mnum = fold(bt["missing_num"].clone())
     tmax = int(bt["input_lengths"].max())
-    out, o2, o3 = model(bt["x"][:, :tmax], None, None, None, None, bt["age"], bt["gen"], bt["input_lengths"].clone(),
-                        bt["txt"], bt["txt_lengths"].clone(), bt["img"], mnum, None, bt["img_time"].half().float(),
-                        bt["txt_time"].half().float(), "train", None, None)
+    if encoder_train:
+        sd_cls.rng, sd_cls.draws = torch.Generator().manual_seed(43), []
+    try:
+        out, o2, o3 = model(bt["x"][:, :tmax], None, None, None, None, bt["age"], bt["gen"], bt["input_lengths"].clone(),
+                            bt["txt"], bt["txt_lengths"].clone(), bt["img"], mnum, None, bt["img_time"].half().float(),
+                            bt["txt_time"].half().float(), "train", None, None)
+        draws = torch.stack(sd_cls.draws) if encoder_train else None
+    finally:
+        sd_cls.rng, sd_cls.draws = None, None
     assert o2 is None and o3 is None
     loss = torch.nn.BCEWithLogitsLoss()(out.squeeze() if out_squeeze else out.squeeze(-1), bt["y"].float())
     loss.backward()
@@ -262,6 +272,12 @@ def _sibling_step(model_name, input_types, tag, fold, out_squeeze):
         else:
             names.append(n)
             dig.append(digest(p_.grad))
+    if encoder_train:
+        assert draws.shape[0] == 22 and len(set(draws.flatten().tolist())) > 2, draws.shape      # 11 blocks with p > 0, two branches each
+        save(tag + "_train_step", seed=np.array(seed), B=np.array(B), T=np.array(T), logits=out, loss=loss, missing_num=mnum,
+             grad_names=np.array(names), nograd_names=np.array(nograd), grad_digest=np.stack(dig), draws=draws)
+        ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls")
+        return
     save(tag + "_step", seed=np.array(seed), B=np.array(B), T=np.array(T), logits=out, loss=loss, missing_num=mnum,
          grad_names=np.array(names), nograd_names=np.array(nograd), grad_digest=np.stack(dig))
     d = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
@@ -283,6 +299,7 @@ def gen_siblings():
         m[0], m[1] = 0, 1                                # both branches of the per-sample mix are exercised
         return m
     _sibling_step("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg", fold_img, False)
+    _sibling_step("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg", fold_img, False, encoder_train=True)      # -> bi_vsltimg_train_step
     # TRI_MBT_V1 (tri_mbt_v1.py:17-283): all three CLS rows, LayerNorm head, per-sample mean over the present modalities
     _sibling_step("tri_mbt_v1", "vslt_img_txt", "tri_v1", lambda m: m, True)
     # TRI_MBT_VFLEXIBLE / 2 / 3 (tri_mbt_vflexible*.py): V1 with learned softmax weights over the present modalities (temperature
