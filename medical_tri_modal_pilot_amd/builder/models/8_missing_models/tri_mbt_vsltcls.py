@@ -120,6 +120,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         self.n_images = int(getattr(args, "n_images", 3)) if self.args.multiimages == 1 else 1
 
     head_fusable = True        # ie_demo = Linear -> LayerNorm -> ReLU: what ops.HeadFn fuses (a sibling may differ)
+    TRAINS_ENCODER_IN_REFERENCE = False      # this model and most siblings run the image encoder under no_grad (:205-209)
 
     def _make_embeddings(self, args) -> bool:
         """ie_vslt / ie_time / ie_feat / ie_demo in the reference's registration order (:51-76); returns vslt_pe."""
@@ -311,7 +312,14 @@ class TRI_MBT_VSLTCLS(nn.Module):
                 # missing_num 0: all three modalities, 1: vital signs + image (builder/trainer missing_to_num)
                 slots = ops.image_slots(missing.to(img.device), 2, hw0)
             return self.img_encoder(img, slots=slots, **kw)
-        if side is not None:
+        trained = self.TRAINS_ENCODER_IN_REFERENCE and self.img_encoder.trains()
+        if trained:
+            # sibling models whose reference back-propagates into the encoder (tri_mbt_v2.py:208-211): the autograd path of the
+            # encoder (SwinTransformer.forward_train), every image encoded, the feature projection passing its input gradient on
+            with on_side(0):
+                feat = self.flatten(self.img_encoder(img))
+                img_embedding = ops.LinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
+        elif side is not None:
             # stages 1-2 on a third stream, stages 3-4 as two half batches on the two side streams (result valid on side[0])
             if not preforked:                             # (prefork() joined the encoder's stream at the head of the step)
                 if getattr(self, "_swin_stream", None) is None or self._swin_stream.device != img.device:
@@ -328,8 +336,9 @@ class TRI_MBT_VSLTCLS(nn.Module):
             with torch.no_grad():
                 feat = encode()
             feat = self.flatten(feat)
-        with on_side(0):
-            img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
+        if not trained:
+            with on_side(0):
+                img_embedding = ops.DataLinearFn.apply(feat, self.linear.weight, self.linear.bias, dt)
         # ---- vital-sign / lab stream
         img_time = img_time.reshape(-1).float()
         txt_time = txt_time.float()
@@ -366,7 +375,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
             enc_outputs=[vslt_embedding, img_embedding, txt_embedding],
             fixed_lengths=[vslt_embedding.size(1), img_embedding.size(1), txt_embedding.size(1)],
             varying_lengths=[input_lengths, img_len, txt_lengths + 2], fusion_idx=None, missing=missing)
-        if side is not None:
+        if side is not None and not trained:
             cur.wait_stream(self._swin_stream)            # joins the encoder's stream to the caller's (its work ended long ago)
         return self._head(outputs, demo_embedding if not fused_head else None, age, gen, missing, fused_head)
 

@@ -234,14 +234,15 @@ def gen_bimodel():
     ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls")     # leave the global args as the other sections expect
 
 
-def _sibling_step(model_name, input_types, tag, fold, out_squeeze, encoder_train=False):
+def _sibling_step(model_name, input_types, tag, fold, out_squeeze, encoder_train=False, token_text=False):
     """One train-mode forward + BCE + backward of a sibling model's REAL class (dropout 0, image encoder in eval mode):
     logits, loss, every parameter gradient's digest, the no-gradient set, and the state_dict shapes.
     encoder_train: the image encoder stays in TRAIN mode as 2_train.py:128 leaves it -- its row-mode StochasticDepth is live (the
     shim draws from a seeded generator and RECORDS the draws, gen_swin_train) -- for the models that back-propagate into it
     (bi_vsltimg_mbt_v1.py:203-206); saved as <tag>_train_step with the draws."""
     import json
-    args = ref_args(input_types=input_types, model=model_name, batch_size=4, transformer_num_layers=2, output_dim=1)
+    args = ref_args(input_types=input_types, model=model_name, batch_size=4, transformer_num_layers=2, output_dim=1,
+                    berttype="bert" if token_text else "biobert")
     from builder.models import get_model
     model = get_model(args)(args)
     load_filled(model)
@@ -253,6 +254,13 @@ def _sibling_step(model_name, input_types, tag, fold, out_squeeze, encoder_train
     bt = filler.make_batch(seed, B, T)
     mnum = fold(bt["missing_num"].clone())
     tmax = int(bt["input_lengths"].max())
+    tokens = None
+    if token_text:
+        # token-id reports (tri_mbt_v2.py:205 casts txts to LongTensor for nn.Embedding(30000, 256)): seeded ids, zeros behind
+        # each report's length; saved with the golden (the synthetic batch carries BioBERT embeddings only)
+        tokens = torch.randint(1, 30000, (B, 128), generator=torch.Generator().manual_seed(seed + 1))
+        tokens[torch.arange(128).unsqueeze(0) >= bt["txt_lengths"].unsqueeze(1)] = 0
+        bt = dict(bt, txt=tokens.float())
     if encoder_train:
         sd_cls.rng, sd_cls.draws = torch.Generator().manual_seed(43), []
     try:
@@ -276,14 +284,15 @@ def _sibling_step(model_name, input_types, tag, fold, out_squeeze, encoder_train
         assert draws.shape[0] == 22 and len(set(draws.flatten().tolist())) > 2, draws.shape      # 11 blocks with p > 0, two branches each
         save(tag + "_train_step", seed=np.array(seed), B=np.array(B), T=np.array(T), logits=out, loss=loss, missing_num=mnum,
              grad_names=np.array(names), nograd_names=np.array(nograd), grad_digest=np.stack(dig), draws=draws)
-        ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls")
+        ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls", berttype="biobert")
         return
+    extra = {} if tokens is None else {"tokens": tokens}
     save(tag + "_step", seed=np.array(seed), B=np.array(B), T=np.array(T), logits=out, loss=loss, missing_num=mnum,
-         grad_names=np.array(names), nograd_names=np.array(nograd), grad_digest=np.stack(dig))
+         grad_names=np.array(names), nograd_names=np.array(nograd), grad_digest=np.stack(dig), **extra)
     d = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in model.state_dict().items()}
     with open(os.path.join(GOLD, f"state_shapes_{tag}_L2.json"), "w") as f:
         json.dump(d, f, indent=0)
-    ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls")     # leave the global args as the other sections expect
+    ref_args(input_types="vslt_img_txt", model="tri_mbt_vsltcls", berttype="biobert")     # leave the global args as the other sections expect
 
 
 def gen_siblings():
@@ -302,6 +311,8 @@ def gen_siblings():
     _sibling_step("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg", fold_img, False, encoder_train=True)      # -> bi_vsltimg_train_step
     # TRI_MBT_V1 (tri_mbt_v1.py:17-283): all three CLS rows, LayerNorm head, per-sample mean over the present modalities
     _sibling_step("tri_mbt_v1", "vslt_img_txt", "tri_v1", lambda m: m, True)
+    # TRI_MBT_V2 (tri_mbt_v2.py:17-262): the image encoder TRAINED (:208-211), token-id reports (:205), BatchNorm head over 3 B rows
+    _sibling_step("tri_mbt_v2", "vslt_img_txt", "tri_v2", lambda m: m, False, token_text=True)
     # TRI_MBT_VFLEXIBLE / 2 / 3 (tri_mbt_vflexible*.py): V1 with learned softmax weights over the present modalities (temperature
     # 1 / 10 / 3.334).  Their __init__ builds mask tensors with .cuda(): patched to identity for the CPU run.  flexibleavg starts
     # at zeros in the reference; the filler gives it distinct values so that the softmax is not uniform.
