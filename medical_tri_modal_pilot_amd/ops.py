@@ -821,8 +821,9 @@ class DataLinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, dtype):
         _gpu(x, weight)
         lead = x.shape[:-1]
+        from .optim import compute_weight          # (a view of the optimizer's bf16 shadow when there is a current one: no cast launch)
         x2 = _c(x.reshape(-1, x.shape[-1]).to(dtype))
-        y = gemm_nt(x2, _c(weight.detach().to(dtype)), _c(bias.detach().float()))
+        y = gemm_nt(x2, _c(compute_weight(weight, dtype)), _c(bias.detach().float()))
         ctx.save_for_backward(x2)
         ctx.wshape, ctx.prm = weight.shape, [weight, bias]
         return y.view(*lead, weight.shape[0])
@@ -845,8 +846,9 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, dtype):
         _gpu(x, weight)
         lead = x.shape[:-1]
+        from .optim import compute_weight
         x2 = _c(x.reshape(-1, x.shape[-1]).to(dtype))
-        wc = _c(weight.detach().to(dtype))
+        wc = _c(compute_weight(weight, dtype))
         y = gemm_nt(x2, wc, None if bias is None else _c(bias.detach().float()))
         ctx.save_for_backward(x2, wc)
         ctx.wshape, ctx.has_bias, ctx.xdtype = weight.shape, bias is not None, x.dtype

@@ -520,7 +520,7 @@ def test_bi_vslttxt_model_surface_matches_reference():
     G = np.load(os.path.join(ROOT, "tests", "golden", "bimodel_step.npz"))
     assert sorted(n for n, _ in model.hot_parameters()) == sorted(str(s) for s in G["grad_names"])
     with pytest.raises(NotImplementedError):
-        a.model = "tri_mbt_v2"            # (a sibling that is not built: DESIGN.md section 8)
+        a.model = "tri_mbt_vmulti"        # (a sibling that is not built: DESIGN.md section 8)
         get_model(a)
 
 
