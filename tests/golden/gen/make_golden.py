@@ -313,6 +313,8 @@ def gen_siblings():
     _sibling_step("tri_mbt_v1", "vslt_img_txt", "tri_v1", lambda m: m, True)
     # TRI_MBT_V2 (tri_mbt_v2.py:17-262): the image encoder TRAINED (:208-211), token-id reports (:205), BatchNorm head over 3 B rows
     _sibling_step("tri_mbt_v2", "vslt_img_txt", "tri_v2", lambda m: m, False, token_text=True)
+    # TRI_MBT_VNOSHAVGTR (tri_mbt_vnoshavgtr.py:17-283): the image encoder trained (:226-231), one head per modality (:160-164)
+    _sibling_step("tri_mbt_vnoshavgtr", "vslt_img_txt", "tri_vnoshavgtr", lambda m: m, False)
     # TRI_MBT_VFLEXIBLE / 2 / 3 (tri_mbt_vflexible*.py): V1 with learned softmax weights over the present modalities (temperature
     # 1 / 10 / 3.334).  Their __init__ builds mask tensors with .cuda(): patched to identity for the CPU run.  flexibleavg starts
     # at zeros in the reference; the filler gives it distinct values so that the softmax is not uniform.

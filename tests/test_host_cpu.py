@@ -528,7 +528,8 @@ def test_bi_vslttxt_model_surface_matches_reference():
                                                   ("tri_mbt_vflexible", "vslt_img_txt", "tri_vflex"), ("tri_mbt_vflexible2", "vslt_img_txt", "tri_vflex2"),
                                                   ("tri_mbt_vflexible3", "vslt_img_txt", "tri_vflex3"),
                                                   ("bi_vsltimg_mbt_v1", "vslt_img", "bi_vsltimg"), ("bitxt_mbt_vflexible1", "vslt_txt", "bitxt_vflex1"),
-                                                  ("biimg_mbt_vflexible1", "vslt_img", "biimg_vflex1"), ("tri_mbt_v2", "vslt_img_txt", "tri_v2")])
+                                                  ("biimg_mbt_vflexible1", "vslt_img", "biimg_vflex1"), ("tri_mbt_v2", "vslt_img_txt", "tri_v2"),
+                                                  ("tri_mbt_vnoshavgtr", "vslt_img_txt", "tri_vnoshavgtr")])
 def test_more_sibling_model_surfaces_match_reference(name, input_types, tag):
     """SURVEY 8 f-4 / VERDICT r2 missing #3: the other two siblings whose forward returns -- state_dict keys / shapes of the
     real classes, parameter ORDER (what torch.optim.AdamW(model.parameters()) state is indexed by), gradient set."""
