@@ -82,10 +82,11 @@ def make_args(wl, dtype: str, dropout: float, hip_graph: int, graph_stages: int,
                        "--pack-rows", str(pack_rows), "--skip-missing-images", str(skip_img), "--synthetic", "1"])
 
 
-def cpu_baseline(wl, shapes, budget_s: float = 150.0):
+def cpu_baseline(wl, shapes, budget_s: float = 300.0):
     """Oracle (port of the reference's CPU path) on the workload's own batch: BASELINE.md section 3 -- the full per-GPU batch
     when the host has >= 32 GB of RAM (config 2 needs ~22 GB), else B = 16 with linear scaling stated; 1 warm-up + 3 timed
-    steps, median.  The warm-up step is timed too: if three more would not fit `budget_s` (slow hosts; the driver's bench run
+    steps, median (the protocol's three whenever a step takes under 100 s: ~50 s on the GPU boxes' 128 host threads).
+    The warm-up step is timed too: if three more would not fit `budget_s` (slow hosts; the driver's bench run
     has ~10 minutes), fewer steps are timed and the sample says so."""
     from medical_tri_modal_pilot_amd import synthetic
     from oracle import tri_mbt_oracle as O
@@ -433,6 +434,13 @@ def main():
                 tj = json.load(fh)
             traffic, traffic_src = tj.get("traffic_bytes_per_launch"), f"profiles/roofline_traffic.json ({tj.get('round')})"
             rocprof_us, rocprof_src = tj.get("rocprof_avg_us"), tj.get("rocprof_source")
+        # the benchmarked build's parity at THIS size (tests/test_gpu_parity.py: test_bf16_build_vs_fp32_build_at_benchmark_sizes,
+        # test_config2_full_size_fp32_step_vs_oracle), measured on the GPU box by the test suite and committed with the profiles
+        parity = None
+        ppath = os.path.join(ROOT, "profiles", "parity_at_benchmark_size.json")
+        if a.dtype == "bf16" and os.path.exists(ppath):
+            with open(ppath) as fh:
+                parity = json.load(fh).get({"full": "config2", "ragged": "config2", "cfg5": "cfg5"}[a.workload])
         rf = roof("attn_fwd", f"attn_fwd_kernel<{'bf16' if a.dtype == 'bf16' else 'float'}> (vslt stream, N={n_tok})")
         rf.update(traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src, rocprof_avg_us=rocprof_us,
                   rocprof_source=rocprof_src)
@@ -441,7 +449,7 @@ def main():
             "value": world * B_PER_GPU * a.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "ms_per_step_median_host": 1e3 * med,
             "host_enqueue_ms_per_step": host_ms, "hip_graph": bool(graphed), "graphs_per_step": n_graphs,
-            "graph_cache": graph_cache,
+            "graph_cache": graph_cache, "parity_bf16_vs_fp32": parity,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (SURVEY 8d recipe), random-init weights",
             "rccl_ranks": dist.get_world_size() if ddp else 1, "ranks_hold_identical_parameters": ranks_agree,
