@@ -352,6 +352,41 @@ int mtmp_gemm_lnbwd_slab_rows(int M);
 int mtmp_reduce_batch(const float* const* slab, const int* rows, const long long* cols, float* const* out_a, const long long* split,
                       float* const* out_b, int n, void* stream);
 
+/* ---- The input nodes' backward with ONE closing launch (ABI 6).  The backward of the three stream-input launches and of the event /
+ * time embeddings (autograd of mbt_encoder.py:697-729,745 and tri_mbt_vsltcls.py:183-190,216-224) is the tail of a training step,
+ * where nothing else runs; each of them used to end in two reduction levels + a multi-tensor copy into the flat gradient, and the
+ * parameters the nodes share (ie_time, ie_feat, the bottleneck tokens) in accumulation launches.
+ * mtmp_stream_input_bwd_partials = mtmp_stream_input_bwd without the reduction: ws receives
+ *   [mtmp_stream_input_slab_rows(B * (nb+1+N))][7][256] floats of partial sums (dgamma, dbeta, dcls, dbott[0..3]).
+ * mtmp_tie_time_embed_bwd_partials = mtmp_tie_embed_bwd of events[n][3] / d_out[n][256] AND mtmp_time_embed_bwd of
+ *   time_events[n_time][3], whose gradient rows are d_time_a[n_time_a][256] followed by d_time_b[n_time - n_time_a][256], as one
+ *   launch: ws receives [mtmp_tie_bwd_slab_rows(n + n_time)][28][256] floats (grads layout of mtmp_tie_embed_bwd).
+ * mtmp_reduce_scatter: out[i][c] = sum_{r < rows[i]} src[i][r * ld[i] + c], c < cols[i], for up to 12 column ranges of such slabs
+ *   in one launch (src[i] = first column of the range inside its slab, ld[i] = the slab's row length in floats; HOST arrays) --
+ *   every destination is a parameter's slice of the flat gradient buffer, or scratch. */
+int mtmp_stream_input_slab_rows(int rows);
+int mtmp_stream_input_bwd_partials(int dtype, const void* dz, const void* x, const float* cls, const float* gamma, const float* stats,
+                                   void* dx, float* ws, int B, int N, int nb, float p, unsigned seed, const unsigned* seed_dev,
+                                   const int32_t* row_start, const int32_t* kv_len, void* stream);
+/* mtmp_stream_input_bwd_partials of up to three token streams as ONE launch: ws receives the streams' slabs back to back (stream i's
+ * mtmp_stream_input_slab_rows(B[i] * (nb[i]+1+N[i])) rows behind those in front of it), so one mtmp_reduce_scatter entry over all
+ * rows sums the bottleneck tokens' columns (768..) of all streams.  HOST arrays of n <= 3 entries; row_start / kv_len may be NULL
+ * as a whole or per entry. */
+int mtmp_stream_input_bwd_grouped(int dtype, int n, const void* const* dz, const void* const* x, const float* const* cls,
+                                  const float* const* gamma, const float* const* stats, void* const* dx, float* ws, const int* B,
+                                  const int* N, const int* nb, const float* p, const unsigned* seed, const unsigned* seed_dev,
+                                  const int32_t* const* row_start, const int32_t* const* kv_len, void* stream);
+/* out[i][j][:] = sum_{t < L[i]} dx[i][j L[i] + t][:] (256 columns, fp32 accumulation, `dtype` in and out) for n <= 2 tensors in one
+ * launch: the gradient of the per-image / per-report time embedding that was added to each of its L tokens
+ * (tri_mbt_vsltcls.py:216-224) -- torch autograd's sum over the token axis.  rows[i] = output rows of tensor i.  HOST arrays. */
+int mtmp_token_sums(int dtype, int n, const void* const* dx, void* const* out, const int* rows, const int* L, void* stream);
+int mtmp_tie_bwd_slab_rows(int n);
+int mtmp_tie_time_embed_bwd_partials(int dtype, const float* events, int n, const float* time_events, int n_time, int n_time_a,
+                                     const float* params, const void* d_out, const void* d_time_a, const void* d_time_b, float* ws,
+                                     void* stream);
+int mtmp_reduce_scatter(const float* const* src, const int* rows, const long long* ld, const long long* cols, float* const* out, int n,
+                        void* stream);
+
 /* pair[0] <- bit pattern of *value (fp32), pair[1] += 1 (both uint32, device memory): a scalar and a sequence number published
  * together.  The training step copies the pair to pinned host memory right behind its loss (2_train.py:76, trainer.py:128), so the
  * reference's `loss.item()` hands the value over when the forward pass is done instead of when the whole step has drained. */

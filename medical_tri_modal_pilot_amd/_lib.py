@@ -49,6 +49,13 @@ SIGNATURES = {
     "mtmp_gemm_tn_slab_rows": (c_int, [c_int] * 4),
     "mtmp_gemm_lnbwd_slab_rows": (c_int, [c_int]),
     "mtmp_reduce_batch": (c_int, [c_void_p] * 6 + [c_int, c_void_p]),
+    "mtmp_reduce_scatter": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
+    "mtmp_stream_input_slab_rows": (c_int, [c_int]),
+    "mtmp_stream_input_bwd_partials": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 3 + [c_float, c_uint, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mtmp_stream_input_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 16),
+    "mtmp_token_sums": (c_int, [c_int, c_int] + [c_void_p] * 5),
+    "mtmp_tie_bwd_slab_rows": (c_int, [c_int]),
+    "mtmp_tie_time_embed_bwd_partials": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6),
     "mtmp_publish_scalar": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mtmp_copy_batch": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_stream_lengths": (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),

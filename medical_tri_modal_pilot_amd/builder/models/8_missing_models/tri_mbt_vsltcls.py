@@ -168,6 +168,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         return emb[:n_it], emb[n_it:]
 
     joint_embeddings = True    # (switch for A/B runs and tests)
+    defer_time_adds = True     # the time embeddings are added to their tokens inside the encoder's stream-input node
 
     def _joint_embeddings(self, x, img_time, txt_time, dt):
         """(vslt [B,T,256], it, tt) from ONE autograd node (ops.TieTimeEmbed) when the event embedding and the two time
@@ -359,10 +360,15 @@ class TRI_MBT_VSLTCLS(nn.Module):
             if side is not None:
                 for s_ in side:
                     s_.wait_stream(cur)              # the time embeddings were made on the main stream
-            with on_side(0):
-                img_embedding = img_embedding + it.unsqueeze(1)
-            with on_side(1):
-                txt_embedding = txt_embedding + tt.unsqueeze(1)
+            # added to every token of its image / report inside the encoder's stream-input node (mbt_encoder ``time_adds``), whose
+            # backward then hands the embedding node its gradient without two more autograd nodes on the step's tail
+            defer_add = (self.defer_time_adds and it.is_cuda and it.dim() == 2 and tt.dim() == 2
+                         and getattr(self.fusion_transformer, "n_modality", 0) == 3)
+            if not defer_add:
+                with on_side(0):
+                    img_embedding = img_embedding + it.unsqueeze(1)
+                with on_side(1):
+                    txt_embedding = txt_embedding + tt.unsqueeze(1)
         if self.args.multiimages == 1:                                                        # (:226-232)
             n_tok = img_embedding.shape[1]
             img_embedding = img_embedding.reshape(B, self.n_images * n_tok, self.model_dim)
@@ -370,6 +376,7 @@ class TRI_MBT_VSLTCLS(nn.Module):
         else:
             img_len = img_embedding.size(1)
         self.fusion_transformer.inputs_on_side_streams = side is not None
+        self.fusion_transformer.time_adds = (it, tt) if (self.args.imgtxt_time == 1 and defer_add) else None
         ops.mark("inputs.e")
         outputs, _ = self.fusion_transformer(
             enc_outputs=[vslt_embedding, img_embedding, txt_embedding],

@@ -126,17 +126,44 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         # the model may have produced the image / text embeddings on the two side streams (inputs_on_side_streams):
         # their stream-input kernels stay there, and the main stream joins before the fusion stack
         side_in = self._side_streams(dev) if (fused_in and getattr(self, "inputs_on_side_streams", False)) else None
-        for m, x in enumerate(enc_outputs):
+        # ``time_adds`` (set by the model for ONE call): the image / report time embeddings (it [n_i, 256], tt [n_t, 256]) still to be
+        # added to every token of their group -- inside ops.StreamInputsFn when that node runs, here through torch otherwise
+        time_adds, self.time_adds = getattr(self, "time_adds", None), None
+        if time_adds is not None and not (fused_in and tuning.FUSED_INPUT_TAIL and self.bottlenecks is not None):
+            enc_outputs = list(enc_outputs)
+            for m, t in ((1, time_adds[0]), (2, time_adds[1])):
+                x = enc_outputs[m]
+                with (torch.cuda.stream(side_in[m - 1]) if side_in is not None else contextlib.nullcontext()):
+                    g = t.shape[0] // x.shape[0]
+                    enc_outputs[m] = (x.reshape(t.shape[0], x.shape[1] // g, x.shape[2]) + t.to(x.dtype).unsqueeze(1)).view(x.shape)
+            time_adds = None
+        if fused_in:          # LN + PE + dropout written behind the bottleneck rows: one HIP launch per stream (ops.StreamInput(s)Fn)
+            pdrop = self.dropout.p if self.training else 0.0
+            seeds_in = [next_dropout_seed() if pdrop > 0 else 0 for _ in enc_outputs]          # (drawn in stream order)
+            pes = [self.positional_encoding(x.size(1) + 1) if self.use_pe[m] else None for m, x in enumerate(enc_outputs)]
+            if tuning.FUSED_INPUT_TAIL and self.bottlenecks is not None:
+                # ONE autograd node for the three streams: its backward -- the tail of the step -- is one launch + one reduction
+                meta = dict(pe=pes, seeds=seeds_in, pack=None if pack_v is None else (pack_v, kv_fused[0]),
+                            streams=None if side_in is None else [None, side_in[0], side_in[1]])
+                lns = self.layer_norms_in
+                prm = [t for m in range(3) for t in (self.cls_token_per_modality[m], lns[m].weight, lns[m].bias)]
+                add_i, add_t = time_adds if time_adds is not None else (None, None)
+                time_adds = None                       # (added inside the node)
+                streams = list(ops.StreamInputsFn.apply(enc_outputs[0], enc_outputs[1], enc_outputs[2], self.bottlenecks, add_i, add_t,
+                                                        lns[0].eps, lns[1].eps, lns[2].eps, pdrop, meta, *prm))
+            else:
+                made = {}
+                # one node per stream, the vital-sign stream's created LAST: autograd runs the three (ready together, behind the
+                # fusion stack's backward) latest-created first, and that stream's chain is the critical path of the step's tail
+                for m in [1, 2, 0] if tuning.INPUT_NODE_ORDER == "long_last" else [0, 1, 2]:
+                    x, ln = enc_outputs[m], self.layer_norms_in[m]
+                    with (torch.cuda.stream(side_in[m - 1]) if (side_in is not None and m > 0) else contextlib.nullcontext()):
+                        pk = (pack_v, kv_fused[0]) if (m == 0 and pack_v is not None) else (None, None)
+                        made[m] = ops.StreamInputFn.apply(x, self.cls_token_per_modality[m], ln.weight, ln.bias, pes[m],
+                                                          self.bottlenecks, ln.eps, pdrop, seeds_in[m], *pk)
+                streams = [made[m] for m in range(len(enc_outputs))]
+        for m, x in enumerate(enc_outputs if not fused_in else []):
             ln = self.layer_norms_in[m]
-            if fused_in:      # one HIP launch: LN + PE + dropout written behind the bottleneck rows (ops.StreamInputFn)
-                pdrop = self.dropout.p if self.training else 0.0
-                pe = self.positional_encoding(x.size(1) + 1) if self.use_pe[m] else None
-                seed = next_dropout_seed() if pdrop > 0 else 0
-                with (torch.cuda.stream(side_in[m - 1]) if (side_in is not None and m > 0) else contextlib.nullcontext()):
-                    pk = (pack_v, kv_fused[0]) if (m == 0 and pack_v is not None) else (None, None)
-                    streams.append(ops.StreamInputFn.apply(x, self.cls_token_per_modality[m], ln.weight, ln.bias, pe,
-                                                           self.bottlenecks, ln.eps, pdrop, seed, *pk))
-                continue
             x = torch.cat([self.cls_token_per_modality[m].expand(B, -1, -1).to(x.dtype), x], dim=1)
             y = F.layer_norm(x.float(), (self.d_model,), ln.weight, ln.bias, ln.eps)
             if self.use_pe[m]:

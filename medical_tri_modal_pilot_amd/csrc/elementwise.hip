@@ -171,11 +171,9 @@ __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const fl
 
 // slab row: [dgamma | dbeta | dcls | dbott[0..3]] = 7 x 256
 template <typename T>
-__global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T* x, const float* cls, const float* gamma,
-                                                            const float* stats, T* dx, float* slab, int B, int N, int nb,
-                                                            float p, unsigned seed0, const unsigned* seed_dev,
-                                                            const int* row_start, const int* kv_len) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 7 * D];              // 28 KiB
+MTMP_DEV void stream_in_bwd_body(const T* dz, const T* x, const float* cls, const float* gamma, const float* stats, T* dx, float* slab,
+                                 int B, int N, int nb, float p, unsigned seed0, const unsigned* seed_dev, const int* row_start,
+                                 const int* kv_len, int block, int nblocks, float* lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = nb + 1 + N;
     const f32x4 gm = ld4f(gamma + 4 * lane);
@@ -191,8 +189,8 @@ __global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T
     // addresses, no branch around a load) is issued before the first row is used -- one dependent load round per row made this
     // a 52 us launch on the step's tail (1.9 TB/s), where nothing else runs.  Rows are still accumulated in order (same sums).
     constexpr int PF = 2;
-    const int stride = gridDim.x * 4, nrows = B * R;
-    for (int row0 = blockIdx.x * 4 + wave; row0 < nrows; row0 += PF * stride) {
+    const int stride = nblocks * 4, nrows = B * R;
+    for (int row0 = block * 4 + wave; row0 < nrows; row0 += PF * stride) {
         int bb[PF], rr[PF];
         bool live[PF];
         f32x4 gg[PF], vv[PF];
@@ -262,7 +260,32 @@ __global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T
             }
         }
     }
-    flush_partials<7>(acc, slab + (size_t)blockIdx.x * 7 * D, lds, lane, wave);
+    flush_partials<7>(acc, slab + (size_t)block * 7 * D, lds, lane, wave);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T* x, const float* cls, const float* gamma,
+                                                            const float* stats, T* dx, float* slab, int B, int N, int nb,
+                                                            float p, unsigned seed0, const unsigned* seed_dev,
+                                                            const int* row_start, const int* kv_len) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 7 * D];              // 28 KiB
+    stream_in_bwd_body<T>(dz, x, cls, gamma, stats, dx, slab, B, N, nb, p, seed0, seed_dev, row_start, kv_len, (int)blockIdx.x,
+                          (int)gridDim.x, lds);
+}
+// The three token streams' launches as ONE grid (mtmp_stream_input_bwd_grouped): blocks [first[i], first[i+1]) run stream i's rows
+// and write stream i's rows of the partial slab; the slabs lie back to back, so the bottleneck tokens' columns sum over all of them.
+constexpr int SI_MAX = 3;
+struct StreamInSeg { const void *dz, *x; const float *cls, *gamma, *stats; void* dx; float* slab; const int *row_start, *kv_len;
+                     int B, N, nb; float p; unsigned seed; };
+struct StreamInGroup { StreamInSeg seg[SI_MAX]; int first[SI_MAX + 1]; const unsigned* seed_dev; };
+template <typename T>
+__global__ __launch_bounds__(256) void stream_in_bwd_grouped_kernel(StreamInGroup g) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 7 * D];
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < SI_MAX; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
+    const StreamInSeg& q = g.seg[i];
+    stream_in_bwd_body<T>((const T*)q.dz, (const T*)q.x, q.cls, q.gamma, q.stats, (T*)q.dx, q.slab, q.B, q.N, q.nb, q.p, q.seed,
+                          g.seed_dev, q.row_start, q.kv_len, (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], lds);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -353,9 +376,14 @@ MTMP_DEV void tie_chain_bwd(const TieChain& c, float s, const f32x4& dE, float (
 }
 
 // slab row layout: [8][256] chain grads (same order as prm) then [20][256] feature-table grads
+// Second row set (n2 > 0; mtmp_tie_time_embed_bwd_partials): rows n .. n + n2 - 1 are TIME events ev2[n2][3] (the image / text times,
+// the time chain and the table only -- their value-chain gradient counts as zero) whose gradient rows come from two tensors,
+// dE2a for the first n2a of them and dE2b for the rest: the event embedding's and the time embedding's backward as ONE launch into
+// one slab, so the shared time chain / table gradients need no add afterwards.
 template <typename T, bool VAL = true>
 __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const float* prm, const T* dE, int n, float* slab,
-                                                      const int* cu, int t_pad) {
+                                                      const int* cu, int t_pad, const float* ev2 = nullptr,
+                                                      const T* dE2a = nullptr, const T* dE2b = nullptr, int n2 = 0, int n2a = 0) {
     // Feature-table gradient: one private [20][256] table per wave (80 KiB), summed in wave order at the end.  A
     // single table with LDS float atomics (the first version) added the four waves' contributions in arrival order:
     // run-to-run 1-ulp differences in d ie_feat (found by the graph-vs-eager bit-equality test once the time
@@ -377,27 +405,38 @@ __global__ __launch_bounds__(256) void tie_bwd_kernel(const float* ev, const flo
     // CU, and one dependent global-load round per row (31 rows per wave at config 2) made this a 69 us launch on the step's
     // tail, where nothing else runs.  Rows are still accumulated in order (same sums).
     constexpr int PF = 4;
-    const int stride = gridDim.x * 4;
-    for (int row0 = blockIdx.x * 4 + wave; row0 < n; row0 += PF * stride) {
+    const int stride = gridDim.x * 4, nt = n + n2;
+    for (int row0 = blockIdx.x * 4 + wave; row0 < nt; row0 += PF * stride) {
         int e[PF];
+        bool second[PF];
         float tau[PF], val[PF], ff[PF];
         f32x4 g[PF];
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int row = row0 + k * stride;
-            e[k] = row < n ? tie_event_of_row(cu, t_pad, row) : -1;
-            const size_t eo = 3 * (size_t)max(e[k], 0);
-            tau[k] = ev[eo]; val[k] = ev[eo + 1]; ff[k] = ev[eo + 2];
-            g[k] = load4<T>(dE + (size_t)min(row, n - 1) * D + 4 * lane);
+            second[k] = row >= n && row < nt;                                   // wave-uniform
+            if (second[k]) {
+                const int r2 = row - n;
+                e[k] = r2;
+                const float* ep = ev2 + 3 * (size_t)r2;
+                tau[k] = ep[0]; val[k] = 0.f; ff[k] = ep[2];
+                g[k] = load4<T>((r2 < n2a ? dE2a + (size_t)r2 * D : dE2b + (size_t)(r2 - n2a) * D) + 4 * lane);
+            } else {
+                e[k] = row < n ? tie_event_of_row(cu, t_pad, row) : -1;
+                const size_t eo = 3 * (size_t)max(e[k], 0);
+                tau[k] = ev[eo]; val[k] = ev[eo + 1]; ff[k] = ev[eo + 2];
+                g[k] = load4<T>(dE + (size_t)min(row, n - 1) * D + 4 * lane);
+            }
         }
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             // pad row / past the end: no event -- its gradient row counts as zero (every sum below then adds +0: the same
             // values as skipping it) so that the four rows' chains are straight-line code the scheduler can interleave: with a
             // branch per row the wave ran one dependent chain of ~400 instructions per row at two waves per SIMD (79 us)
-            const f32x4 gk = e[k] < 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : g[k];
+            const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 gk = e[k] < 0 ? zero : g[k];
             const int f = min(max((int)ff[k], 0), 19);
-            if (VAL) tie_chain_bwd(cv, val[k], gk, acc, 0);
+            if (VAL) tie_chain_bwd(cv, val[k], second[k] ? zero : gk, acc, 0);
             tie_chain_bwd(ct, tau[k], gk, acc, 4);
             f32x4* tp = reinterpret_cast<f32x4*>(my_tab + f * D + 4 * lane);    // wave-private: plain read-modify-write
             f32x4 tv = *tp;
@@ -479,15 +518,24 @@ int launch_tie_fwd(int dtype, const float* events, const float* params, const fl
     MTMP_CHECK_LAUNCH(who);
     return MTMP_OK;
 }
-int launch_tie_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads, float* ws,
-                   int rows, const int* cu, int t_pad, hipStream_t st, const char* who, bool val = true) {
-    const int nb = max(1, min((rows + 3) / 4, 512));
-    if (dtype == 0 && val) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad);
-    else if (dtype == 1 && val) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad);
-    else if (dtype == 0) hipLaunchKernelGGL((tie_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad);
-    else if (dtype == 1) hipLaunchKernelGGL((tie_bwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad);
+int tie_bwd_blocks(int rows) { return max(1, min((rows + 3) / 4, 512)); }
+int launch_tie_bwd_partials(int dtype, const float* events, const float* params, const void* d_out, float* ws, int rows, const int* cu,
+                            int t_pad, hipStream_t st, const char* who, bool val, const float* ev2 = nullptr, const void* d2a = nullptr,
+                            const void* d2b = nullptr, int n2 = 0, int n2a = 0) {
+    const int nb = tie_bwd_blocks(rows + n2);
+    if (dtype == 0 && val) hipLaunchKernelGGL(tie_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad, ev2, (const float*)d2a, (const float*)d2b, n2, n2a);
+    else if (dtype == 1 && val) hipLaunchKernelGGL(tie_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad, ev2, (const bf16*)d2a, (const bf16*)d2b, n2, n2a);
+    else if (dtype == 0) hipLaunchKernelGGL((tie_bwd_kernel<float, false>), dim3(nb), dim3(256), 0, st, events, params, (const float*)d_out, rows, ws, cu, t_pad, ev2, (const float*)d2a, (const float*)d2b, n2, n2a);
+    else if (dtype == 1) hipLaunchKernelGGL((tie_bwd_kernel<bf16, false>), dim3(nb), dim3(256), 0, st, events, params, (const bf16*)d_out, rows, ws, cu, t_pad, ev2, (const bf16*)d2a, (const bf16*)d2b, n2, n2a);
     else { mtmp_set_error("%s: unknown dtype %d", who, dtype); return MTMP_ERR_ARG; }
     MTMP_CHECK_LAUNCH(who);
+    return MTMP_OK;
+}
+int launch_tie_bwd(int dtype, const float* events, const float* params, const void* d_out, float* grads, float* ws,
+                   int rows, const int* cu, int t_pad, hipStream_t st, const char* who, bool val = true) {
+    const int rc = launch_tie_bwd_partials(dtype, events, params, d_out, ws, rows, cu, t_pad, st, who, val);
+    if (rc != MTMP_OK) return rc;
+    const int nb = tie_bwd_blocks(rows);
     launch_slab_reduce(ws, nb, 28 * D, ws + (size_t)nb * 28 * D, grads, st);
     MTMP_CHECK_LAUNCH(who);
     return MTMP_OK;
@@ -545,6 +593,22 @@ extern "C" int mtmp_tie_embed_packed_bwd(int dtype, const float* events, const i
                           "mtmp_tie_embed_packed_bwd");
 }
 
+// The event embedding's and the time embedding's backward as one launch, PARTIAL slabs only: ws receives
+// [mtmp_tie_bwd_slab_rows(n + n_time)][28][256] floats (8 chain vectors in params order, then the 20 table rows), to be summed by
+// mtmp_reduce_scatter straight into the parameters' gradient slices.  time_events [n_time][3] = (time, unused, feature index);
+// d_time_a: gradient rows of the first n_time_a time events, d_time_b: of the rest (tri_mbt_vsltcls.py:216-224: image / text times).
+extern "C" int mtmp_tie_bwd_slab_rows(int n) { return tie_bwd_blocks(n); }
+extern "C" int mtmp_tie_time_embed_bwd_partials(int dtype, const float* events, int n, const float* time_events, int n_time,
+                                                int n_time_a, const float* params, const void* d_out, const void* d_time_a,
+                                                const void* d_time_b, float* ws, void* stream) {
+    MTMP_CHECK_ARG(events && params && d_out && ws && n > 0 && n_time >= 0 && n_time_a >= 0 && n_time_a <= n_time &&
+                       (n_time == 0 || time_events) && (n_time_a == 0 || d_time_a) && (n_time_a == n_time || d_time_b) &&
+                       (long long)n + n_time < (1ll << 31),
+                   "mtmp_tie_time_embed_bwd_partials: bad argument (n=%d n_time=%d n_time_a=%d)", n, n_time, n_time_a);
+    return launch_tie_bwd_partials(dtype, events, params, d_out, ws, n, nullptr, 0, (hipStream_t)stream,
+                                   "mtmp_tie_time_embed_bwd_partials", true, time_events, d_time_a, d_time_b, n_time, n_time_a);
+}
+
 extern "C" int mtmp_stream_input_ws_floats(int rows) { return (max(1, min((rows + 15) / 16, 1024)) + RED_GROUPS) * 7 * D; }
 
 // z [B, nb+1+N, 256] (dtype) from x [B, N, 256] (dtype); cls, gamma, beta [256], pe [>= N+1][256] or NULL,
@@ -574,6 +638,23 @@ extern "C" int mtmp_stream_input_fwd(int dtype, const void* x, const float* cls,
 // dx [B, N, 256] (dtype); grads float[7][256] = dgamma, dbeta, dcls, dbott[0..3] (rows past nb are zero),
 // overwritten; ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats.  row_start / kv_len: dz is PACKED as the forward's output
 // was; dx stays padded (its pad rows are written as zeros).
+namespace {
+int stream_in_bwd_blocks(int rows) { return max(1, min((rows + 15) / 16, 1024)); }
+int launch_stream_in_bwd(int dtype, const void* dz, const void* x, const float* cls, const float* gamma, const float* stats, void* dx,
+                         float* ws, int B, int N, int nb, float p, unsigned seed, const unsigned* seed_dev, const int32_t* row_start,
+                         const int32_t* kv_len, hipStream_t st, const char* who) {
+    const int nbk = stream_in_bwd_blocks(B * (nb + 1 + N));
+    if (dtype == 0)
+        hipLaunchKernelGGL(stream_in_bwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)dz, (const float*)x, cls,
+                           gamma, stats, (float*)dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(stream_in_bwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)dz, (const bf16*)x, cls,
+                           gamma, stats, (bf16*)dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len);
+    else { mtmp_set_error("%s: unknown dtype %d", who, dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH(who);
+    return MTMP_OK;
+}
+}  // namespace
 extern "C" int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, const float* cls, const float* gamma,
                                      const float* stats, void* dx, float* grads, float* ws, int B, int N, int nb, float p,
                                      unsigned seed, const unsigned* seed_dev, const int32_t* row_start, const int32_t* kv_len,
@@ -582,18 +663,109 @@ extern "C" int mtmp_stream_input_bwd(int dtype, const void* dz, const void* x, c
                        p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25) && (!row_start || kv_len),
                    "mtmp_stream_input_bwd: bad argument (B=%d N=%d nb=%d p=%f)", B, N, nb, p);
     hipStream_t st = (hipStream_t)stream;
-    const int rows = B * (nb + 1 + N), nbk = max(1, min((rows + 15) / 16, 1024));
-    if (dtype == 0)
-        hipLaunchKernelGGL(stream_in_bwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)dz, (const float*)x, cls,
-                           gamma, stats, (float*)dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len);
-    else if (dtype == 1)
-        hipLaunchKernelGGL(stream_in_bwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)dz, (const bf16*)x, cls,
-                           gamma, stats, (bf16*)dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len);
-    else { mtmp_set_error("mtmp_stream_input_bwd: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
-    MTMP_CHECK_LAUNCH("mtmp_stream_input_bwd");
+    const int rc = launch_stream_in_bwd(dtype, dz, x, cls, gamma, stats, dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len, st,
+                                        "mtmp_stream_input_bwd");
+    if (rc != MTMP_OK) return rc;
+    const int nbk = stream_in_bwd_blocks(B * (nb + 1 + N));
     launch_slab_reduce(ws, nbk, 7 * D, ws + (size_t)nbk * 7 * D, grads, st);
     MTMP_CHECK_LAUNCH("mtmp_stream_input_bwd(reduce)");
     return MTMP_OK;
+}
+// out[j, :] = sum_{t < L} dx[(j L + t), :] for up to two tensors in one launch: the gradient of a per-image / per-report vector that
+// was added to every token of its L-token group (the time + modality embedding, tri_mbt_vsltcls.py:216-224).  One workgroup per
+// output row: wave w sums tokens w, w + 4, ... in fp32, the four waves combine in a fixed order; result rounded to the tensors' type.
+namespace {
+struct TokenSums { const void* dx[2]; void* out[2]; int rows[2], L[2]; };
+template <typename T>
+__global__ __launch_bounds__(256) void token_sums_kernel(TokenSums q) {
+    __shared__ __attribute__((aligned(16))) float part[4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = (int)blockIdx.x >= q.rows[0] ? 1 : 0, j = (int)blockIdx.x - (s ? q.rows[0] : 0), L = q.L[s];
+    const T* base = (const T*)q.dx[s] + (size_t)j * L * D + 4 * lane;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    int t = wave;
+    for (; t + 4 < L; t += 8) {                                    // two rows in flight per wave
+        a0 += load4<T>(base + (size_t)t * D);
+        a1 += load4<T>(base + (size_t)(t + 4) * D);
+    }
+    if (t < L) a0 += load4<T>(base + (size_t)t * D);
+    *reinterpret_cast<f32x4*>(&part[wave][4 * lane]) = a0 + a1;
+    __syncthreads();
+    if (wave == 0) {
+        const f32x4 v = (*reinterpret_cast<const f32x4*>(&part[0][4 * lane]) + *reinterpret_cast<const f32x4*>(&part[1][4 * lane])) +
+                        (*reinterpret_cast<const f32x4*>(&part[2][4 * lane]) + *reinterpret_cast<const f32x4*>(&part[3][4 * lane]));
+        store4<T>((T*)q.out[s] + (size_t)j * D + 4 * lane, v[0], v[1], v[2], v[3]);
+    }
+}
+}  // namespace
+extern "C" int mtmp_token_sums(int dtype, int n, const void* const* dx, void* const* out, const int* rows, const int* L, void* stream) {
+    MTMP_CHECK_ARG(n > 0 && n <= 2 && dx && out && rows && L, "mtmp_token_sums: bad argument (n=%d)", n);
+    TokenSums q;
+    int total = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int k = i < n ? i : 0;
+        MTMP_CHECK_ARG(dx[k] && out[k] && rows[k] > 0 && L[k] > 0 && (long long)rows[k] * L[k] < (1ll << 25), "mtmp_token_sums: bad entry %d", k);
+        q.dx[i] = dx[k]; q.out[i] = out[k]; q.rows[i] = i < n ? rows[k] : 0; q.L[i] = L[k];
+        total += q.rows[i];
+    }
+    if (dtype == 0) hipLaunchKernelGGL(token_sums_kernel<float>, dim3(total), dim3(256), 0, (hipStream_t)stream, q);
+    else if (dtype == 1) hipLaunchKernelGGL(token_sums_kernel<bf16>, dim3(total), dim3(256), 0, (hipStream_t)stream, q);
+    else { mtmp_set_error("mtmp_token_sums: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_token_sums");
+    return MTMP_OK;
+}
+
+// The stream-input backward of up to three token streams in ONE launch, partial slabs only: ws receives the streams' slabs back to
+// back -- stream i's [mtmp_stream_input_slab_rows(B[i] * (nb[i]+1+N[i]))][7][256] floats behind those of the streams in front of it
+// -- for ONE mtmp_reduce_scatter (the bottleneck tokens' columns 768.. sum over all rows of ws when every nb[i] is the same).
+// All arrays are HOST arrays of n entries; row_start / kv_len may be NULL as a whole or per entry.
+extern "C" int mtmp_stream_input_bwd_grouped(int dtype, int n, const void* const* dz, const void* const* x, const float* const* cls,
+                                             const float* const* gamma, const float* const* stats, void* const* dx, float* ws,
+                                             const int* B, const int* N, const int* nb, const float* p, const unsigned* seed,
+                                             const unsigned* seed_dev, const int32_t* const* row_start,
+                                             const int32_t* const* kv_len, void* stream) {
+    MTMP_CHECK_ARG(n > 0 && n <= SI_MAX && dz && x && cls && gamma && stats && dx && ws && B && N && nb && p && seed,
+                   "mtmp_stream_input_bwd_grouped: bad argument (n=%d)", n);
+    StreamInGroup g;
+    g.seed_dev = seed_dev;
+    int total = 0;
+    for (int i = 0; i < SI_MAX; ++i) {
+        const int k = i < n ? i : 0;
+        if (i < n) {
+            const int32_t* rs = row_start ? row_start[k] : nullptr;
+            const int32_t* kv = kv_len ? kv_len[k] : nullptr;
+            MTMP_CHECK_ARG(dz[k] && x[k] && cls[k] && gamma[k] && stats[k] && dx[k] && B[k] > 0 && N[k] > 0 && nb[k] >= 0 &&
+                               nb[k] <= NB_MAX && p[k] >= 0.f && p[k] < 1.f && (long long)B[k] * (nb[k] + 1 + N[k]) < (1ll << 25) &&
+                               (!rs || kv),
+                           "mtmp_stream_input_bwd_grouped: bad stream %d (B=%d N=%d nb=%d p=%f)", k, B[k], N[k], nb[k], p[k]);
+            g.seg[i] = StreamInSeg{dz[k], x[k], cls[k], gamma[k], stats[k], dx[k], ws + (size_t)total * 7 * D, rs, kv,
+                                   B[k], N[k], nb[k], p[k], seed[k]};
+            g.first[i] = total;
+            total += stream_in_bwd_blocks(B[k] * (nb[k] + 1 + N[k]));
+        } else {
+            g.seg[i] = g.seg[0];
+            g.first[i] = total;                    // (empty: no block index reaches it)
+        }
+    }
+    g.first[SI_MAX] = total;
+    if (dtype == 0) hipLaunchKernelGGL(stream_in_bwd_grouped_kernel<float>, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    else if (dtype == 1) hipLaunchKernelGGL(stream_in_bwd_grouped_kernel<bf16>, dim3(total), dim3(256), 0, (hipStream_t)stream, g);
+    else { mtmp_set_error("mtmp_stream_input_bwd_grouped: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_stream_input_bwd_grouped");
+    return MTMP_OK;
+}
+// The same launch, PARTIAL slabs only: ws receives [mtmp_stream_input_slab_rows(B * (nb+1+N))][7][256] floats (dgamma, dbeta, dcls,
+// dbott[0..3]) for mtmp_reduce_scatter.
+extern "C" int mtmp_stream_input_slab_rows(int rows) { return stream_in_bwd_blocks(rows); }
+extern "C" int mtmp_stream_input_bwd_partials(int dtype, const void* dz, const void* x, const float* cls, const float* gamma,
+                                              const float* stats, void* dx, float* ws, int B, int N, int nb, float p, unsigned seed,
+                                              const unsigned* seed_dev, const int32_t* row_start, const int32_t* kv_len,
+                                              void* stream) {
+    MTMP_CHECK_ARG(dz && x && cls && gamma && stats && dx && ws && B > 0 && N > 0 && nb >= 0 && nb <= NB_MAX &&
+                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25) && (!row_start || kv_len),
+                   "mtmp_stream_input_bwd_partials: bad argument (B=%d N=%d nb=%d p=%f)", B, N, nb, p);
+    return launch_stream_in_bwd(dtype, dz, x, cls, gamma, stats, dx, ws, B, N, nb, p, seed, seed_dev, row_start, kv_len,
+                                (hipStream_t)stream, "mtmp_stream_input_bwd_partials");
 }
 
 // In-place AdamW step over flat fp32 buffers of n elements (n % 4 == 0); bf16_shadow may be null.

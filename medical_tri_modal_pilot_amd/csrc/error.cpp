@@ -12,4 +12,4 @@ void mtmp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mtmp_last_error(void) { return g_err; }
-extern "C" int mtmp_abi_version(void) { return 5; }
+extern "C" int mtmp_abi_version(void) { return 6; }

@@ -1315,15 +1315,18 @@ __global__ __launch_bounds__(512, 1) void gemm_tn_dma_kernel(Grouped<TnArgs<bf16
 // split_e go to a_e, the rest to b_e (the weight / bias gradient of a split-M product share a slab row).  A layer's backward
 // produced seven of these reductions (3 weight gradients, 2 x 2 levels of LayerNorm gamma / beta partials): seven launches of
 // 5-13 us each on the vital-sign stream, and worse on the image / text streams, whose launches wait for a free CU.
-constexpr int RB_MAX = 8;
-struct ReduceBatch { const float* slab[RB_MAX]; float* a[RB_MAX]; float* b[RB_MAX]; long long cols[RB_MAX], split[RB_MAX]; int rows[RB_MAX]; };
+// ld_e: floats between two rows of slab_e (= cols_e for a whole slab; larger when the entry is a column range of a wider slab --
+// mtmp_reduce_scatter: one slab's column ranges summed straight into separate destinations, e.g. slices of the flat gradient).
+constexpr int RB_MAX = 12;
+struct ReduceBatch { const float* slab[RB_MAX]; float* a[RB_MAX]; float* b[RB_MAX]; long long cols[RB_MAX], split[RB_MAX], ld[RB_MAX]; int rows[RB_MAX]; };
 __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch t) {
     __shared__ f32x4 part4[4][64];
     const int e = blockIdx.y;
     const long long cols = t.cols[e];
     const int rows = t.rows[e], rl = threadIdx.x >> 6, cl = threadIdx.x & 63;
     const float* slab = t.slab[e];
-    if ((cols & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
+    const size_t ld = (size_t)t.ld[e];
+    if ((cols & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)slab & 15) == 0) {
         // four columns per thread (16-byte loads, four rows in flight per row lane); the slabs are the bulk of a layer's
         // reduction traffic and 4-byte loads kept this launch at ~1.6 TB/s.  Row lanes per block by the slab's height: the
         // LayerNorm partials (one row per 128 tokens: 503 rows of 512 columns at config 2) would otherwise be two blocks walking
@@ -1338,12 +1341,12 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch t) {
                 const float* col = slab + c;
                 int q = rl4;
                 for (; q + 3 * RL < rows; q += 4 * RL) {
-                    s0 += ld4f(col + (size_t)q * cols);
-                    s1 += ld4f(col + (size_t)(q + RL) * cols);
-                    s2 += ld4f(col + (size_t)(q + 2 * RL) * cols);
-                    s3 += ld4f(col + (size_t)(q + 3 * RL) * cols);
+                    s0 += ld4f(col + (size_t)q * ld);
+                    s1 += ld4f(col + (size_t)(q + RL) * ld);
+                    s2 += ld4f(col + (size_t)(q + 2 * RL) * ld);
+                    s3 += ld4f(col + (size_t)(q + 3 * RL) * ld);
                 }
-                for (; q < rows; q += RL) s0 += ld4f(col + (size_t)q * cols);
+                for (; q < rows; q += RL) s0 += ld4f(col + (size_t)q * ld);
             }
             __syncthreads();
             part[rl4 * CQ + cq] = (s0 + s1) + (s2 + s3);
@@ -1367,12 +1370,12 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(ReduceBatch t) {
         if (c < cols) {
             int q = rl;
             for (; q + 12 < rows; q += 16) {                      // four independent loads in flight per row lane
-                s0 += slab[(size_t)q * cols + c];
-                s1 += slab[(size_t)(q + 4) * cols + c];
-                s2 += slab[(size_t)(q + 8) * cols + c];
-                s3 += slab[(size_t)(q + 12) * cols + c];
+                s0 += slab[(size_t)q * ld + c];
+                s1 += slab[(size_t)(q + 4) * ld + c];
+                s2 += slab[(size_t)(q + 8) * ld + c];
+                s3 += slab[(size_t)(q + 12) * ld + c];
             }
-            for (; q < rows; q += 4) s0 += slab[(size_t)q * cols + c];
+            for (; q < rows; q += 4) s0 += slab[(size_t)q * ld + c];
         }
         __syncthreads();
         part[rl][cl] = (s0 + s1) + (s2 + s3);
@@ -1742,6 +1745,7 @@ int launch_gemm_tn(const void* dy, const void* x, float* dw, float* db, float* w
     ReduceBatch t;                                            // the same kernel (and summation order) as the deferred form
     for (int i = 0; i < RB_MAX; ++i) {
         t.slab[i] = ws; t.a[i] = dw; t.b[i] = db; t.cols[i] = (long long)cols; t.split[i] = (long long)nk; t.rows[i] = splits;
+        t.ld[i] = (long long)cols;
     }
     const int rlanes = splits >= 256 ? 64 : splits >= 64 ? 16 : 4;
     const size_t blocks = (cols + 4 * (256 / rlanes) - 1) / (4 * (256 / rlanes));
@@ -1945,16 +1949,18 @@ extern "C" int mtmp_gemm_lnbwd(int dtype, const void* dy, const void* wt, const 
 // NULL).  All arrays are HOST arrays of n entries.
 extern "C" int mtmp_gemm_tn_slab_rows(int dtype, int M, int N, int K) { return tn_launch_splits(dtype == 1, M, N, K, nullptr); }
 extern "C" int mtmp_gemm_lnbwd_slab_rows(int M) { return (M + 127) / 128; }
-extern "C" int mtmp_reduce_batch(const float* const* slab, const int* rows, const long long* cols, float* const* out_a,
-                                 const long long* split, float* const* out_b, int n, void* stream) {
-    MTMP_CHECK_ARG(slab && rows && cols && out_a && split && out_b && n > 0 && n <= RB_MAX, "mtmp_reduce_batch: bad argument (n=%d)", n);
+namespace {
+int launch_reduce_batch(const float* const* slab, const int* rows, const long long* cols, const long long* ld, float* const* out_a,
+                        const long long* split, float* const* out_b, int n, hipStream_t st, const char* who) {
     ReduceBatch t;
     long long most = 0;
     for (int i = 0; i < RB_MAX; ++i) {
         const int k = i < n ? i : 0;
-        MTMP_CHECK_ARG(slab[k] && out_a[k] && rows[k] > 0 && cols[k] > 0 && split[k] >= 0 && split[k] <= cols[k] &&
-                           (split[k] == cols[k] || out_b[k] || true), "mtmp_reduce_batch: bad entry %d", k);
-        t.slab[i] = slab[k]; t.a[i] = out_a[k]; t.b[i] = out_b[k]; t.cols[i] = cols[k]; t.split[i] = split[k]; t.rows[i] = rows[k];
+        const long long ldk = ld ? ld[k] : cols[k];
+        MTMP_CHECK_ARG(slab[k] && out_a[k] && rows[k] > 0 && cols[k] > 0 && split[k] >= 0 && split[k] <= cols[k] && ldk >= cols[k],
+                       "%s: bad entry %d", who, k);
+        t.slab[i] = slab[k]; t.a[i] = out_a[k]; t.b[i] = out_b ? out_b[k] : nullptr; t.cols[i] = cols[k]; t.split[i] = split[k];
+        t.rows[i] = rows[k]; t.ld[i] = ldk;
         most = most > cols[k] ? most : cols[k];
     }
     long long blocks = (most + 255) / 256;
@@ -1963,9 +1969,25 @@ extern "C" int mtmp_reduce_batch(const float* const* slab, const int* rows, cons
         const long long need = (cols[i] + 4 * (256 / rl) - 1) / (4 * (256 / rl));
         blocks = blocks > need ? blocks : need;
     }
-    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), n), dim3(256), 0, (hipStream_t)stream, t);
-    MTMP_CHECK_LAUNCH("mtmp_reduce_batch");
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks), n), dim3(256), 0, st, t);
+    MTMP_CHECK_LAUNCH(who);
     return MTMP_OK;
+}
+}  // namespace
+extern "C" int mtmp_reduce_batch(const float* const* slab, const int* rows, const long long* cols, float* const* out_a,
+                                 const long long* split, float* const* out_b, int n, void* stream) {
+    MTMP_CHECK_ARG(slab && rows && cols && out_a && split && out_b && n > 0 && n <= RB_MAX, "mtmp_reduce_batch: bad argument (n=%d)", n);
+    return launch_reduce_batch(slab, rows, cols, nullptr, out_a, split, out_b, n, (hipStream_t)stream, "mtmp_reduce_batch");
+}
+// Column ranges of partial slabs summed straight into separate destinations, up to 12 per launch: out[i][c] = sum_r src[i][r * ld[i]
+// + c] for c < cols[i], where src[i] points at the first column of the range inside its slab and ld[i] is the slab's row length.
+// The input nodes' backward (mtmp_stream_input_bwd_partials, mtmp_tie_time_embed_bwd_partials) ends in ONE of these launches that
+// writes every parameter's slice of the flat gradient -- instead of two reduction levels, a multi-tensor copy and the gradient
+// accumulations of shared parameters (11 launches of ~5 us on the step's tail).  All arrays are HOST arrays of n entries.
+extern "C" int mtmp_reduce_scatter(const float* const* src, const int* rows, const long long* ld, const long long* cols,
+                                   float* const* out, int n, void* stream) {
+    MTMP_CHECK_ARG(src && rows && ld && cols && out && n > 0 && n <= RB_MAX, "mtmp_reduce_scatter: bad argument (n=%d)", n);
+    return launch_reduce_batch(src, rows, cols, ld, out, cols, nullptr, n, (hipStream_t)stream, "mtmp_reduce_scatter");
 }
 
 extern "C" long long mtmp_gemm_tn_ws_floats(int M, int N, int K) {

@@ -660,6 +660,32 @@ def sink_param_grads(params, grads):
     return [None] * len(grads)
 
 
+def _sink_dsts(params):
+    """(flat, idx, dsts): the slices of optim.FlatParams' flat gradient buffer a kernel may OVERWRITE for these parameters (claimed
+    as sink_param_grads claims them; call flat.mark_ready(idx) behind the launch), or None -> hand the gradients to autograd."""
+    flat = getattr(params[0], "_mtmp_flat", None) if params else None
+    if flat is None or any(getattr(q, "_mtmp_flat", None) is not flat or id(q) not in flat.index_of for q in params):
+        return None
+    idx = [flat.index_of[id(q)] for q in params]
+    if not flat.claim(idx):
+        return None
+    return flat, idx, [flat.grad[flat.offsets[i]:flat.offsets[i] + flat.params[i].numel()] for i in idx]
+
+
+REDUCE_SCATTER_MAX = 12
+
+
+def reduce_scatter(entries):
+    """Column ranges of partial slabs summed straight into their destinations, twelve per launch (mtmp_reduce_scatter):
+    entries (slab [rows, ld] fp32 contiguous, rows, col0, ncols, dst fp32 contiguous with >= ncols elements)."""
+    for i in range(0, len(entries), REDUCE_SCATTER_MAX):
+        ch = entries[i:i + REDUCE_SCATTER_MAX]
+        n = len(ch)
+        PV, IV, LV = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
+        call("mtmp_reduce_scatter", PV(*[e[0].data_ptr() + 4 * e[2] for e in ch]), IV(*[e[1] for e in ch]),
+             LV(*[e[0].shape[-1] for e in ch]), LV(*[e[3] for e in ch]), PV(*[e[4].data_ptr() for e in ch]), n, _stream())
+
+
 # ----------------------------------------------------------------------------- TIE embedding
 class TieEmbed(torch.autograd.Function):
     """tri_mbt_vsltcls.py:183-190.  events [B,T,3] fp32 (already rounded through fp16 by the
@@ -750,6 +776,24 @@ class TieTimeEmbed(torch.autograd.Function):
     def backward(ctx, d_out, d_it, d_tt):
         ev, te, prm = ctx.saved_tensors
         dev, lib = ev.device, _lib.lib()
+        n, n2, n_img = ev.shape[0], te.shape[0], ctx.n_img
+        have_time = (n_img == 0 or d_it is not None) and (n2 == n_img or d_tt is not None)
+        sk = _sink_dsts(ctx.prm) if (d_out is not None and have_time and tuning.FUSED_INPUT_TAIL) else None
+        if sk is not None:
+            # ONE launch over the events and the image / text times into one slab, ONE launch that sums the slab into the nine
+            # parameters' slices of the flat gradient: this is the step's tail, where nothing else runs
+            flat, idx, dsts = sk
+            d_out = _c(d_out)
+            d_a = None if d_it is None else _c(d_it.to(ctx.dtype))
+            d_b = None if d_tt is None else _c(d_tt.to(ctx.dtype))
+            rows = lib.mtmp_tie_bwd_slab_rows(n + n2)
+            ws = torch.empty(rows, 28 * D_MODEL, dtype=torch.float32, device=dev)
+            call("mtmp_tie_time_embed_bwd_partials", _dt(d_out), _p(ev), n, _p(te), n2, n_img, _p(prm), _p(d_out), _p(d_a), _p(d_b),
+                 _p(ws), _stream())
+            ent = [(ws, rows, k * D_MODEL, D_MODEL, dsts[k]) for k in range(8)] + [(ws, rows, 8 * D_MODEL, 20 * D_MODEL, dsts[8])]
+            reduce_scatter(ent)
+            flat.mark_ready(idx)
+            return (None,) * 13
         g = None
         if d_it is not None or d_tt is not None:
             n, n_img = te.shape[0], ctx.n_img
@@ -1108,6 +1152,24 @@ class StreamInputFn(torch.autograd.Function):
         B, N, nb, p, seed, cls_shape, bott_shape = ctx.meta
         dz = _c(dz)
         dx = torch.empty_like(x)
+        sk = _sink_dsts(ctx.prm) if tuning.FUSED_INPUT_TAIL else None
+        if sk is not None:
+            # partial slab + ONE launch that sums its column ranges into the parameters' slices of the flat gradient (the bottleneck
+            # tokens' share, which other streams add to, into a tensor for autograd)
+            flat, idx, (d_cls, d_g, d_b) = sk
+            rows = _lib.lib().mtmp_stream_input_slab_rows(B * (nb + 1 + N))
+            ws = torch.empty(rows, 7 * D_MODEL, dtype=torch.float32, device=x.device)
+            call("mtmp_stream_input_bwd_partials", _dt(x), _p(dz), _p(x), _p(cls_f), _p(g_f), _p(stats), _p(dx), _p(ws),
+                 B, N, nb, p, seed, _p(_seed_word), _p(ctx.pack[0]), _p(ctx.pack[1]), _stream())
+            ent = [(ws, rows, 0, D_MODEL, d_g), (ws, rows, D_MODEL, D_MODEL, d_b), (ws, rows, 2 * D_MODEL, D_MODEL, d_cls)]
+            d_bott = None
+            if bott_shape is not None:
+                dst = torch.empty(nb * D_MODEL, dtype=torch.float32, device=x.device)
+                d_bott = dst.view(bott_shape)
+                ent.append((ws, rows, 3 * D_MODEL, nb * D_MODEL, dst))
+            reduce_scatter(ent)
+            flat.mark_ready(idx)
+            return dx, None, None, None, None, d_bott, None, None, None, None, None
         grads = torch.empty(7, D_MODEL, dtype=torch.float32, device=x.device)
         ws = torch.empty(_lib.lib().mtmp_stream_input_ws_floats(B * (nb + 1 + N)), dtype=torch.float32, device=x.device)
         call("mtmp_stream_input_bwd", _dt(x), _p(dz), _p(x), _p(cls_f), _p(g_f), _p(stats), _p(dx), _p(grads), _p(ws),
@@ -1115,6 +1177,112 @@ class StreamInputFn(torch.autograd.Function):
         d_bott = None if bott_shape is None else grads[3:3 + nb].view(bott_shape)
         gc, gw, gb = sink_param_grads(ctx.prm, [grads[2].view(cls_shape), grads[0], grads[1]])
         return dx, gc, gw, gb, None, d_bott, None, None, None, None, None
+
+
+class StreamInputsFn(torch.autograd.Function):
+    """StreamInputFn of the three token streams as ONE autograd node: apply(x_v, x_i, x_t, bott, add_i, add_t, eps_v, eps_i, eps_t, p,
+    meta, cls_v, w_v, b_v, cls_i, w_i, b_i, cls_t, w_t, b_t) -> (z_v, z_i, z_t); meta = dict(pe=[pe_v, pe_i, pe_t], seeds=[...],
+    streams=[None, side0, side1] | None, pack=(row_starts, kv_len) | None for stream 0).  add_i [n_i, 256] / add_t [n_t, 256]
+    (or None): the time + modality embedding of every image / report (tri_mbt_vsltcls.py:216-224), added here to each token of its
+    group (n_i groups of N_i / (n_i / B) tokens) instead of by a torch add in the model.  The forward is the three launches of
+    StreamInputFn, each on its stream.  The BACKWARD is the tail of a training step, where nothing else runs: as three nodes (and
+    two add nodes) it was three chains of (kernel, two reduction levels, multi-tensor copy), two token-axis sums and two
+    accumulation launches for the bottleneck tokens, spread over the replayed graph's queues by the runtime; here it is ONE launch
+    over the three streams' rows (mtmp_stream_input_bwd_grouped), ONE mtmp_reduce_scatter that writes the ten gradients' slices of
+    the flat buffer and ONE mtmp_token_sums, all on the caller's stream, in front of the embeddings' backward."""
+
+    @staticmethod
+    def forward(ctx, x_v, x_i, x_t, bott, add_i, add_t, eps_v, eps_i, eps_t, p, meta, *prm):
+        xs, epss, adds = [x_v, x_i, x_t], [eps_v, eps_i, eps_t], [None, add_i, add_t]
+        _gpu(*xs)
+        nb = bott.shape[-2]
+        bott_f = _c(bott.detach().float().view(nb, D_MODEL))
+        streams = meta.get("streams") or [None, None, None]
+        outs, saved, geo = [], [], []
+        for m in range(3):
+            cls, ln_w, ln_b = prm[3 * m:3 * m + 3]
+            with (torch.cuda.stream(streams[m]) if streams[m] is not None else contextlib.nullcontext()):
+                x = xs[m]
+                B, N, _ = x.shape
+                n_add = 0
+                if adds[m] is not None:
+                    n_add = adds[m].shape[0]
+                    if n_add % B or N % (n_add // B):
+                        raise ValueError("StreamInputsFn: the time embeddings do not divide the stream's tokens")
+                    x = (x.reshape(n_add, N // (n_add // B), D_MODEL) + adds[m].to(x.dtype).unsqueeze(1)).view(B, N, D_MODEL)
+                x = _c(x)
+                cls_f, g_f, b_f = _c(cls.detach().float().view(-1)), _c(ln_w.detach().float()), _c(ln_b.detach().float())
+                pe = meta["pe"][m]
+                pe_f = None if pe is None else _c(pe.float().view(-1, D_MODEL))
+                if pe_f is not None and pe_f.shape[0] < N + 1:
+                    raise ValueError("positional table shorter than the stream")
+                pack, kv = meta["pack"] if (m == 0 and meta.get("pack") is not None) else (None, None)
+                out = torch.empty(B, nb + 1 + N, D_MODEL, dtype=x.dtype, device=x.device)
+                stats = torch.empty(B * (N + 1), 2, dtype=torch.float32, device=x.device)
+                seed = int(meta["seeds"][m]) & 0xFFFFFFFF
+                call("mtmp_stream_input_fwd", _dt(x), _p(x), _p(cls_f), _p(g_f), _p(b_f), _p(pe_f), _p(bott_f), _p(out), _p(stats),
+                     B, N, nb, float(epss[m]), float(p), seed, _p(_seed_word), _p(pack), _p(kv), _stream())
+            outs.append(out)
+            saved += [x, cls_f, g_f, stats]
+            geo.append((B, N, seed, pack, kv, n_add))
+        ctx.save_for_backward(*saved)
+        ctx.meta = (nb, float(p), geo, bott.shape, [t.shape for t in prm])
+        ctx.prm = list(prm) + [bott]
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dzs):
+        sv = ctx.saved_tensors
+        nb, p, geo, bott_shape, pshapes = ctx.meta
+        lib = _lib.lib()
+        live = [m for m in range(3) if dzs[m] is not None]
+        if not live:
+            return (None,) * (11 + 9)
+        dev = sv[0].device
+        xs = [sv[4 * m] for m in range(3)]
+        dxs = [torch.empty_like(xs[m]) if m in live else None for m in range(3)]
+        rows = [lib.mtmp_stream_input_slab_rows(geo[m][0] * (nb + 1 + geo[m][1])) for m in live]
+        ws = torch.empty(sum(rows), 7 * D_MODEL, dtype=torch.float32, device=dev)
+        dz = [_c(dzs[m]) for m in live]
+        n = len(live)
+        PV, IV, FV, UV = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_float * n, ctypes.c_uint * n
+        call("mtmp_stream_input_bwd_grouped", _dt(xs[live[0]]), n, PV(*[t.data_ptr() for t in dz]), PV(*[xs[m].data_ptr() for m in live]),
+             PV(*[sv[4 * m + 1].data_ptr() for m in live]), PV(*[sv[4 * m + 2].data_ptr() for m in live]),
+             PV(*[sv[4 * m + 3].data_ptr() for m in live]), PV(*[dxs[m].data_ptr() for m in live]), _p(ws),
+             IV(*[geo[m][0] for m in live]), IV(*[geo[m][1] for m in live]), IV(*([nb] * n)), FV(*([p] * n)),
+             UV(*[geo[m][2] for m in live]), _p(_seed_word), PV(*[None if geo[m][3] is None else geo[m][3].data_ptr() for m in live]),
+             PV(*[None if geo[m][4] is None else geo[m][4].data_ptr() for m in live]), _stream())
+        # the time embeddings' gradient: sums over each group's tokens (both tensors in one launch), for the embedding node behind
+        d_add = [None, None, None]
+        ts = [m for m in live if geo[m][5] > 0 and ctx.needs_input_grad[3 + m]]
+        if ts:
+            for m in ts:
+                d_add[m] = torch.empty(geo[m][5], D_MODEL, dtype=xs[m].dtype, device=dev)
+            k = len(ts)
+            call("mtmp_token_sums", _dt(xs[ts[0]]), k, (ctypes.c_void_p * k)(*[dxs[m].data_ptr() for m in ts]),
+                 (ctypes.c_void_p * k)(*[d_add[m].data_ptr() for m in ts]), (ctypes.c_int * k)(*[geo[m][5] for m in ts]),
+                 (ctypes.c_int * k)(*[geo[m][0] * geo[m][1] // geo[m][5] for m in ts]), _stream())
+        sk = _sink_dsts(ctx.prm) if n == 3 else None
+        if sk is not None:
+            dsts = sk[2]
+        else:                                        # gradients for autograd (a plain optimizer, or slices that cannot be overwritten)
+            dsts = [torch.zeros(t.numel(), dtype=torch.float32, device=dev) for t in ctx.prm]
+        ent, r0 = [], 0
+        for k, m in enumerate(live):
+            sl = ws[r0:r0 + rows[k]]
+            r0 += rows[k]
+            ent += [(sl, rows[k], 0, D_MODEL, dsts[3 * m + 1]), (sl, rows[k], D_MODEL, D_MODEL, dsts[3 * m + 2]),
+                    (sl, rows[k], 2 * D_MODEL, D_MODEL, dsts[3 * m])]
+        ent.append((ws, ws.shape[0], 3 * D_MODEL, nb * D_MODEL, dsts[9]))
+        reduce_scatter(ent)
+        if sk is not None:
+            sk[0].mark_ready(sk[1])
+            pg, d_bott = [None] * 9, None
+        else:
+            pg = [dsts[i].view(pshapes[i]) if (i // 3) in live else None for i in range(9)]
+            d_bott = dsts[9].view(bott_shape)
+        return (dxs[0], dxs[1], dxs[2], d_bott, d_add[1], d_add[2], None, None, None, None, None, *pg)
 
 
 # ----------------------------------------------------------------------------- encoder layer

@@ -29,3 +29,11 @@ STREAM_ISSUE_ORDER_FWD = (0, 1, 2)
 STREAM_ISSUE_ORDER_BWD = (0, 1, 2)
 # builder/trainer: model.prefork() forks the frozen image encoder's stream at the head of the step, before zero_grad (-0.15 ms).
 PREFORK_IMAGE_ENCODER = True
+# mbt_encoder: the autograd node of the vital-sign stream's input kernel is created after the two short streams' ("long_last"), so
+# that the backward issues it FIRST (autograd runs ready nodes latest-created first): the tail of the step is that stream's chain.
+# "stream_order" = the order of round 4 (vital signs created first, issued last).  Measured in DESIGN section 7a.
+INPUT_NODE_ORDER = "long_last"
+# ops.StreamInputFn / ops.TieTimeEmbed backward: partial slabs + ONE mtmp_reduce_scatter launch that writes the parameters' slices of
+# the flat gradient (the event and time embeddings' backward as one launch, the bottleneck tokens' gradient through ops.BottSink)
+# instead of two reduction levels, a multi-tensor copy and the accumulation launches of the shared parameters per node.
+FUSED_INPUT_TAIL = True

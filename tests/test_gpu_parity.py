@@ -2579,9 +2579,11 @@ def test_layer_with_ffn_on_read_rows_only(ops, Ns, lens):
 
 
 def test_joint_embedding_node_equals_separate_nodes(ops, monkeypatch):
-    """ops.TieTimeEmbed (event embedding + image / text time embeddings as one autograd node: one sum of the shared ie_time /
-    ie_feat gradients, one multi-tensor copy into the flat buffer) against ops.TieEmbed + ops.TimeEmbed through autograd's own
-    accumulation: same kernels, a two-operand sum either way -> bit-identical losses and parameters (bf16 replayed, fp32 eager)."""
+    """ops.TieTimeEmbed (event embedding + image / text time embeddings as one autograd node whose backward is ONE launch over the
+    events and the image / text times and one mtmp_reduce_scatter into the flat gradient) against ops.TieEmbed + ops.TimeEmbed
+    through autograd's own accumulation: the shared ie_time / ie_feat gradients are summed in another order (one slab instead of
+    two sums added afterwards), so losses and parameters agree to rounding, not bit for bit (bf16 replayed, fp32 eager; three
+    AdamW steps at lr <= 1e-4: an element whose gradient is rounding noise may move by 2 lr either way)."""
     import importlib
     cls = importlib.import_module("medical_tri_modal_pilot_amd.builder.models.8_missing_models.tri_mbt_vsltcls").TRI_MBT_VSLTCLS
     lens = [[96, 50, 7, 1], [96, 96, 96, 96], [3, 96, 20, 64]]
@@ -2590,12 +2592,14 @@ def test_joint_embedding_node_equals_separate_nodes(ops, monkeypatch):
         monkeypatch.setattr(cls, "joint_embeddings", joint)
         for graph, dtype in ((1, "bf16"), (0, "fp32")):
             res[joint, graph, dtype] = _loop(graph, 0.0, dtype, 3, lens)[:2]
+    worst_l = worst_p = 0.0
     for graph, dtype in ((1, "bf16"), (0, "fp32")):
-        if True:
-            a, b = res[True, graph, dtype], res[False, graph, dtype]
-            assert a[0] == b[0], (graph, dtype, a[0], b[0])
-            assert torch.equal(a[1], b[1]), (graph, dtype, float((a[1] - b[1]).abs().max()))
-    REPORT["joint_embedding_node"] = {"rel_err": 0.0, "tol": 0.0}
+        a, b = res[True, graph, dtype], res[False, graph, dtype]
+        worst_l = max(worst_l, max(abs(x - y) for x, y in zip(a[0], b[0])))
+        worst_p = max(worst_p, float((a[1] - b[1]).abs().max()))
+    REPORT["joint_embedding_node.loss"] = {"rel_err": worst_l, "tol": 1e-5}
+    REPORT["joint_embedding_node.params"] = {"rel_err": worst_p, "tol": 2e-4}
+    assert worst_l < 1e-5 and worst_p < 2e-4, (worst_l, worst_p)
 
 
 def test_packed_training_steps_equal_padded_steps(ops):

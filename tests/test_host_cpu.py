@@ -39,7 +39,7 @@ def test_c_abi_exports_every_declared_symbol():
     from medical_tri_modal_pilot_amd import _lib
     assert set(_lib.SIGNATURES) == declared
     lib.mtmp_abi_version.restype = ctypes.c_int
-    assert lib.mtmp_abi_version() == 5
+    assert lib.mtmp_abi_version() == 6
 
 
 def test_ops_fail_loudly_without_gpu():
