@@ -244,6 +244,12 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const T* qkv, const T* 
 //   * out^T += W2[:, panel] H accumulates over the panels; the epilogue adds b2, rounds, applies the per-image
 //     StochasticDepth factor and the residual exactly like mtmp_gemm_nt's epilogue, through a wave-private LDS tile so
 //     that HBM sees 64-byte row pieces.
+#ifdef MTMP_LAB_CLOCK                                         // lab builds only (tools/dbg/swin_mlp_clock.py): s_memtime stamps of every 8th workgroup
+__device__ long long mtmp_dbg_swin_stamps[256 * 4 * 32];
+#define MLP_STAMP(k) do { if ((blockIdx.x & 7) == 0 && blockIdx.x < 2048 && lane == 0 && (k) < 32) mtmp_dbg_swin_stamps[((blockIdx.x >> 3) * 4 + wave) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MLP_STAMP(k) do {} while (0)
+#endif
 template <int C, int HP> struct MlpGeom {
     static constexpr int KC = C / 16, OG = C / 32, HG = HP / 32, NPAN = 4 * C / HP;
     static constexpr int LD1 = C + 8, LD2 = HP + 8;               // LDS row strides (elements): 16 B pad, conflict-free b128 reads
@@ -251,8 +257,10 @@ template <int C, int HP> struct MlpGeom {
     static constexpr int CPR1 = C / 8, CPR2 = HP / 8;             // 16-byte chunks per panel row
     static constexpr int L1 = HP * CPR1 / 256, L2 = C * CPR2 / 256;   // loads per thread (3 + 3 for both shapes)
     static constexpr int FS = 40;                                 // staging row: 32 features + 16 B pad
-    static constexpr size_t lds_bytes = (size_t)(2 * (P1 + P2) + 4 * 32 * FS) * sizeof(bf16);
+    static constexpr size_t b1_off = (size_t)(2 * (P1 + P2) + 4 * 32 * FS) * sizeof(bf16);   // fc1's bias, 4 C floats
+    static constexpr size_t lds_bytes = b1_off + (size_t)4 * C * sizeof(float);
     static_assert(HP * CPR1 % 256 == 0 && C * CPR2 % 256 == 0, "panel chunks must divide over 256 threads");
+    static_assert(b1_off % 16 == 0, "bias block must be 16-byte aligned");
 };
 template <int C, int HP> struct MlpRegs { u32x4_t a[MlpGeom<C, HP>::L1], b[MlpGeom<C, HP>::L2]; };
 
@@ -297,10 +305,13 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const f
     bf16* sP = reinterpret_cast<bf16*>(smem_raw);                                  // [2][P1 + P2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, half = lane >> 5;
     bf16* sS = sP + 2 * (G::P1 + G::P2) + wave * 32 * G::FS;                       // wave-private [32][FS]
+    float* sB1 = reinterpret_cast<float*>(smem_raw + G::b1_off);                   // fc1's bias (read per hidden group in the loop)
     const long long m_wave = (long long)blockIdx.x * 128 + wave * 32;
     const long long row = min(m_wave + r, M - 1);
     MlpRegs<C, HP> preg;
+    MLP_STAMP(0);
     mlp_fetch<C, HP>(preg, w1, w2, 0, tid);
+    for (int i = tid; i < 4 * C; i += 256) sB1[i] = b1[i];                         // (visible behind the barrier in front of the loop)
     // ---- LayerNorm prologue in registers: lane (r, half) holds channels 16c + 8 half + j of token r
     Frag<bf16> af[G::KC];
     const bf16* xrow = x + row * C + 8 * half;
@@ -331,47 +342,87 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const f
             af[c].v[i + 4] = from_f32<bf16>(fmaf((to_f32(af[c].v[i + 4]) - mean) * rstd, g1[i], o1[i]));
         }
     }
+    MLP_STAMP(1);
     mlp_commit<C, HP>(sP, sP + G::P1, preg, tid);
     mlp_fetch<C, HP>(preg, w1, w2, 1, tid);
     f32x16 acc2[G::OG];
 #pragma unroll
     for (int o = 0; o < G::OG; ++o) acc2[o] = f32x16{0};
     __syncthreads();
+    MLP_STAMP(2);
     for (int j = 0; j < G::NPAN; ++j) {
         const bf16* c1 = sP + (j & 1) * (G::P1 + G::P2);
         const bf16* c2 = c1 + G::P1;
         bf16* n1 = sP + ((j & 1) ^ 1) * (G::P1 + G::P2);
 #pragma unroll
         for (int g = 0; g < G::HG; ++g) {
+            // Every LDS operand of the group is requested BEFORE its first MFMA: W1's KC fragments, the bias block (staged in LDS by
+            // the prologue -- as global loads at this point they put an s_waitcnt vmcnt(0), i.e. the whole L2 latency AND the wait
+            // for the next panel's prefetch, in front of the first MFMA of every group) and W2's 2 OG fragments, which do not depend
+            // on the hidden tile and land under the first product and the GELU.  Left to itself hipcc keeps one fragment register
+            // and emits ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma 24 times per panel: ~130 cycles of LDS latency per MFMA.
             // accumulator register t of this lane = hidden unit j HP + 32 g + 16 (t >> 3) + 8 half + (t & 7)
-            const float* bp = b1 + j * HP + 32 * g + 8 * half;
+            const bf16* wrow = c1 + (32 * g + swz23(r)) * G::LD1 + 8 * half;
+            Frag<bf16> wf[G::KC], vf[G::OG][2];
+#pragma unroll
+            for (int c = 0; c < G::KC; ++c) wf[c] = frag_load<bf16>(wrow + 16 * c);
+            const float* bp = sB1 + j * HP + 32 * g + 8 * half;
             const f32x4 ba = *reinterpret_cast<const f32x4*>(bp), bb = *reinterpret_cast<const f32x4*>(bp + 4);
             const f32x4 bc = *reinterpret_cast<const f32x4*>(bp + 16), bd = *reinterpret_cast<const f32x4*>(bp + 20);
-            f32x16 h = {ba[0], ba[1], ba[2], ba[3], bb[0], bb[1], bb[2], bb[3], bc[0], bc[1], bc[2], bc[3], bd[0], bd[1], bd[2], bd[3]};
-            const bf16* wrow = c1 + (32 * g + swz23(r)) * G::LD1 + 8 * half;
 #pragma unroll
-            for (int c = 0; c < G::KC; ++c) mma<bf16>(h, frag_load<bf16>(wrow + 16 * c), af[c]);
+            for (int o = 0; o < G::OG; ++o) {
+                const bf16* vrow = c2 + (32 * o + r) * G::LD2 + 32 * g + 8 * half;
+                vf[o][0] = frag_load<bf16>(vrow);
+                vf[o][1] = frag_load<bf16>(vrow + 16);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, G::KC + 4 + 2 * G::OG, 0);      // (all DS reads of the group first)
+            f32x16 h = {ba[0], ba[1], ba[2], ba[3], bb[0], bb[1], bb[2], bb[3], bc[0], bc[1], bc[2], bc[3], bd[0], bd[1], bd[2], bd[3]};
+#pragma unroll
+            for (int c = 0; c < G::KC; ++c) mma<bf16>(h, wf[c], af[c]);
 #pragma unroll
             for (int t = 0; t < 16; ++t) h[t] = gelu<bf16>(h[t]);
             const Frag<bf16> h0 = frag_from_acc<bf16>(h, 0), h1 = frag_from_acc<bf16>(h, 1);
 #pragma unroll
             for (int o = 0; o < G::OG; ++o) {
-                const bf16* vrow = c2 + (32 * o + r) * G::LD2 + 32 * g + 8 * half;
-                mma<bf16>(acc2[o], frag_load<bf16>(vrow), h0);
-                mma<bf16>(acc2[o], frag_load<bf16>(vrow + 16), h1);
+                mma<bf16>(acc2[o], vf[o][0], h0);
+                mma<bf16>(acc2[o], vf[o][1], h1);
             }
         }
+        if (j < 6) MLP_STAMP(3 + 3 * j);
         mlp_commit<C, HP>(n1, n1 + G::P1, preg, tid);               // panel j+1 (or a harmless repeat of the last one)
         mlp_fetch<C, HP>(preg, w1, w2, min(j + 2, G::NPAN - 1), tid);
+        if (j < 6) MLP_STAMP(4 + 3 * j);
         __syncthreads();
+        if (j < 6) MLP_STAMP(5 + 3 * j);
     }
+    MLP_STAMP(21);
     // ---- epilogue: acc2[o] register t = output feature 32 o + acc_row(t, half) of token r
     const int tok = lane >> 2, ch = lane & 3;
+    // every residual piece (and the two rows' StochasticDepth factors) is requested up front: inside the loop below -- whose waits
+    // are memory barriers for the compiler -- each of the 2 OG global loads was a round trip of its own in front of its store
+    Frag<bf16> resv[G::OG][2];
+    float rsc[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const long long grow = min(m_wave + tok + 16 * ps, M - 1);
+        rsc[ps] = row_scale ? row_scale[grow / rows_per_scale] : 1.0f;
+#pragma unroll
+        for (int o = 0; o < G::OG; ++o) resv[o][ps] = frag_load<bf16>(x + grow * C + 32 * o + 8 * ch);
+    }
+    f32x4 b2v[G::OG][4];
+#pragma unroll
+    for (int o = 0; o < G::OG; ++o)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) b2v[o][i4] = *reinterpret_cast<const f32x4*>(b2 + 32 * o + 8 * i4 + 4 * half);
+#ifdef MTMP_LAB_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MLP_STAMP(22);
+#endif
 #pragma unroll
     for (int o = 0; o < G::OG; ++o) {
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + 32 * o + 8 * i4 + 4 * half);
+            const f32x4 bv = b2v[o][i4];
             store4<bf16>(sS + r * G::FS + 8 * i4 + 4 * half, acc2[o][4 * i4] + bv[0], acc2[o][4 * i4 + 1] + bv[1],
                          acc2[o][4 * i4 + 2] + bv[2], acc2[o][4 * i4 + 3] + bv[3]);
         }
@@ -381,8 +432,8 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const f
             const int t = tok + 16 * ps;
             const long long grow = min(m_wave + t, M - 1);
             const Frag<bf16> v = frag_load<bf16>(sS + t * G::FS + 8 * ch);
-            const Frag<bf16> res = frag_load<bf16>(x + grow * C + 32 * o + 8 * ch);
-            const float rsv = row_scale ? row_scale[grow / rows_per_scale] : 1.0f;
+            const Frag<bf16> res = resv[o][ps];
+            const float rsv = rsc[ps];
             Frag<bf16> out;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -394,7 +445,18 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_kernel(const bf16* x, const f
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#ifdef MTMP_LAB_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MLP_STAMP(23);
+#endif
 }
+#ifdef MTMP_LAB_CLOCK
+}  // namespace
+extern "C" int mtmp_dbg_read_swin_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mtmp_dbg_swin_stamps), (size_t)n * sizeof(long long));
+}
+namespace {
+#endif
 
 template <int C, int HP>
 int launch_swin_mlp(const void* x, const float* ln_w, const float* ln_b, const void* w1, const float* b1, const void* w2,

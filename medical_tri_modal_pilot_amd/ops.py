@@ -876,6 +876,11 @@ class DataLinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         (x2,) = ctx.saved_tensors
         dy2 = _c(dy.reshape(-1, dy.shape[-1]).to(x2.dtype))
+        sk = _sink_dsts(ctx.prm) if tuning.FUSED_INPUT_TAIL else None
+        if sk is not None:            # the product's reduction writes the two slices of the flat gradient itself (no copy launch)
+            gemm_tn(dy2, x2, out=(sk[2][0].view(ctx.wshape), sk[2][1]))
+            sk[0].mark_ready(sk[1])
+            return None, None, None, None
         dw, db = gemm_tn(dy2, x2)
         gw, gb = sink_param_grads(ctx.prm, [dw.view(ctx.wshape), db])
         return None, gw, gb, None

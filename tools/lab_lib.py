@@ -27,7 +27,7 @@ def build():
         shutil.rmtree(os.path.join(LAB, name), ignore_errors=True)
         os.makedirs(d)
         for f in os.listdir(CSRC):
-            if f.endswith((".hip", ".cuh", ".cpp")) or f == "Makefile":
+            if f.endswith((".hip", ".h", ".cpp")) or f == "Makefile":
                 shutil.copy(os.path.join(CSRC, f), d)
         for f, old, new in reps:
             s = open(os.path.join(d, f)).read()
