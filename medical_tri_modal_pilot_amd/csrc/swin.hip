@@ -688,6 +688,27 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
             for (int s_ = 0; s_ < 2; ++s_) qf[tb][s_] = frag_from_acc<bf16>(qa[tb], s_);
     }
     __syncthreads();                                              // every wave is done with the normalised tokens
+    // Requested HERE, a phase ahead of their use: the residual pieces of the epilogue (in a branch per token block they were eight
+    // load -> s_waitcnt vmcnt(0) -> store round trips at the end of every workgroup: pad tokens read token 0 instead) and, where
+    // the registers allow (C = 96), the projection's weight fragments (read one fragment ahead, every second MFMA of the
+    // projection waited for an L2 round trip).
+    f32x4 resv[2][4];
+    long long pxv[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tq = 32 * tb + r;
+        pxv[tb] = pix(tq < L ? tq : 0);
+        const bf16* xr = x + pxv[tb] * C + head * DH + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) resv[tb][g] = load4<bf16>(xr + 8 * g);
+    }
+    constexpr bool PREW = KC <= 6;
+    const bf16* wpl = wproj + (size_t)(head * DH + r) * C + 8 * half;
+    Frag<bf16> wpf[PREW ? KC : 1];
+    if constexpr (PREW) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c) wpf[c] = frag_load<bf16>(wpl + 16 * c);
+    }
     // ---- per query block: S^T = K Q^T (rows = keys, cols = queries on lanes), * scale + bias / mask table, softmax over
     //      the rows, O^T = V^T P^T (rows = head dims), normalised, to LDS as [token][channel]
     const bf16* tab = table + ((size_t)type * HEADS + head) * LP * LP;
@@ -741,24 +762,28 @@ __global__ __launch_bounds__(2 * C, 3) void swin_attn_block_kernel(const bf16* x
 #pragma unroll
         for (int i = 0; i < 4; ++i) pa[0][4 * i4 + i] = pa[1][4 * i4 + i] = bp[i];
     }
-    const bf16* wpl = wproj + (size_t)(head * DH + r) * C + 8 * half;
-#pragma unroll UNR
-    for (int c = 0; c < KC; ++c) {
-        const Frag<bf16> wp = frag_load<bf16>(wpl + 16 * c);
+    if constexpr (PREW) {
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) mma<bf16>(pa[tb], wp, frag_load<bf16>(xl + 32 * tb * LDO + 16 * c));
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) mma<bf16>(pa[tb], wpf[c], frag_load<bf16>(xl + 32 * tb * LDO + 16 * c));
+    } else {
+#pragma unroll UNR
+        for (int c = 0; c < KC; ++c) {
+            const Frag<bf16> wp = frag_load<bf16>(wpl + 16 * c);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) mma<bf16>(pa[tb], wp, frag_load<bf16>(xl + 32 * tb * LDO + 16 * c));
+        }
     }
     const float sc = row_scale ? row_scale[img] : 1.0f;
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
         const int tq = 32 * tb + r;
         if (tq < L) {
-            const long long px = pix(tq);
-            const bf16* xr = x + px * C + head * DH + 4 * half;
-            bf16* yo = out + px * C + head * DH + 4 * half;
+            bf16* yo = out + pxv[tb] * C + head * DH + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 res = load4<bf16>(xr + 8 * g);
+                const f32x4 res = resv[tb][g];
                 // (rounded where mtmp_gemm_nt's epilogue rounds: the projection, its scaled value, then the sum)
                 float v[4];
 #pragma unroll
