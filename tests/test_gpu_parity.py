@@ -652,6 +652,83 @@ def test_stream_input_vs_torch_chain(ops, dt, use_pe):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("flat", [False, True])
+def test_stream_inputs_node_vs_three_stream_input_nodes(ops, dt, flat):
+    """ops.StreamInputsFn (the three streams' input kernels as ONE autograd node: mtmp_stream_input_bwd_grouped, mtmp_token_sums,
+    one mtmp_reduce_scatter -- into autograd tensors, or straight into an optim.FlatParams gradient buffer) against three
+    ops.StreamInputFn nodes with the time embeddings added through torch in front of them (the form of rounds 1-4, itself pinned by
+    test_stream_input_vs_torch_chain): outputs bit-identical (same forward launches), every gradient to rounding -- with dropout
+    (same seeds: same masks), a PACKED first stream, K = 2 images per sample (two time embeddings per sample's image tokens)."""
+    from medical_tri_modal_pilot_amd.optim import FlatParams
+    from oracle import tri_mbt_oracle as O
+    g = torch.Generator().manual_seed(11)
+    B, nb, K = 3, 4, 2
+    Ns = [37, 2 * 7, 9]
+    R = lambda *sh: torch.randn(*sh, generator=g)
+    xs = [R(B, n, 256).to(dt) for n in Ns]
+    add_i, add_t = R(B * K, 256).to(dt), R(B, 256).to(dt)
+    cls = [R(1, 1, 256) for _ in range(3)]
+    gam = [1 + 0.1 * R(256) for _ in range(3)]
+    bet = [0.1 * R(256) for _ in range(3)]
+    bott = R(1, nb, 256)
+    pe = [None, O.sinusoid_table(2500, 256)[:Ns[1] + 1], None]
+    ws = [R(B, nb + 1 + n, 256) for n in Ns]
+    kv = torch.tensor([nb + 1 + 37, nb + 1 + 5, nb + 1 + 20], dtype=torch.int32, device=DEV)
+    pack = ops.row_starts(kv, nb + 1 + Ns[0])
+    p_drop, seeds = 0.2, [17, 18, 19]
+
+    def leaves():
+        L = dict(x=[t.clone().to(DEV).requires_grad_() for t in xs], ai=add_i.clone().to(DEV).requires_grad_(),
+                 at=add_t.clone().to(DEV).requires_grad_())
+        mod = torch.nn.ParameterDict({f"cls{m}": torch.nn.Parameter(cls[m].clone()) for m in range(3)})
+        for m in range(3):
+            mod[f"g{m}"], mod[f"b{m}"] = torch.nn.Parameter(gam[m].clone()), torch.nn.Parameter(bet[m].clone())
+        mod["bott"] = torch.nn.Parameter(bott.clone())
+        return L, mod.to(DEV)
+
+    def loss_of(zs):
+        tot = 0.0
+        for m, z in enumerate(zs):
+            w = ws[m].to(DEV)
+            if m == 0:                                    # packed stream: rows pack[b] .. pack[b] + kv[b] of the same allocation
+                rows = torch.cat([int(pack[b]) + torch.arange(int(kv[b]), device=DEV) for b in range(B)])
+                tot = tot + (z.reshape(-1, 256)[rows].float() * w.reshape(-1, 256)[:rows.numel()]).sum()
+            else:
+                tot = tot + (z.float() * w).sum()
+        return tot
+
+    # (a) three nodes, adds through torch
+    La, Ma = leaves()
+    xa = [La["x"][0], (La["x"][1].view(B * K, Ns[1] // K, 256) + La["ai"].unsqueeze(1)).view(B, Ns[1], 256),
+          La["x"][2] + La["at"].unsqueeze(1)]
+    za = []
+    for m in range(3):
+        pk = (pack, kv) if m == 0 else (None, None)
+        za.append(ops.StreamInputFn.apply(xa[m], Ma[f"cls{m}"], Ma[f"g{m}"], Ma[f"b{m}"], None if pe[m] is None else pe[m].to(DEV),
+                                          Ma["bott"], 1e-5, p_drop, seeds[m], *pk))
+    loss_of(za).backward()
+    # (b) one node
+    Lb, Mb = leaves()
+    fl = FlatParams(Mb.named_parameters()) if flat else None
+    meta = dict(pe=[None if q is None else q.to(DEV) for q in pe], seeds=seeds, pack=(pack, kv), streams=None)
+    prm = [Mb[k] for m in range(3) for k in (f"cls{m}", f"g{m}", f"b{m}")]
+    zb = ops.StreamInputsFn.apply(Lb["x"][0], Lb["x"][1], Lb["x"][2], Mb["bott"], Lb["ai"], Lb["at"], 1e-5, 1e-5, 1e-5, p_drop, meta, *prm)
+    rows0 = torch.cat([int(pack[b]) + torch.arange(int(kv[b]), device=DEV) for b in range(B)])
+    assert torch.equal(za[0].reshape(-1, 256)[rows0], zb[0].reshape(-1, 256)[rows0]) and torch.equal(za[1], zb[1]) and torch.equal(za[2], zb[2])
+    loss_of(zb).backward()
+    if flat:                                            # the node wrote the ten slices itself and reported them
+        assert all(fl.index_of[id(q)] in fl.written for q in Mb.values())
+    t = f"stream_inputs_node[{str(dt)[6:]},flat={int(flat)}]"
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    for m in range(3):
+        check(f"{t}.dx{m}", Lb["x"][m].grad.float(), La["x"][m].grad.float(), tol)
+    check(t + ".d_add_img", Lb["ai"].grad.float(), La["ai"].grad.float(), tol)
+    check(t + ".d_add_txt", Lb["at"].grad.float(), La["at"].grad.float(), tol)
+    for k in Ma.keys():
+        check(f"{t}.d_{k}", Mb[k].grad, Ma[k].grad, 2e-5 if dt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_time_embed_and_data_linear_vs_torch(ops, dt):
     """ie_time(t) + ie_feat(18|19) (tri_mbt_vsltcls.py:216-224) and the Linear(768,256) projections of data tensors
     (:200, :205-211) against the torch modules they replace, forward and parameter gradients."""
