@@ -235,6 +235,18 @@ int mtmp_head_fwd(const float* cls, const float* age, const float* gender, const
 int mtmp_head_bwd(const float* d_out, const float* cls, const float* age, const float* gender, const void* const* params,
                   const float* ws_fwd, float* dcls, float* g_rows, float* dw1, float* g_feat, float* db2, float* ws_bwd, int B,
                   float ln_eps, int training, void* stream);
+/* The head with the CLS vectors in the fusion stack's own type (ABI 6): cls / dcls [B][256] in cls_dtype (no cast launch on either
+ * side of the head), num_batches_tracked (device int64, may be NULL) incremented by the first launch, and every parameter's
+ * gradient written to a destination of its own: dst[12] in the order of the 12 trained parameters of `params` (ie_demo.0.weight
+ * [256][2], ie_demo.0.bias, ie_demo.1.{weight,bias}, layer_norms_after_concat.{weight,bias}, fc_list.0.{weight,bias},
+ * fc_list.1.{weight,bias}, fc_list.3.{weight,bias}) -- slices of the flat gradient buffer, or scratch.  Same math, workspaces and
+ * limits as mtmp_head_fwd / mtmp_head_bwd. */
+int mtmp_head_fwd_t(int cls_dtype, const void* cls, const float* age, const float* gender, const void* const* params, float* out,
+                    float* ws, int B, float ln_eps, float bn_eps, float momentum, int training, long long* num_batches_tracked,
+                    void* stream);
+int mtmp_head_bwd_scatter(int cls_dtype, const float* d_out, const void* cls, const float* age, const float* gender,
+                          const void* const* params, const float* ws_fwd, void* dcls, float* const* dst, float* ws_bwd, int B,
+                          float ln_eps, int training, void* stream);
 
 /* BCEWithLogitsLoss(reduction="mean") (2_train.py:76, trainer.py:128): loss[0] = mean_b [max(o,0) - o t + log1p(exp(-|o|))],
  * dlogit[b] = (sigmoid(o_b) - t_b) / n; logits / target / dlogit float[n]. */

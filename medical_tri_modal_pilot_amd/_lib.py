@@ -93,6 +93,8 @@ SIGNATURES = {
     "mtmp_head_ws_floats": (c_int, [c_int]),
     "mtmp_head_fwd": (c_int, [c_void_p] * 6 + [c_int, c_float, c_float, c_float, c_int, c_void_p]),
     "mtmp_head_bwd": (c_int, [c_void_p] * 12 + [c_int, c_float, c_int, c_void_p]),
+    "mtmp_head_fwd_t": (c_int, [c_int] + [c_void_p] * 6 + [c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "mtmp_head_bwd_scatter": (c_int, [c_int] + [c_void_p] * 9 + [c_int, c_float, c_int, c_void_p]),
     "mtmp_bce_logits_mean": (c_int, [c_void_p] * 4 + [c_int, c_void_p]),
     "mtmp_timestamp": (c_int, [c_void_p, c_void_p]),
     "mtmp_swin_ln_linear": (c_int, [c_int] + [c_void_p] * 6 + [c_longlong, c_int, c_int, c_float, c_void_p]),

@@ -98,11 +98,13 @@ class BI_VSLTTXT_MBT_V1(nn.Module):
         fused_head = B <= ops.HEAD_MAX_B and "rmse" not in self.args.auxiliary_loss_type and (B > 1 or not self.training)
         if fused_head:                   # LN(cls) | ie_demo(age, gender) -> fc_list as six HIP launches (ops.HeadFn)
             bn, ln, dm = self.fc_list[1], self.layer_norms_after_concat, self.ie_demo
-            if bn.training and bn.track_running_stats:
-                bn.num_batches_tracked.add_(1)
+            nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+            if nbt is not None and not nbt.is_cuda:
+                nbt.add_(1)
+                nbt = None
             use_batch = bn.training or not bn.track_running_stats
             out = ops.HeadFn.apply(cls, age, gen, use_batch, 0.1 if bn.momentum is None else bn.momentum, bn.eps,
-                                   bn.running_mean, bn.running_var, dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias,
+                                   bn.running_mean, bn.running_var, nbt, dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias,
                                    ln.weight, ln.bias, self.fc_list[0].weight, self.fc_list[0].bias, bn.weight, bn.bias,
                                    self.fc_list[3].weight, self.fc_list[3].bias)
             return out.squeeze(), None, None

@@ -389,18 +389,22 @@ class TRI_MBT_VSLTCLS(nn.Module):
     def _head(self, outputs, demo_embedding, age, gen, missing, fused_head):
         """The classifier on the encoder's result (:248-255), fp32 -- a hook: sibling models read other rows."""
         cls = self.fusion_transformer.last_cls             # outputs[0][:, 0, :] as a dedicated autograd output
-        cls = (outputs[0][:, 0, :] if cls is None else cls).float()
+        cls = outputs[0][:, 0, :] if cls is None else cls
         ops.mark("stack.e")
         if fused_head:
+            # (the kernels read the CLS vectors in the fusion stack's type and count the batch themselves)
             bn, ln, dm = self.fc_list[1], self.layer_norms_after_concat, self.ie_demo
-            if bn.training and bn.track_running_stats:
-                bn.num_batches_tracked.add_(1)
+            nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+            if nbt is not None and not nbt.is_cuda:
+                nbt.add_(1)
+                nbt = None
             use_batch = bn.training or not bn.track_running_stats
             output1 = ops.HeadFn.apply(cls, age, gen, use_batch, 0.1 if bn.momentum is None else bn.momentum, bn.eps,
-                                       bn.running_mean, bn.running_var, dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias,
+                                       bn.running_mean, bn.running_var, nbt, dm[0].weight, dm[0].bias, dm[1].weight, dm[1].bias,
                                        ln.weight, ln.bias, self.fc_list[0].weight, self.fc_list[0].bias, bn.weight, bn.bias,
                                        self.fc_list[3].weight, self.fc_list[3].bias)
             return output1, None, None
+        cls = cls.float()
         class_input = self.layer_norms_after_concat(cls)
         if self.args.vslt_type != "QIE":
             class_input = torch.cat([class_input, demo_embedding], dim=1)

@@ -126,6 +126,11 @@ class TrimodalTransformerEncoder_MBT(nn.Module):
         # the model may have produced the image / text embeddings on the two side streams (inputs_on_side_streams):
         # their stream-input kernels stay there, and the main stream joins before the fusion stack
         side_in = self._side_streams(dev) if (fused_in and getattr(self, "inputs_on_side_streams", False)) else None
+        if side_in is None and getattr(self, "inputs_on_side_streams", False) and dev.type == "cuda":
+            # the image / text embeddings were produced on the side streams but this call takes a torch path on the caller's
+            # stream (uni-modal layers in front of the fusion layers, mixed dtypes): join them here
+            for s_ in self._side_streams(dev) or ():
+                torch.cuda.current_stream(dev).wait_stream(s_)
         # ``time_adds`` (set by the model for ONE call): the image / report time embeddings (it [n_i, 256], tt [n_t, 256]) still to be
         # added to every token of their group -- inside ops.StreamInputsFn when that node runs, here through torch otherwise
         time_adds, self.time_adds = getattr(self, "time_adds", None), None

@@ -33,12 +33,14 @@ struct HeadParams {
 };
 
 // x[b] = [LN(cls[b]) | ReLU(LN(age*w0 + gen*w1 + b))]; one wave per row, lane owns 4 columns of each half.
-__global__ __launch_bounds__(256) void head_x_kernel(const float* cls, const float* age, const float* gen, HeadParams p,
-                                                     float* x, int B, float eps) {
+template <typename TC>
+__global__ __launch_bounds__(256) void head_x_kernel(const TC* cls, const float* age, const float* gen, HeadParams p,
+                                                     float* x, int B, float eps, long long* nbt) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;          // BatchNorm1d.num_batches_tracked (one launch less in front of the head)
     if (b >= B) return;
     const int c = 4 * lane;
-    f32x4 v = *reinterpret_cast<const f32x4*>(cls + (size_t)b * D + c);
+    f32x4 v = load4<TC>(cls + (size_t)b * D + c);
     float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / D), d[4], sq = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { d[i] = v[i] - mean; sq += d[i] * d[i]; }
@@ -199,8 +201,11 @@ __global__ __launch_bounds__(256) void head_fc_bwd_kernel(const float* dout, con
 
 // row-parallel backward: workgroup = row b, thread = column k of each half of x.
 // slab row b: [dln_g | dln_b | ddemo_g | ddemo_be | ddemo_w0 | ddemo_w1 | ddemo_b] = 7 x 256
-__global__ __launch_bounds__(256) void head_x_bwd_kernel(const float* dh, const float* cls, const float* age, const float* gen,
-                                                         HeadParams p, float* dcls, float* slab, float eps) {
+// WIL: the two columns of ie_demo.0.weight's gradient interleaved in the slab row ([256][2], the parameter's own layout) instead of
+// as two rows of 256 -- the reduction then writes the parameter's gradient slice as it stands.
+template <typename TC, bool WIL>
+__global__ __launch_bounds__(256) void head_x_bwd_kernel(const float* dh, const TC* cls, const float* age, const float* gen,
+                                                         HeadParams p, TC* dcls, float* slab, float eps) {
     __shared__ float dhr[D];
     __shared__ float red[4];
     const int b = blockIdx.x, k = threadIdx.x;
@@ -215,13 +220,13 @@ __global__ __launch_bounds__(256) void head_x_bwd_kernel(const float* dh, const 
     float* row = slab + (size_t)b * 7 * D;
     // LayerNorm(cls) backward
     {
-        const float v = cls[(size_t)b * D + k];
+        const float v = to_f32(cls[(size_t)b * D + k]);
         const float mean = block_sum(v, red, k) * (1.0f / D);
         const float d = v - mean;
         const float rstd = rsqrtf(block_sum(d * d, red, k) * (1.0f / D) + eps);
         const float xh = d * rstd, gy = dxc * p.ln_g[k];
         const float m1 = block_sum(gy, red, k) * (1.0f / D), m2 = block_sum(gy * xh, red, k) * (1.0f / D);
-        dcls[(size_t)b * D + k] = rstd * (gy - m1 - xh * m2);
+        dcls[(size_t)b * D + k] = from_f32<TC>(rstd * (gy - m1 - xh * m2));
         row[k] = dxc * xh;
         row[D + k] = dxc;
     }
@@ -239,8 +244,13 @@ __global__ __launch_bounds__(256) void head_x_bwd_kernel(const float* dh, const 
         const float du = rstd * (gy - m1 - xh * m2);
         row[2 * D + k] = dyd * xh;
         row[3 * D + k] = dyd;
-        row[4 * D + k] = du * a;
-        row[5 * D + k] = du * g;
+        if (WIL) {
+            row[4 * D + 2 * k] = du * a;
+            row[4 * D + 2 * k + 1] = du * g;
+        } else {
+            row[4 * D + k] = du * a;
+            row[5 * D + k] = du * g;
+        }
         row[6 * D + k] = du;
     }
 }
@@ -252,6 +262,31 @@ __global__ __launch_bounds__(256) void head_rows_reduce_kernel(const float* slab
     float s = 0.f;
     for (int r = 0; r < rows; ++r) s += slab[(size_t)r * cols + c];
     out[c] = s;
+}
+
+// the same sums with every 256-column block of the slab going to a destination of its own (block i -> dst[i]; blocks 4 and 5 are
+// the interleaved ie_demo.0.weight gradient: one destination of 512)
+struct HeadDst { float* d[7]; };
+// (a block = 64 columns x 4 row lanes combined in a fixed order: 28 blocks -- as 7 blocks of 256 columns walking all rows one after
+//  the other, like head_rows_reduce_kernel, this launch took 16 us on the chain between the loss and the backward)
+__global__ __launch_bounds__(256) void head_rows_scatter_kernel(const float* slab, int rows, HeadDst t) {
+    __shared__ float part[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    int r = rl;
+    for (; r + 4 < rows; r += 8) {
+        s0 += slab[(size_t)r * 7 * D + c];
+        s1 += slab[(size_t)(r + 4) * 7 * D + c];
+    }
+    if (r < rows) s0 += slab[(size_t)r * 7 * D + c];
+    part[rl][cl] = s0 + s1;
+    __syncthreads();
+    if (rl == 0) {
+        const float s = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+        const int blk = c / D, k = c - blk * D;
+        if (blk == 5) t.d[4][D + k] = s;
+        else t.d[blk][k] = s;
+    }
 }
 
 // BCEWithLogitsLoss(reduction="mean") (2_train.py:76, trainer.py:128): loss = mean_b [max(o,0) - o t + log(1 + exp(-|o|))];
@@ -292,7 +327,7 @@ extern "C" int mtmp_head_fwd(const float* cls, const float* age, const float* ge
                  (const float*)params[12], (const float*)params[13]};
     hipStream_t st = (hipStream_t)stream;
     float* x = ws; float* hhat = x + (size_t)B * DX; float* rstd = hhat + (size_t)B * D; float* partial = rstd + D;
-    hipLaunchKernelGGL(head_x_kernel, dim3((B + 3) / 4), dim3(256), 0, st, cls, age, gender, p, x, B, ln_eps);
+    hipLaunchKernelGGL(head_x_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, st, cls, age, gender, p, x, B, ln_eps, (long long*)nullptr);
     MTMP_CHECK_LAUNCH("mtmp_head_fwd(x)");
     const int R = rows_per_lane(B);
     auto fc = R == 1 ? head_fc_kernel<1> : (R == 2 ? head_fc_kernel<2> : head_fc_kernel<4>);
@@ -322,9 +357,75 @@ extern "C" int mtmp_head_bwd(const float* d_out, const float* cls, const float* 
     hipLaunchKernelGGL(fcb, dim3(D / FPW), dim3(256), 0, st, d_out, x, hhat, rstd, p, dh, dw1, g_feat, g_feat + D, g_feat + 2 * D,
                        g_feat + 3 * D, db2, B, training);
     MTMP_CHECK_LAUNCH("mtmp_head_bwd(fc)");
-    hipLaunchKernelGGL(head_x_bwd_kernel, dim3(B), dim3(256), 0, st, (const float*)dh, cls, age, gender, p, dcls, slab, ln_eps);
+    hipLaunchKernelGGL((head_x_bwd_kernel<float, false>), dim3(B), dim3(256), 0, st, (const float*)dh, cls, age, gender, p, dcls, slab, ln_eps);
     MTMP_CHECK_LAUNCH("mtmp_head_bwd(x)");
     hipLaunchKernelGGL(head_rows_reduce_kernel, dim3(7), dim3(256), 0, st, (const float*)slab, B, 7 * D, g_rows);
     MTMP_CHECK_LAUNCH("mtmp_head_bwd(reduce)");
+    return MTMP_OK;
+}
+
+// The head with the CLS vectors in the fusion stack's own type (ABI 6): cls / dcls [B][256] in `cls_dtype` (MTMP_F32 | MTMP_BF16: no
+// cast launch on either side of the head), num_batches_tracked (int64 on the device, may be NULL) incremented by the first launch,
+// and every parameter's gradient written to a destination of its own -- dst[12] in the order of the 12 trained parameters
+// (ie_demo.0.weight [256][2], ie_demo.0.bias, ie_demo.1.weight, ie_demo.1.bias, layer_norms_after_concat.{weight,bias},
+// fc_list.0.{weight [256][512], bias}, fc_list.1.{weight, bias}, fc_list.3.{weight, bias}): slices of the flat gradient buffer,
+// or scratch.  ws_bwd: B*256 + B*7*256 floats.
+extern "C" int mtmp_head_fwd_t(int cls_dtype, const void* cls, const float* age, const float* gender, const void* const* params,
+                               float* out, float* ws, int B, float ln_eps, float bn_eps, float momentum, int training,
+                               long long* num_batches_tracked, void* stream) {
+    MTMP_CHECK_ARG(cls && age && gender && params && out && ws && B > 0 && B <= MAXB && (training == 0 || B > 1) &&
+                       (cls_dtype == 0 || cls_dtype == 1),
+                   "mtmp_head_fwd_t: bad argument (B=%d, needs 1 <= B <= %d, and B > 1 in training mode; dtype %d)", B, MAXB, cls_dtype);
+    HeadParams p{(const float*)params[0], (const float*)params[1], (const float*)params[2], (const float*)params[3],
+                 (const float*)params[4], (const float*)params[5], (const float*)params[6], (const float*)params[7],
+                 (const float*)params[8], (const float*)params[9], (float*)params[10], (float*)params[11],
+                 (const float*)params[12], (const float*)params[13]};
+    hipStream_t st = (hipStream_t)stream;
+    float* x = ws; float* hhat = x + (size_t)B * DX; float* rstd = hhat + (size_t)B * D; float* partial = rstd + D;
+    if (cls_dtype == 0)
+        hipLaunchKernelGGL(head_x_kernel<float>, dim3((B + 3) / 4), dim3(256), 0, st, (const float*)cls, age, gender, p, x, B, ln_eps,
+                           num_batches_tracked);
+    else
+        hipLaunchKernelGGL(head_x_kernel<bf16>, dim3((B + 3) / 4), dim3(256), 0, st, (const bf16*)cls, age, gender, p, x, B, ln_eps,
+                           num_batches_tracked);
+    MTMP_CHECK_LAUNCH("mtmp_head_fwd_t(x)");
+    const int R = rows_per_lane(B);
+    auto fc = R == 1 ? head_fc_kernel<1> : (R == 2 ? head_fc_kernel<2> : head_fc_kernel<4>);
+    hipLaunchKernelGGL(fc, dim3(D / FPW), dim3(256), 0, st, (const float*)x, p, hhat, rstd, partial, B, bn_eps, momentum, training);
+    MTMP_CHECK_LAUNCH("mtmp_head_fwd_t(fc)");
+    hipLaunchKernelGGL(head_out_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, p.b2, out, B, 64 * R);
+    MTMP_CHECK_LAUNCH("mtmp_head_fwd_t(out)");
+    return MTMP_OK;
+}
+extern "C" int mtmp_head_bwd_scatter(int cls_dtype, const float* d_out, const void* cls, const float* age, const float* gender,
+                                     const void* const* params, const float* ws_fwd, void* dcls, float* const* dst, float* ws_bwd,
+                                     int B, float ln_eps, int training, void* stream) {
+    MTMP_CHECK_ARG(d_out && cls && age && gender && params && ws_fwd && dcls && dst && ws_bwd && B > 0 && B <= MAXB &&
+                       (cls_dtype == 0 || cls_dtype == 1),
+                   "mtmp_head_bwd_scatter: bad argument (B=%d dtype %d)", B, cls_dtype);
+    for (int i = 0; i < 12; ++i) MTMP_CHECK_ARG(dst[i], "mtmp_head_bwd_scatter: destination %d is NULL", i);
+    HeadParams p{(const float*)params[0], (const float*)params[1], (const float*)params[2], (const float*)params[3],
+                 (const float*)params[4], (const float*)params[5], (const float*)params[6], (const float*)params[7],
+                 (const float*)params[8], (const float*)params[9], (float*)params[10], (float*)params[11],
+                 (const float*)params[12], (const float*)params[13]};
+    hipStream_t st = (hipStream_t)stream;
+    const float* x = ws_fwd; const float* hhat = x + (size_t)B * DX; const float* rstd = hhat + (size_t)B * D;
+    float* dh = ws_bwd; float* slab = dh + (size_t)B * D;
+    const int R = rows_per_lane(B);
+    auto fcb = R == 1 ? head_fc_bwd_kernel<1> : (R == 2 ? head_fc_bwd_kernel<2> : head_fc_bwd_kernel<4>);
+    hipLaunchKernelGGL(fcb, dim3(D / FPW), dim3(256), 0, st, d_out, x, hhat, rstd, p, dh, dst[6], dst[7], dst[8], dst[9], dst[10], dst[11],
+                       B, training);
+    MTMP_CHECK_LAUNCH("mtmp_head_bwd_scatter(fc)");
+    if (cls_dtype == 0)
+        hipLaunchKernelGGL((head_x_bwd_kernel<float, true>), dim3(B), dim3(256), 0, st, (const float*)dh, (const float*)cls, age, gender, p,
+                           (float*)dcls, slab, ln_eps);
+    else
+        hipLaunchKernelGGL((head_x_bwd_kernel<bf16, true>), dim3(B), dim3(256), 0, st, (const float*)dh, (const bf16*)cls, age, gender, p,
+                           (bf16*)dcls, slab, ln_eps);
+    MTMP_CHECK_LAUNCH("mtmp_head_bwd_scatter(x)");
+    // slab blocks: dln_g, dln_b, ddemo_g, ddemo_be, ddemo_w (two blocks, interleaved), ddemo_b
+    HeadDst t{{dst[4], dst[5], dst[2], dst[3], dst[0], nullptr, dst[1]}};
+    hipLaunchKernelGGL(head_rows_scatter_kernel, dim3(7 * D / 64), dim3(256), 0, st, (const float*)slab, B, t);
+    MTMP_CHECK_LAUNCH("mtmp_head_bwd_scatter(reduce)");
     return MTMP_OK;
 }

@@ -1026,24 +1026,31 @@ HEAD_MAX_B = 256        # rows per rank the head kernels take (csrc/head.hip: on
 
 class HeadFn(torch.autograd.Function):
     """tri_mbt_vsltcls.py:248-255 with the ie_demo chain of :59-76: logits [B,1] from the vital-sign CLS vector and
-    (age, gender).  apply(cls [B,256] fp32, age [B], gender [B], training, momentum, bn_eps, run_mean, run_var,
-    *12 parameters in include/mtmp.h order without the two running statistics)."""
+    (age, gender).  apply(cls [B,256] fp32 | bf16, age [B], gender [B], training, momentum, bn_eps, run_mean, run_var,
+    num_batches_tracked | None, *12 parameters in include/mtmp.h order without the two running statistics).  The CLS vectors are
+    read (and their gradient written) in the fusion stack's own type, BatchNorm's batch counter is incremented by the first
+    launch, and the backward's last launch writes the twelve gradients where they belong -- slices of the flat gradient buffer
+    when they can be overwritten (no cast, counter, stack and multi-tensor-copy launches around the head: five of the ~19
+    small launches between the fusion stack's forward and its backward)."""
 
     @staticmethod
-    def forward(ctx, cls, age, gender, training, momentum, bn_eps, run_mean, run_var, *prm):
+    def forward(ctx, cls, age, gender, training, momentum, bn_eps, run_mean, run_var, nbt, *prm):
         _gpu(cls)
         B = cls.shape[0]
         if B > HEAD_MAX_B:
             raise ValueError(f"HeadFn handles up to {HEAD_MAX_B} rows per rank (got {B})")
-        cls, age, gender = _c(cls.detach().float()), _c(age.detach().float()), _c(gender.detach().float())
+        cls = _c(cls.detach() if cls.dtype in (torch.float32, torch.bfloat16) else cls.detach().float())
+        age, gender = _c(age.detach().float()), _c(gender.detach().float())
         P = [_c(t.detach().float()) for t in prm]
         # order of include/mtmp.h: demo_w, demo_b, demo_g, demo_be, ln_g, ln_b, w1, b1, bn_g, bn_b, run_mean, run_var, w2, b2
         ptrs = P[:10] + [run_mean, run_var] + P[10:]
         table = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in ptrs])
         out = torch.empty(B, 1, dtype=torch.float32, device=cls.device)
         ws = torch.empty(_lib.lib().mtmp_head_ws_floats(B), dtype=torch.float32, device=cls.device)
-        call("mtmp_head_fwd", _p(cls), _p(age), _p(gender), ctypes.cast(table, ctypes.c_void_p), _p(out), _p(ws), B, 1e-5,
-             float(bn_eps), float(momentum), int(bool(training)), _stream())
+        if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+            raise TypeError("HeadFn: num_batches_tracked must be an int64 device tensor")
+        call("mtmp_head_fwd_t", _dt(cls), _p(cls), _p(age), _p(gender), ctypes.cast(table, ctypes.c_void_p), _p(out), _p(ws), B, 1e-5,
+             float(bn_eps), float(momentum), int(bool(training)), _p(nbt), _stream())
         ctx.save_for_backward(cls, age, gender, ws, run_mean, run_var, *P)
         ctx.training = bool(training)
         ctx.shapes = [t.shape for t in prm]
@@ -1057,20 +1064,19 @@ class HeadFn(torch.autograd.Function):
         ptrs = P[:10] + [run_mean, run_var] + P[10:]
         table = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in ptrs])
         d_out = _c(d_out.float().view(-1))
-        dcls = torch.empty(B, D_MODEL, dtype=torch.float32, device=dev)
-        g_rows = torch.empty(7, D_MODEL, dtype=torch.float32, device=dev)
-        dw1 = torch.empty(D_MODEL, 2 * D_MODEL, dtype=torch.float32, device=dev)
-        g_feat = torch.empty(4, D_MODEL, dtype=torch.float32, device=dev)
-        db2 = torch.empty(1, dtype=torch.float32, device=dev)
+        dcls = torch.empty(B, D_MODEL, dtype=cls.dtype, device=dev)
         wsb = torch.empty(B * D_MODEL * 8, dtype=torch.float32, device=dev)
-        call("mtmp_head_bwd", _p(d_out), _p(cls), _p(age), _p(gender), ctypes.cast(table, ctypes.c_void_p), _p(ws), _p(dcls),
-             _p(g_rows), _p(dw1), _p(g_feat), _p(db2), _p(wsb), B, 1e-5, int(ctx.training), _stream())
-        sh = ctx.shapes
-        grads = (torch.stack([g_rows[4], g_rows[5]], 1).view(sh[0]), g_rows[6], g_rows[2], g_rows[3],      # ie_demo
-                 g_rows[0], g_rows[1],                                                                      # LN after concat
-                 dw1.view(sh[6]), g_feat[0], g_feat[1], g_feat[2],                                          # fc0, bn
-                 g_feat[3].view(sh[10]), db2.view(sh[11]))                                                  # fc3
-        return (dcls, None, None, None, None, None, None, None) + tuple(sink_param_grads(ctx.prm, list(grads)))
+        sk = _sink_dsts(ctx.prm)
+        dsts = sk[2] if sk is not None else [torch.empty(t.numel(), dtype=torch.float32, device=dev) for t in ctx.prm]
+        dtab = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in dsts])
+        call("mtmp_head_bwd_scatter", _dt(cls), _p(d_out), _p(cls), _p(age), _p(gender), ctypes.cast(table, ctypes.c_void_p), _p(ws),
+             _p(dcls), ctypes.cast(dtab, ctypes.c_void_p), _p(wsb), B, 1e-5, int(ctx.training), _stream())
+        if sk is not None:
+            sk[0].mark_ready(sk[1])
+            grads = (None,) * 12
+        else:
+            grads = tuple(t.view(sh) for t, sh in zip(dsts, ctx.shapes))
+        return (dcls, None, None, None, None, None, None, None, None) + grads
 
 
 class BceLogitsMean(torch.autograd.Function):
@@ -1475,7 +1481,9 @@ def cls_layer_forward(z, kv_len, P, fused, drop_p, seeds, pack, cls_tok):
     o_cls, r1, lse = attn_cls_fwd(qkv, z, kv_len, pack, cls_tok)
     h, xn2, st2, hsign = ln_gemm(r1, g2, b2, w1c, c1, 4 * D, relu=True, drop_p=drop_p, seed=seeds[0], want_signs=True)
     out = gemm_nt(h, w2c, c2, res2d=r1, drop_p=drop_p, seed=seeds[1])
-    rows = pack[:B].long() + cls_tok if pack is not None else _cls_rows(B, N, cls_tok, z.device)
+    # the CLS rows of the stream buffer, for the backward's residual add: a packed stream's row starts AS THEY ARE (int32; the
+    # backward adds into the view that begins at row cls_tok -- `pack[:B].long() + cls_tok` was two launches in front of the head)
+    rows = pack[:B] if pack is not None else _cls_rows(B, N, cls_tok, z.device)
     return out, (z, kv_len, g1, g2, wqkvt, w1t, w2t, xn1, st1, qkv, o_cls, lse, r1, xn2, st2, h, drop_p, seeds, hsign, pack, rows, cls_tok)
 
 
@@ -1505,7 +1513,8 @@ def cls_layer_backward(saved, d_cls, sink=None, late=None):
     else:
         dwqkv, dbqkv = gemm_tn(dqkv, xn1, out=(sink.wqkv, sink.bqkv) if direct else None, defer=red)
         dz, dg1, db1 = gemm_lnbwd(dqkv, wqkvt, z2, st1, g1, d_res2d=None, gb_out=sink.gb1 if direct else None, defer=red)
-    dz.index_add_(0, rows, dr1)                        # r1 = z + o: the CLS rows' residual gradient
+    # r1 = z + o: the CLS rows' residual gradient (packed: `rows` are the samples' first rows, the CLS row lies cls_tok behind)
+    (dz[cls_tok:] if pack is not None else dz).index_add_(0, rows, dr1)
     if late is not None and red:
         late.append((red, sink if direct else None))
     else:
@@ -1877,6 +1886,14 @@ class FusionStackFn(torch.autograd.Function):
                     if sk is not None:
                         sk.flat.mark_ready(sk.idx)
             del late[m][:]
+        def zero_other_streams(nxt):
+            """zero gradient buffers of the streams a vslt-only layer skipped: ONE fill for both (views of one allocation)"""
+            buf = torch.zeros(B * sum(Ns[m] for m in range(1, n_s)), D_MODEL, dtype=dt, device=dev)
+            r0 = 0
+            for m in range(1, n_s):
+                nxt[m] = buf[r0:r0 + B * Ns[m]].view(B, Ns[m], D_MODEL)
+                r0 += B * Ns[m]
+
         for li in range(n_run - 1, -1, -1):
             ms = active[li]
             if not ((final and (cfg["vsltonly"] == 1 or cfg.get("first_only")) and li == L - 1)
@@ -1899,8 +1916,7 @@ class FusionStackFn(torch.autograd.Function):
                 mark(f"b{li}.g0.e")
                 saved[li] = None
                 if li > 0:
-                    for m in range(1, n_s):
-                        nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
+                    zero_other_streams(nxt)
                 dz = nxt
                 continue
             groups = launch_groups(ms, streams, saved[li][ms[0]][0])
@@ -1937,8 +1953,7 @@ class FusionStackFn(torch.autograd.Function):
             saved[li] = None
             # streams skipped by the vslt-only last layer re-enter here with zero gradient
             if len(ms) == 1 and li > 0:
-                for m in range(1, n_s):
-                    nxt[m] = torch.zeros(B, Ns[m], D_MODEL, dtype=dt, device=dev)
+                zero_other_streams(nxt)
             dz = nxt
         for m in range(3):                  # the first layer's reductions, on the stream their group ran on
             if late[m]:
