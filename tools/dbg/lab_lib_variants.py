@@ -33,3 +33,4 @@ VARIANTS = {
         };
         // The unit pipeline runs ACROSS""")],
 }
+
