@@ -387,7 +387,16 @@ int mtmp_stream_input_bwd_partials(int dtype, const void* dz, const void* x, con
 int mtmp_stream_input_bwd_grouped(int dtype, int n, const void* const* dz, const void* const* x, const float* const* cls,
                                   const float* const* gamma, const float* const* stats, void* const* dx, float* ws, const int* B,
                                   const int* N, const int* nb, const float* p, const unsigned* seed, const unsigned* seed_dev,
-                                  const int32_t* const* row_start, const int32_t* const* kv_len, void* stream);
+                                  const int32_t* const* row_start, const int32_t* const* kv_len, const void* const* add,
+                                  const int* add_L, void* stream);
+/* mtmp_stream_input_fwd with `add` [B N / add_L][256] (dtype; may be NULL): row (b N + t) / add_L is added to input token (b, t) in
+ * front of the LayerNorm, the sum rounded to dtype -- the time + modality embedding of the token's image / report
+ * (tri_mbt_vsltcls.py:216-224) without a torch add launch or a second copy of the tokens; mtmp_stream_input_bwd_grouped takes the
+ * same add / add_L (per stream, NULL entries allowed) and recomputes the sum; x then is the tensor WITHOUT the add. */
+int mtmp_stream_input_fwd_add(int dtype, const void* x, const float* cls, const float* gamma, const float* beta, const float* pe,
+                              const float* bott, void* out, float* stats, int B, int N, int nb, float eps, float p, unsigned seed,
+                              const unsigned* seed_dev, const int32_t* row_start, const int32_t* kv_len, const void* add,
+                              int add_L, void* stream);
 /* out[i][j][:] = sum_{t < L[i]} dx[i][j L[i] + t][:] (256 columns, fp32 accumulation, `dtype` in and out) for n <= 2 tensors in one
  * launch: the gradient of the per-image / per-report time embedding that was added to each of its L tokens
  * (tri_mbt_vsltcls.py:216-224) -- torch autograd's sum over the token axis.  rows[i] = output rows of tensor i.  HOST arrays. */

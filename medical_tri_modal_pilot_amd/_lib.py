@@ -52,7 +52,8 @@ SIGNATURES = {
     "mtmp_reduce_scatter": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     "mtmp_stream_input_slab_rows": (c_int, [c_int]),
     "mtmp_stream_input_bwd_partials": (c_int, [c_int] + [c_void_p] * 7 + [c_int] * 3 + [c_float, c_uint, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mtmp_stream_input_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 16),
+    "mtmp_stream_input_bwd_grouped": (c_int, [c_int, c_int] + [c_void_p] * 18),
+    "mtmp_stream_input_fwd_add": (c_int, [c_int] + [c_void_p] * 8 + [c_int] * 3 + [c_float, c_float, c_uint, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mtmp_token_sums": (c_int, [c_int, c_int] + [c_void_p] * 5),
     "mtmp_tie_bwd_slab_rows": (c_int, [c_int]),
     "mtmp_tie_time_embed_bwd_partials": (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int] + [c_void_p] * 6),

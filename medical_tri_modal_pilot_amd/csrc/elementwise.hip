@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const fl
                                                             const float* beta, const float* pe, const float* bott, T* out,
                                                             float* stats, int B, int N, int nb, float eps, float p,
                                                             unsigned seed0, const unsigned* seed_dev, const int* row_start,
-                                                            const int* kv_len) {
+                                                            const int* kv_len, const T* add = nullptr, int add_L = 1) {
+    // add [B * N / add_L][256] (or NULL): row (b N + t - 1) / add_L of it is added to token t of sample b before the LayerNorm, the sum
+    // rounded to T as the torch add it replaces rounds it -- the time + modality embedding of the token's image / report
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = nb + 1 + N;
     const f32x4 gm = ld4f(gamma + 4 * lane), be = ld4f(beta + 4 * lane);
@@ -143,7 +145,13 @@ __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const fl
             const f32x4 c = ld4f(cls + 4 * lane);                              // cls.to(x.dtype) then .float()
             v = f32x4{round_as<T>(c[0]), round_as<T>(c[1]), round_as<T>(c[2]), round_as<T>(c[3])};
         } else {
-            v = load4<T>(x + ((size_t)b * N + t - 1) * D + 4 * lane);
+            const size_t xr = (size_t)b * N + t - 1;
+            v = load4<T>(x + xr * D + 4 * lane);
+            if (add) {
+                const f32x4 av = load4<T>(add + (xr / add_L) * D + 4 * lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = round_as<T>(v[i] + av[i]);
+            }
         }
         const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / D);
         float d[4], sq = 0.f;
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void stream_in_fwd_kernel(const T* x, const fl
 template <typename T>
 MTMP_DEV void stream_in_bwd_body(const T* dz, const T* x, const float* cls, const float* gamma, const float* stats, T* dx, float* slab,
                                  int B, int N, int nb, float p, unsigned seed0, const unsigned* seed_dev, const int* row_start,
-                                 const int* kv_len, int block, int nblocks, float* lds) {
+                                 const int* kv_len, int block, int nblocks, float* lds, const T* add = nullptr, int add_L = 1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int R = nb + 1 + N;
     const f32x4 gm = ld4f(gamma + 4 * lane);
@@ -204,7 +212,13 @@ MTMP_DEV void stream_in_bwd_body(const T* dz, const T* x, const float* cls, cons
             const size_t grow = row_start ? (size_t)row_start[b] + min(r, max(kv_len[b] - 1, 0)) : (size_t)row;
             gg[k] = load4<T>(dz + grow * D + 4 * lane);
             const int t = max(r - nb, 0);
-            vv[k] = load4<T>(x + ((size_t)b * N + max(t - 1, 0)) * D + 4 * lane);
+            const size_t xr = (size_t)b * N + max(t - 1, 0);
+            vv[k] = load4<T>(x + xr * D + 4 * lane);
+            if (add) {                                                         // (the forward's input row: x + its group's add row, rounded to T)
+                const f32x4 av = load4<T>(add + (xr / add_L) * D + 4 * lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[k][i] = round_as<T>(vv[k][i] + av[i]);
+            }
             const size_t lnrow = (size_t)b * (N + 1) + t;
             mn[k] = stats[2 * lnrow]; rs[k] = stats[2 * lnrow + 1];
         }
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(256) void stream_in_bwd_kernel(const T* dz, const T
 // and write stream i's rows of the partial slab; the slabs lie back to back, so the bottleneck tokens' columns sum over all of them.
 constexpr int SI_MAX = 3;
 struct StreamInSeg { const void *dz, *x; const float *cls, *gamma, *stats; void* dx; float* slab; const int *row_start, *kv_len;
-                     int B, N, nb; float p; unsigned seed; };
+                     int B, N, nb; float p; unsigned seed; const void* add; int add_L; };
 struct StreamInGroup { StreamInSeg seg[SI_MAX]; int first[SI_MAX + 1]; const unsigned* seed_dev; };
 template <typename T>
 __global__ __launch_bounds__(256) void stream_in_bwd_grouped_kernel(StreamInGroup g) {
@@ -285,7 +299,8 @@ __global__ __launch_bounds__(256) void stream_in_bwd_grouped_kernel(StreamInGrou
     for (int k = 1; k < SI_MAX; ++k) i += (int)blockIdx.x >= g.first[k] ? 1 : 0;
     const StreamInSeg& q = g.seg[i];
     stream_in_bwd_body<T>((const T*)q.dz, (const T*)q.x, q.cls, q.gamma, q.stats, (T*)q.dx, q.slab, q.B, q.N, q.nb, q.p, q.seed,
-                          g.seed_dev, q.row_start, q.kv_len, (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], lds);
+                          g.seed_dev, q.row_start, q.kv_len, (int)blockIdx.x - g.first[i], g.first[i + 1] - g.first[i], lds,
+                          (const T*)q.add, q.add_L);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,6 +650,30 @@ extern "C" int mtmp_stream_input_fwd(int dtype, const void* x, const float* cls,
     return MTMP_OK;
 }
 
+// mtmp_stream_input_fwd with `add` [B N / add_L][256] (dtype, may be NULL): row (b N + t) / add_L is added to input token (b, t) in
+// front of the LayerNorm, the sum rounded to `dtype` (= the torch add it replaces: tri_mbt_vsltcls.py:216-224, the time + modality
+// embedding of the token's image / report); the backward (mtmp_stream_input_bwd_grouped with the same add) recomputes it.
+extern "C" int mtmp_stream_input_fwd_add(int dtype, const void* x, const float* cls, const float* gamma, const float* beta,
+                                         const float* pe, const float* bott, void* out, float* stats, int B, int N, int nb,
+                                         float eps, float p, unsigned seed, const unsigned* seed_dev, const int32_t* row_start,
+                                         const int32_t* kv_len, const void* add, int add_L, void* stream) {
+    MTMP_CHECK_ARG(x && cls && gamma && beta && out && stats && B > 0 && N > 0 && nb >= 0 && nb <= NB_MAX && (nb == 0 || bott) &&
+                       p >= 0.f && p < 1.f && (long long)B * (nb + 1 + N) < (1ll << 25) && (!row_start || kv_len) && add_L > 0 &&
+                       (!add || ((long long)B * N) % add_L == 0),
+                   "mtmp_stream_input_fwd_add: bad argument (B=%d N=%d nb=%d p=%f add_L=%d)", B, N, nb, p, add_L);
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = B * (nb + 1 + N), nbk = max(1, min((rows + 3) / 4, 2048));
+    if (dtype == 0)
+        hipLaunchKernelGGL(stream_in_fwd_kernel<float>, dim3(nbk), dim3(256), 0, st, (const float*)x, cls, gamma, beta, pe,
+                           bott, (float*)out, stats, B, N, nb, eps, p, seed, seed_dev, row_start, kv_len, (const float*)add, add_L);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(stream_in_fwd_kernel<bf16>, dim3(nbk), dim3(256), 0, st, (const bf16*)x, cls, gamma, beta, pe,
+                           bott, (bf16*)out, stats, B, N, nb, eps, p, seed, seed_dev, row_start, kv_len, (const bf16*)add, add_L);
+    else { mtmp_set_error("mtmp_stream_input_fwd_add: unknown dtype %d", dtype); return MTMP_ERR_ARG; }
+    MTMP_CHECK_LAUNCH("mtmp_stream_input_fwd_add");
+    return MTMP_OK;
+}
+
 // dx [B, N, 256] (dtype); grads float[7][256] = dgamma, dbeta, dcls, dbott[0..3] (rows past nb are zero),
 // overwritten; ws: mtmp_stream_input_ws_floats(B * (nb+1+N)) floats.  row_start / kv_len: dz is PACKED as the forward's output
 // was; dx stays padded (its pad rows are written as zeros).
@@ -723,7 +762,7 @@ extern "C" int mtmp_stream_input_bwd_grouped(int dtype, int n, const void* const
                                              const float* const* gamma, const float* const* stats, void* const* dx, float* ws,
                                              const int* B, const int* N, const int* nb, const float* p, const unsigned* seed,
                                              const unsigned* seed_dev, const int32_t* const* row_start,
-                                             const int32_t* const* kv_len, void* stream) {
+                                             const int32_t* const* kv_len, const void* const* add, const int* add_L, void* stream) {
     MTMP_CHECK_ARG(n > 0 && n <= SI_MAX && dz && x && cls && gamma && stats && dx && ws && B && N && nb && p && seed,
                    "mtmp_stream_input_bwd_grouped: bad argument (n=%d)", n);
     StreamInGroup g;
@@ -738,8 +777,11 @@ extern "C" int mtmp_stream_input_bwd_grouped(int dtype, int n, const void* const
                                nb[k] <= NB_MAX && p[k] >= 0.f && p[k] < 1.f && (long long)B[k] * (nb[k] + 1 + N[k]) < (1ll << 25) &&
                                (!rs || kv),
                            "mtmp_stream_input_bwd_grouped: bad stream %d (B=%d N=%d nb=%d p=%f)", k, B[k], N[k], nb[k], p[k]);
+            const void* ad = add ? add[k] : nullptr;
+            const int aL = (ad && add_L) ? add_L[k] : 1;
+            MTMP_CHECK_ARG(aL > 0 && (!ad || ((long long)B[k] * N[k]) % aL == 0), "mtmp_stream_input_bwd_grouped: stream %d: add rows of %d tokens do not divide B N", k, aL);
             g.seg[i] = StreamInSeg{dz[k], x[k], cls[k], gamma[k], stats[k], dx[k], ws + (size_t)total * 7 * D, rs, kv,
-                                   B[k], N[k], nb[k], p[k], seed[k]};
+                                   B[k], N[k], nb[k], p[k], seed[k], ad, aL};
             g.first[i] = total;
             total += stream_in_bwd_blocks(B[k] * (nb[k] + 1 + N[k]));
         } else {

@@ -1215,12 +1215,12 @@ class StreamInputsFn(torch.autograd.Function):
             with (torch.cuda.stream(streams[m]) if streams[m] is not None else contextlib.nullcontext()):
                 x = xs[m]
                 B, N, _ = x.shape
-                n_add = 0
-                if adds[m] is not None:
+                n_add, add = 0, None
+                if adds[m] is not None:                 # added to the tokens inside the kernels (both ways): no launch, no second copy
                     n_add = adds[m].shape[0]
                     if n_add % B or N % (n_add // B):
                         raise ValueError("StreamInputsFn: the time embeddings do not divide the stream's tokens")
-                    x = (x.reshape(n_add, N // (n_add // B), D_MODEL) + adds[m].to(x.dtype).unsqueeze(1)).view(B, N, D_MODEL)
+                    add = _c(adds[m].detach().to(x.dtype))
                 x = _c(x)
                 cls_f, g_f, b_f = _c(cls.detach().float().view(-1)), _c(ln_w.detach().float()), _c(ln_b.detach().float())
                 pe = meta["pe"][m]
@@ -1231,11 +1231,12 @@ class StreamInputsFn(torch.autograd.Function):
                 out = torch.empty(B, nb + 1 + N, D_MODEL, dtype=x.dtype, device=x.device)
                 stats = torch.empty(B * (N + 1), 2, dtype=torch.float32, device=x.device)
                 seed = int(meta["seeds"][m]) & 0xFFFFFFFF
-                call("mtmp_stream_input_fwd", _dt(x), _p(x), _p(cls_f), _p(g_f), _p(b_f), _p(pe_f), _p(bott_f), _p(out), _p(stats),
-                     B, N, nb, float(epss[m]), float(p), seed, _p(_seed_word), _p(pack), _p(kv), _stream())
+                call("mtmp_stream_input_fwd_add", _dt(x), _p(x), _p(cls_f), _p(g_f), _p(b_f), _p(pe_f), _p(bott_f), _p(out), _p(stats),
+                     B, N, nb, float(epss[m]), float(p), seed, _p(_seed_word), _p(pack), _p(kv), _p(add),
+                     B * N // n_add if n_add else 1, _stream())
             outs.append(out)
             saved += [x, cls_f, g_f, stats]
-            geo.append((B, N, seed, pack, kv, n_add))
+            geo.append((B, N, seed, pack, kv, n_add, add))
         ctx.save_for_backward(*saved)
         ctx.meta = (nb, float(p), geo, bott.shape, [t.shape for t in prm])
         ctx.prm = list(prm) + [bott]
@@ -1263,7 +1264,9 @@ class StreamInputsFn(torch.autograd.Function):
              PV(*[sv[4 * m + 3].data_ptr() for m in live]), PV(*[dxs[m].data_ptr() for m in live]), _p(ws),
              IV(*[geo[m][0] for m in live]), IV(*[geo[m][1] for m in live]), IV(*([nb] * n)), FV(*([p] * n)),
              UV(*[geo[m][2] for m in live]), _p(_seed_word), PV(*[None if geo[m][3] is None else geo[m][3].data_ptr() for m in live]),
-             PV(*[None if geo[m][4] is None else geo[m][4].data_ptr() for m in live]), _stream())
+             PV(*[None if geo[m][4] is None else geo[m][4].data_ptr() for m in live]),
+             PV(*[None if geo[m][6] is None else geo[m][6].data_ptr() for m in live]),
+             IV(*[geo[m][0] * geo[m][1] // geo[m][5] if geo[m][5] else 1 for m in live]), _stream())
         # the time embeddings' gradient: sums over each group's tokens (both tensors in one launch), for the embedding node behind
         d_add = [None, None, None]
         ts = [m for m in live if geo[m][5] > 0 and ctx.needs_input_grad[3 + m]]
